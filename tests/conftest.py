@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name + ".npz"))
+    return load
+
+
+def rel_l1(a, b):
+    """sum|a-b| / sum|b| - the parity metric of BASELINE.md §3."""
+    import torch
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    return float((a - b).abs().sum() / b.abs().sum().clamp_min(1e-300))
