@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py - depth-maps/s of the CER-MVS depth-inference hot path on MI355X.
+
+A "step" is one test-mode RAFT.forward (one depth map: 1 reference + V source views already resident in
+HBM -> disparity in HBM) at BASELINE.json configs[1]: DTU 1600x1184, 10 source views, 32 GRU iterations
+(cascade (64,64,16),(-1,320,16)), synthetic images + closed-form weights, fp32 end to end.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1 (configs[3]): the V source views of ONE reference frame are sharded over the ranks
+(rank g owns views v with (v-1) % N == g); each rank builds its partial view-sum cost volume and the
+level-0 volume is all-reduced (RCCL over xGMI) once per cascade stage; the GRU loop is replicated.
+Total work is fixed as N grows => "scaling": "strong".  `--mode replica` instead runs N independent
+depth maps (one per rank, no collective, weak scaling).
+
+Rank 0 prints ONE JSON line (see the README of this file's contract in DESIGN.md §Measurement): besides
+the driver's keys it carries
+  "roofline":     the dominant kernel (the z|r gate convolution, MFMA-bound) - algorithmic FLOPs per launch
+                  divided by its average launch duration measured with HIP events on its stream,
+  "cpu_baseline": the oracle (a CPU port of the reference's torch op sequence) timed on this box's host
+                  cores on a bounded sample of the same workload, extrapolated to depth-maps/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+WORKLOADS = {
+    # name: (H, W, V, cascade)
+    "dtu_1600x1184_v10_it32": (1184, 1600, 10, [(64, 64, 16), (-1, 320, 16)]),
+    "dtu_640x480_v2_it4": (480, 640, 2, [(64, 64, 2), (-1, 320, 2)]),
+    "blended_2048x1536_v7_it16": (1536, 2048, 7, [(64, 64, 8), (-1, 320, 8)]),
+}
+FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="dtu_1600x1184_v10_it32", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="shard", choices=["shard", "replica"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "amp"])
+    return ap.parse_args()
+
+
+def kernel_timing(model, inputs, scale):
+    """One extra, instrumented forward: HIP events (on the launch stream = torch's current stream) around every
+    kernel class of the inner loop.  Returns {name: (launches, total_ms)}."""
+    from cer_mvs_amd import ops
+    records = {}
+    pending = []
+    originals = {}
+
+    def wrap(name, fn, label=None):
+        def inner(*a, **k):
+            key = label(*a, **k) if label else name
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            pending.append((key, e0, e1))
+            return out
+        return inner
+
+    def conv_label(pc, srcs, h, w, epi, **k):
+        return {0: "conv3x3_linear", 1: f"conv3x3_relu_{pc.cout}", 2: "conv3x3_gates_zr", 3: "conv3x3_gru_q"}[epi]
+
+    for name in ("cost_build", "pyramid", "lookup_encode", "delta_tail"):
+        originals[name] = getattr(ops, name)
+        setattr(ops, name, wrap(name, originals[name]))
+    originals["conv3x3"] = ops.conv3x3
+    ops.conv3x3 = wrap("conv3x3", originals["conv3x3"], conv_label)
+    try:
+        with torch.no_grad():
+            model(*inputs, scale=scale)
+        torch.cuda.synchronize()
+    finally:
+        for name, fn in originals.items():
+            setattr(ops, name, fn)
+    for key, e0, e1 in pending:
+        n, t = records.get(key, (0, 0.0))
+        records[key] = (n + 1, t + e0.elapsed_time(e1))
+    return records
+
+
+def cpu_baseline(H, W, V, cascade, sd):
+    """Oracle (CPU port of the reference's torch op sequence) on a bounded sample, extrapolated to one depth map."""
+    from oracle import cer_oracle as O
+    from cer_mvs_amd.synthetic import synthetic_scene
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    h, w = H // 4, W // 4
+    P = h * w
+    images, poses, intr, _ = synthetic_scene(H, W, 1, seed=0)
+    imgs = images[0].float() * (2 / 255.0) - 1
+    intr_f = intr[0].clone()
+    intr_f[:, :2] /= 4
+    stages = O.resolve_cascade(cascade)
+    t = {}
+    with torch.no_grad():
+        O.encoder(imgs[0:1, :, :64, :64], sd, "fnet.", "instance")            # warm the thread pool
+        t0 = time.perf_counter()
+        fm = torch.cat([O.encoder(imgs[i:i + 1], sd, "fnet.", "instance") for i in range(2)], 0)
+        t["enc_per_image"] = (time.perf_counter() - t0) / 2
+        disp = torch.full((h, w), 0.0015)
+        t["build_per_view"] = []
+        for s, (D, incre, T) in enumerate(stages):
+            t0 = time.perf_counter()
+            vol, origin = O.cost_volume(fm, poses[0], intr_f, D, incre, disp, shift=(s == 0))
+            levels = O.pyramid(vol, 3)
+            t["build_per_view"].append(time.perf_counter() - t0)
+        # one lookup (all V views: cost is value-independent, so tile the 1-view pyramid) + one update iteration
+        D, incre, _ = stages[-1]
+        lv = [l.expand(V, -1, -1).contiguous() for l in levels]
+        net = torch.zeros(1, 64, h, w)
+        inp = torch.zeros(1, 64, h, w)
+        d4 = disp.view(1, 1, h, w)
+        t0 = time.perf_counter()
+        feats = O.lookup(lv, origin, disp, D, incre, 5)
+        t["lookup_per_iter"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.update_block(sd, net, inp, d4, feats, 1)
+        t["update_per_iter"] = time.perf_counter() - t0
+    iters = sum(T for _, _, T in stages)
+    total = (V + 2) * t["enc_per_image"] + V * sum(t["build_per_view"]) + iters * (t["lookup_per_iter"] + t["update_per_iter"])
+    sample_s = 2 * t["enc_per_image"] + sum(t["build_per_view"]) + t["lookup_per_iter"] + t["update_per_iter"]
+    return {
+        "value": 1.0 / total, "unit": "depth-maps/s", "cores": cores, "kind": "port",
+        "sample": (f"oracle/cer_oracle.py at {W}x{H}: 2 fnet passes, 1-view cost volume + pyramid for both stages, "
+                   f"1 lookup over {V} views + 1 update-block iteration ({sample_s:.1f} s measured); extrapolated to "
+                   f"{V + 2} encoder passes, {V} views x 2 stages, {iters} iterations = {total:.1f} s per depth map"),
+        "seconds_per_depth_map": total,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        group = dist.group.WORLD
+
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+
+    H, W, V, cascade = WORKLOADS[args.workload]
+    shard = world > 1 and args.mode == "shard"
+    model = RAFT(cascade=cascade, test_mode=True, precision=args.precision, view_group=group if shard else None)
+    sd = fill_state_dict(model.state_dict(), seed=5)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    seed = 0 if (shard or world == 1) else rank          # replicas: a different reference frame per rank
+    images, poses, intr, scale = synthetic_scene(H, W, V, seed=seed)
+    inputs = (images.to(dev), poses.to(dev), intr.to(dev))
+
+    def sync():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = model(*inputs, scale=scale)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = model(*inputs, scale=scale)
+        sync()
+        elapsed = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+    maps = args.steps * (world if (world > 1 and not shard) else 1)
+
+    result = None
+    if rank == 0:
+        P = (H // 4) * (W // 4)
+        rec = kernel_timing(model, inputs, scale)
+        kern = {k: {"launches": n, "avg_us": 1e3 * t / n, "total_ms": t} for k, (n, t) in sorted(rec.items())}
+        n_zr, t_zr = rec["conv3x3_gates_zr"]
+        flops_zr = 2.0 * 9 * (64 + 49 + 64) * 128 * P            # algorithmic (unpadded K = net|disp49|corr), DESIGN.md
+        achieved = flops_zr / (t_zr / n_zr * 1e-3) / 1e12
+        roofline = {"kernel": "conv3x3_kernel<2,2,4,4,GATES> (z|r gates, 3x3, K=177, N=128)", "bound": "mfma",
+                    "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                    "traffic": None, "avg_launch_us": 1e3 * t_zr / n_zr, "launches": n_zr, "flops_per_launch": flops_zr}
+        result = {
+            "metric": "depth-maps/sec (ref+N src views) at DTU 1600x1184; HBM GB/s vs roofline",
+            "value": maps / elapsed, "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong" if (shard or world == 1) else "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f32 (encoders f16 autocast)", "data": "synthetic",
+            "config": {"workload": args.workload, "image": f"{W}x{H}", "src_views": V, "cascade": cascade,
+                       "gru_iters": sum(c[2] for c in cascade),
+                       "parallelism": "single" if world == 1 else (f"view-shard x{world} + all-reduce/stage" if shard else f"replica x{world}")},
+            "roofline": roofline, "kernels": kern,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(H, W, V, cascade, {k: v.cpu() for k, v in sd.items()})
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

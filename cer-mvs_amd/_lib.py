@@ -1,0 +1,100 @@
+"""ctypes binding of csrc/libcermvs.so (the C ABI in include/cer_mvs.h).
+
+There is deliberately NO fallback: if the shared library is missing, cannot be loaded, or
+reports no HIP device when an op is called, a RuntimeError is raised."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcermvs.so")
+ABI_VERSION = 1000
+CONV_MAX_SRC = 4
+EPI_LINEAR, EPI_RELU, EPI_GATES, EPI_GRU = 0, 1, 2, 3
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_L = _c.c_long
+_F = _c.c_float
+
+
+class ConvInputs(ctypes.Structure):
+    _fields_ = [("src", _P * CONV_MAX_SRC), ("ch", _I * CONV_MAX_SRC), ("kind", _I * CONV_MAX_SRC), ("nsrc", _I)]
+
+
+_SIGNATURES = {
+    "cer_abi_version": (_I, []),
+    "cer_error_string": (_c.c_char_p, [_I]),
+    "cer_device_count": (_I, []),
+    "cer_alt_corr_forward_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "cer_alt_corr_backward_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "cer_cost_build_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
+    "cer_pyramid_f32": (_I, [_P, _L, _I, _I, _I, _F, _P]),
+    "cer_corr_lookup_f32": (_I, [_P, _P, _P, _L, _P, _I, _L, _I, _I, _F, _I, _I, _P]),
+    "cer_corr_encode_f32": (_I, [_P, _P, _P, _P, _I, _I, _L, _I, _P]),
+    "cer_lookup_encode_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _I, _I, _P]),
+    "cer_conv3x3_packed_size": (_L, [_I, _I]),
+    "cer_conv3x3_pack_f32": (_I, [_P, _P, _I, _I, _c.POINTER(_I), _c.POINTER(_I), _I]),
+    "cer_conv3x3_f32": (_I, [_c.POINTER(ConvInputs), _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cer_delta_tail_f32": (_I, [_P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
+    "cer_nchw_to_nhwc_f32": (_I, [_P, _P, _I, _L, _F, _P]),
+    "cer_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _L, _F, _P]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names every build of the library must export (mirrors include/cer_mvs.h)."""
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """Load (once) and return the ctypes library; never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"cer-mvs_amd: HIP library not found at {LIB_PATH}. Build it with `make -C cer-mvs_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the host's ROCm install
+        raise RuntimeError(f"cer-mvs_amd: cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"cer-mvs_amd: {LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cer_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"cer-mvs_amd: ABI mismatch (library {lib.cer_abi_version()}, python {ABI_VERSION}); rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().cer_error_string(rc).decode()
+        raise RuntimeError(f"cer-mvs_amd: {what} failed with code {rc}: {msg}")
+
+
+def dev_ptr(t, name, dtype=torch.float32):
+    """Device pointer of a dense CUDA tensor - the reference's CHECK_INPUT (correlation.cpp:19-21)."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def cur_stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

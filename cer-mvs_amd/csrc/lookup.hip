@@ -1,0 +1,219 @@
+// K2: multi-level correlation lookup (reference: CorrBlock.__call__ core/corr.py:102-143 and
+// bilinear_sampler1 utils/bilinear_sampler.py:6-25 - 528 grid_sample launches per GRU iteration in
+// the reference), optionally fused with the view mean (core/update.py:103) and the first
+// corr_encoder layer (core/update.py:61-62: Conv2d(33,64,1) + ReLU).
+//
+// HBM-bound: per pixel one volume row (level0|level1|level2, e.g. 112 floats) is read and
+// L*(2r+1) = 33 floats (or 64 encoded floats) are written.  A block stages 64 consecutive rows
+// into LDS with coalesced 16-B loads; each thread then owns (pixel, level-slice) windows.
+#include "common.hpp"
+
+#define LK_PIX 64          // pixels per block
+#define LK_MAX_ROW 256     // max row_stride (floats)
+#define LK_MAX_TAPS 64     // max L*(2r+1)
+
+struct LevelInfo {
+    int off[8];
+    int len[8];
+};
+
+__device__ __forceinline__ float lk_index(float disp, float origin, float incre, int D) {
+    // core/corr.py:107 - true division then + D//2, lower clamp only
+    const float c = __fadd_rn(__fdiv_rn(__fsub_rn(disp, origin), incre), (float)(D / 2));
+    return fmaxf(c, 0.0f);    // NaN -> 0 like torch.maximum? (torch.maximum propagates NaN; disp is never NaN on this path)
+}
+
+// one window of 2r+1 taps on level `lv` of the LDS row
+__device__ __forceinline__ void lk_window(const float* __restrict__ row, int off, int len, float x, int r, float* __restrict__ o) {
+    // x = c / 2^lv (exact); taps at x + dx, dx = -r..r; zero outside [0, len-1] (grid_sample zeros padding, align_corners)
+    const float fx = floorf(x);
+    const float w = x - fx;
+    const bool in_range = fx < (float)(len + r + 1);         // else every tap is outside
+    const int i0 = in_range ? (int)fx - r : 0;
+    float prev = 0.f;
+    {
+        const int i = i0;
+        prev = (in_range && i >= 0 && i < len) ? row[off + i] : 0.f;
+    }
+    for (int j = 0; j < 2 * r + 1; ++j) {
+        const int i = i0 + j + 1;
+        const float next = (in_range && i >= 0 && i < len) ? row[off + i] : 0.f;
+        o[j] = prev * (1.0f - w) + next * w;
+        prev = next;
+    }
+}
+
+// out [nv, L*(2r+1), P] planar
+__global__ __launch_bounds__(256) void lookup_kernel(const float* __restrict__ vol, const float* __restrict__ origin,
+                                                     const float* __restrict__ disp, long dvs, float* __restrict__ out, long P, int D,
+                                                     int rs, float incre, int L, int r, LevelInfo li) {
+    extern __shared__ __attribute__((aligned(16))) float lk_smem[];
+    float* rows = lk_smem;                                   // [LK_PIX][rs + 4]
+    const int v = blockIdx.y;
+    const long p0 = (long)blockIdx.x * LK_PIX;
+    const int npix = (int)min((long)LK_PIX, P - p0);
+    const int rsp = rs + 4;                                  // padded LDS stride: rs % 32 == 16 or 0 -> +4 breaks the conflict pattern
+    // stage rows: rs/4 float4 per row
+    const float* src = vol + ((long)v * P + p0) * rs;
+    const int n4 = rs / 4;
+    for (int t = threadIdx.x; t < npix * n4; t += 256) {
+        const int pr = t / n4, q = t - pr * n4;
+        const float4 val = cer_ld4(src + (long)pr * rs + 4 * q);
+        *reinterpret_cast<float4*>(&rows[pr * rsp + 4 * q]) = val;
+    }
+    __syncthreads();
+    const int taps = 2 * r + 1;
+    // thread -> (pixel = tid & 63, level = tid >> 6 ...) : levels strided over the 4 waves
+    const int pix = threadIdx.x & 63;
+    if (pix >= npix) return;
+    const long p = p0 + pix;
+    const float c = lk_index(disp[(long)v * dvs + p], origin[p], incre, D);
+    for (int lv = threadIdx.x >> 6; lv < L; lv += 4) {
+        float o[32];
+        const float x = c / (float)(1 << lv);
+        lk_window(&rows[pix * rsp], li.off[lv], li.len[lv], x, r, o);
+        float* dst = out + ((long)v * L * taps + (long)lv * taps) * P + p;
+        for (int j = 0; j < taps; ++j) dst[(long)j * P] = o[j];
+    }
+}
+
+// fused: lookup on the folded volume + 1x1 conv (taps_total -> 64) + bias + ReLU, out [P,64] NHWC
+__global__ __launch_bounds__(256) void lookup_encode_kernel(const float* __restrict__ vol, const float* __restrict__ origin,
+                                                            const float* __restrict__ disp, const float* __restrict__ wgt,
+                                                            const float* __restrict__ bias, float* __restrict__ out, long P, int D, int rs,
+                                                            float incre, int L, int r, LevelInfo li) {
+    extern __shared__ __attribute__((aligned(16))) float lk_smem[];
+    const int rsp = rs + 4;
+    const int taps = 2 * r + 1, K = L * taps;
+    float* rows = lk_smem;                                   // [LK_PIX][rs + 4]
+    float* wsm = rows + LK_PIX * rsp;                        // [K][64]
+    float* feats = wsm + K * 64;                             // [LK_PIX][LK_MAX_TAPS + 1]
+    const long p0 = (long)blockIdx.x * LK_PIX;
+    const int npix = (int)min((long)LK_PIX, P - p0);
+    const float* src = vol + p0 * rs;
+    const int n4 = rs / 4;
+    for (int t = threadIdx.x; t < npix * n4; t += 256) {
+        const int pr = t / n4, q = t - pr * n4;
+        *reinterpret_cast<float4*>(&rows[pr * rsp + 4 * q]) = cer_ld4(src + (long)pr * rs + 4 * q);
+    }
+    for (int t = threadIdx.x; t < K * 64; t += 256) wsm[t] = wgt[t];
+    __syncthreads();
+    const int pix = threadIdx.x & 63;
+    const int grp = threadIdx.x >> 6;           // wave id: also the output-channel group (16 channels each)
+    if (pix < npix) {
+        const long p = p0 + pix;
+        const float c = lk_index(disp[p], origin[p], incre, D);
+        for (int lv = grp; lv < L; lv += 4) {
+            float o[32];
+            lk_window(&rows[pix * rsp], li.off[lv], li.len[lv], c / (float)(1 << lv), r, o);
+            for (int j = 0; j < taps; ++j) feats[pix * (LK_MAX_TAPS + 1) + lv * taps + j] = o[j];
+        }
+    }
+    __syncthreads();
+    if (pix >= npix) return;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = bias[grp * 16 + j];
+    for (int k = 0; k < K; ++k) {
+        const float f = feats[pix * (LK_MAX_TAPS + 1) + k];
+        const float* wr = &wsm[k * 64 + grp * 16];       // wave-uniform address: LDS broadcast
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = fmaf(f, wr[j], acc[j]);
+    }
+    float* dst = out + (p0 + pix) * 64 + grp * 16;
+#pragma unroll
+    for (int j = 0; j < 16; j += 4)
+        *reinterpret_cast<float4*>(dst + j) =
+            make_float4(fmaxf(acc[j], 0.f), fmaxf(acc[j + 1], 0.f), fmaxf(acc[j + 2], 0.f), fmaxf(acc[j + 3], 0.f));
+}
+
+static int level_info(int D, int rs, int L, int r, LevelInfo* li) {
+    if (L <= 0 || L > 8 || r < 0 || r > 15 || L * (2 * r + 1) > LK_MAX_TAPS) return CER_ESHAPE;
+    if (rs % 4 != 0 || rs > LK_MAX_ROW) return CER_ESHAPE;
+    int off = 0, n = D;
+    for (int l = 0; l < L; ++l) {
+        li->off[l] = off;
+        li->len[l] = n;
+        off += n;
+        n /= 2;
+    }
+    if (off > rs) return CER_ESHAPE;
+    return CER_OK;
+}
+
+extern "C" int cer_corr_lookup_f32(const float* vol, const float* origin, const float* disp, long disp_view_stride, float* out, int nv,
+                                   long P, int D, int row_stride, float incre, int num_levels, int radius, void* stream) {
+    if (!vol || !origin || !disp || !out || nv <= 0 || P <= 0 || D <= 0) return CER_EINVAL;
+    if (!cer_aligned16(vol)) return CER_EALIGN;
+    LevelInfo li;
+    int rc = level_info(D, row_stride, num_levels, radius, &li);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lookup_kernel, dim3((unsigned)((P + LK_PIX - 1) / LK_PIX), (unsigned)nv), dim3(256),
+                       sizeof(float) * LK_PIX * (row_stride + 4), (hipStream_t)stream, vol, origin,
+                       disp, disp_view_stride, out, P, D, row_stride, incre, num_levels, radius, li);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}
+
+extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, const float* disp, const float* w, const float* b, float* out,
+                                     long P, int D, int row_stride, float incre, int num_levels, int radius, int Cout, void* stream) {
+    if (!vol || !origin || !disp || !w || !b || !out || P <= 0 || D <= 0) return CER_EINVAL;
+    if (Cout != 64) return CER_ESHAPE;
+    if (!cer_aligned16(vol) || !cer_aligned16(out)) return CER_EALIGN;
+    LevelInfo li;
+    int rc = level_info(D, row_stride, num_levels, radius, &li);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lookup_encode_kernel, dim3((unsigned)((P + LK_PIX - 1) / LK_PIX)), dim3(256),
+                       sizeof(float) * (LK_PIX * (row_stride + 4) + num_levels * (2 * radius + 1) * 64 + LK_PIX * (LK_MAX_TAPS + 1)),
+                       (hipStream_t)stream, vol, origin, disp, w,
+                       b, out, P, D, row_stride, incre, num_levels, radius, li);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}
+
+// mean over views of planar features + 1x1 conv (K -> 64) + bias + ReLU -> NHWC [P,64]
+__global__ __launch_bounds__(256) void corr_encode_kernel(const float* __restrict__ feats, const float* __restrict__ wgt,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int nv, int K, long P) {
+    extern __shared__ __attribute__((aligned(16))) float lk_smem[];
+    float* wsm = lk_smem;                        // [K][64]
+    float* fm = wsm + K * 64;                    // [K][LK_PIX]
+    const long p0 = (long)blockIdx.x * LK_PIX;
+    const int npix = (int)min((long)LK_PIX, P - p0);
+    for (int t = threadIdx.x; t < K * 64; t += 256) wsm[t] = wgt[t];
+    const float inv = 1.0f / (float)nv;
+    for (int t = threadIdx.x; t < K * LK_PIX; t += 256) {
+        const int k = t / LK_PIX, pix = t - k * LK_PIX;
+        float s = 0.f;
+        if (pix < npix)
+            for (int v = 0; v < nv; ++v) s += feats[((long)v * K + k) * P + p0 + pix];
+        fm[t] = nv == 1 ? s : s * inv;
+    }
+    __syncthreads();
+    const int pix = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    if (pix >= npix) return;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = bias[grp * 16 + j];
+    for (int k = 0; k < K; ++k) {
+        const float f = fm[k * LK_PIX + pix];
+        const float* wr = &wsm[k * 64 + grp * 16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = fmaf(f, wr[j], acc[j]);
+    }
+    float* dst = out + (p0 + pix) * 64 + grp * 16;
+#pragma unroll
+    for (int j = 0; j < 16; j += 4)
+        *reinterpret_cast<float4*>(dst + j) =
+            make_float4(fmaxf(acc[j], 0.f), fmaxf(acc[j + 1], 0.f), fmaxf(acc[j + 2], 0.f), fmaxf(acc[j + 3], 0.f));
+}
+
+extern "C" int cer_corr_encode_f32(const float* feats, const float* w, const float* b, float* out, int nv, int K, long P, int Cout,
+                                   void* stream) {
+    if (!feats || !w || !b || !out || nv <= 0 || K <= 0 || P <= 0) return CER_EINVAL;
+    if (Cout != 64 || K > 256) return CER_ESHAPE;
+    if (!cer_aligned16(out)) return CER_EALIGN;
+    hipLaunchKernelGGL(corr_encode_kernel, dim3((unsigned)((P + LK_PIX - 1) / LK_PIX)), dim3(256), sizeof(float) * (K * 64 + K * LK_PIX),
+                       (hipStream_t)stream, feats, w, b, out, nv, K, P);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}

@@ -1,0 +1,104 @@
+"""Caller-side counterpart of the reference's inference driver (reference: inference.py:19-66,
+utils/data_utils.py:58-78, utils/frame_utils.py:138-163): scale/crop of images + intrinsics,
+model call, disparity -> depth, PFM writer.  Dataset readers are out of scope:
+``inference`` takes any iterable yielding the reference's loader tuple
+(images [1,N,3,H,W], poses [1,N,4,4], intrinsics [1,N,3,3], image_names, scale)."""
+import os
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .raft import RAFT
+
+
+def scale_operation(images, intrinsics, s):
+    """images [N,3,H,W], intrinsics [N,3,3] -> bilinear (align_corners=True) resize to int(s*H) x int(s*W),
+    fx, fy, cx, cy scaled (reference: utils/data_utils.py:58-66).  Out of place."""
+    ht2, wd2 = int(s * images.shape[2]), int(s * images.shape[3])
+    intrinsics = intrinsics.clone()
+    intrinsics[:, 0] *= s
+    intrinsics[:, 1] *= s
+    return F.interpolate(images, [ht2, wd2], mode="bilinear", align_corners=True), intrinsics
+
+
+def crop_operation(images, intrinsics, crop_h, crop_w):
+    """Centre crop; principal point shifted (reference: utils/data_utils.py:69-78).  Out of place."""
+    x0 = (images.shape[3] - crop_w) // 2
+    y0 = (images.shape[2] - crop_h) // 2
+    intrinsics = intrinsics.clone()
+    intrinsics[:, 0, 2] -= x0
+    intrinsics[:, 1, 2] -= y0
+    return images[:, :, y0:y0 + crop_h, x0:x0 + crop_w], intrinsics
+
+
+def disp_to_depth(res):
+    """numpy [h,w] inverse depth -> float32 depth, 0 where disparity is 0 (reference: inference.py:57-58)."""
+    with np.errstate(divide="ignore"):
+        return np.where(res == 0, 0, 1 / res).astype(np.float32)
+
+
+def write_pfm(file, image, scale=1):
+    """Greyscale/colour float32 PFM, rows bottom-up, negative scale = little endian
+    (reference: utils/frame_utils.py:138-163)."""
+    if image.dtype.name != "float32":
+        raise Exception("Image dtype must be float32.")
+    image = np.flipud(image)
+    if image.ndim == 3 and image.shape[2] == 3:
+        color = True
+    elif image.ndim == 2 or (image.ndim == 3 and image.shape[2] == 1):
+        color = False
+    else:
+        raise Exception("Image must have H x W x 3, H x W x 1 or H x W dimensions.")
+    import sys
+    endian = image.dtype.byteorder
+    if endian == "<" or (endian == "=" and sys.byteorder == "little"):
+        scale = -scale
+    with open(file, "wb") as f:
+        f.write(b"PF\n" if color else b"Pf\n")
+        f.write(b"%d %d\n" % (image.shape[1], image.shape[0]))
+        f.write(b"%f\n" % scale)
+        image.tofile(f)
+
+
+def inference(test_loader, ckpt, output_folder, rescale=1, crop=None, do_report=False, write_min_depth=None,
+              model=None, num_frames=None):
+    """Reference signature (inference.py:19-27) plus ``model`` (pre-built RAFT) and ``num_frames``
+    (the reference reads test_loader.dataset.num_frames for the file name)."""
+    if model is None:
+        model = RAFT(test_mode=True).cuda()
+        if ckpt is not None:
+            model.load_state_dict(torch.load(ckpt, map_location="cpu"), strict=True)
+    model.eval()
+    output_folder = Path(output_folder)
+    (output_folder / "depths").mkdir(exist_ok=True, parents=True)
+    written = []
+    with torch.no_grad():
+        for images, poses, intrinsics, image_names, scale in test_loader:
+            poses = poses.cuda()
+            images, intrinsics = scale_operation(images.squeeze(0), intrinsics.squeeze(0), rescale)
+            if crop is not None:
+                images, intrinsics = crop_operation(images, intrinsics, crop[0], crop[1])
+            images = images.unsqueeze(0).cuda()
+            intrinsics = intrinsics.unsqueeze(0).cuda()
+            if do_report:
+                torch.cuda.synchronize()
+                tic = time.time()
+            disp_est = model(images, poses, intrinsics, do_report=do_report, scale=scale)
+            if do_report:
+                torch.cuda.synchronize()
+                print(f"per view time: {time.time() - tic}")
+            im = disp_to_depth(disp_est.cpu().numpy()[0, 0])
+            name = image_names[0][0] if isinstance(image_names[0], (list, tuple)) else image_names[0]
+            nf = num_frames if num_frames is not None else getattr(getattr(test_loader, "dataset", None), "num_frames", images.shape[1])
+            path = output_folder / "depths" / f"{name}_scale{rescale}_nf{nf}.pfm"
+            write_pfm(path, im)
+            written.append(str(path))
+            if write_min_depth is not None:
+                wm = Path(write_min_depth)
+                wm.mkdir(exist_ok=True)
+                with open(wm / f"{name}.txt", "w") as f:
+                    f.write(f"{np.quantile(im[im > 0], 0.1) / 2}\n")
+    return written

@@ -1,0 +1,178 @@
+"""Python faces of the HIP kernels: shape bookkeeping + output allocation around include/cer_mvs.h.
+All tensors are CUDA float32; every call enqueues on torch's current stream."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+def row_layout(D, num_levels):
+    """Volume row layout [level0 | level1 | ...] -> (offsets, lengths, row_stride multiple of 4)."""
+    offs, lens, n, off = [], [], D, 0
+    for _ in range(num_levels):
+        offs.append(off)
+        lens.append(n)
+        off += n
+        n //= 2
+    return offs, lens, (off + 3) // 4 * 4
+
+
+def alt_corr_forward(fmap1, fmap2, coords, radius):
+    B, H1, W1, C = fmap1.shape
+    _, H2, W2, _ = fmap2.shape
+    N = coords.shape[1]
+    rd = 2 * radius + 1
+    corr = torch.empty(B, N, rd * rd, H1, W1, device=fmap1.device, dtype=torch.float32)
+    L.check(L.load().cer_alt_corr_forward_f32(L.dev_ptr(fmap1, "fmap1"), L.dev_ptr(fmap2, "fmap2"), L.dev_ptr(coords, "coords"),
+                                              L.dev_ptr(corr, "corr"), B, N, H1, W1, H2, W2, C, radius, L.cur_stream()),
+            "alt_corr_forward")
+    return corr
+
+
+def alt_corr_backward(fmap1, fmap2, coords, corr_grad, radius):
+    B, H1, W1, C = fmap1.shape
+    _, H2, W2, _ = fmap2.shape
+    N = coords.shape[1]
+    g1 = torch.empty_like(fmap1)
+    g2 = torch.empty_like(fmap2)
+    gc = torch.empty_like(coords)
+    L.check(L.load().cer_alt_corr_backward_f32(L.dev_ptr(fmap1, "fmap1"), L.dev_ptr(fmap2, "fmap2"), L.dev_ptr(coords, "coords"),
+                                               L.dev_ptr(corr_grad, "corr_grad"), L.dev_ptr(g1, "g1"), L.dev_ptr(g2, "g2"),
+                                               L.dev_ptr(gc, "gc"), B, N, H1, W1, H2, W2, C, radius, L.cur_stream()),
+            "alt_corr_backward")
+    return g1, g2, gc
+
+
+def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, fold, vol=None, accumulate=False):
+    """fmap1 [P,C], fmap2 [V,P2,C] (NHWC, pre-scaled), Pij [V,4,4], disp_in [P].
+    Returns (vol [V,P,rs] or [P,rs], origin [P]).  Level 0 only; call ``pyramid`` next."""
+    V, P2, C = fmap2.shape
+    P = h1 * w1
+    _, _, rs = row_layout(D, num_levels)
+    if vol is None:
+        shape = (P, rs) if fold else (V, P, rs)
+        vol = torch.zeros(shape, device=fmap1.device, dtype=torch.float32)
+    origin = torch.empty(P, device=fmap1.device, dtype=torch.float32)
+    mode = (2 if accumulate else 1) if fold else 0
+    L.check(L.load().cer_cost_build_f32(L.dev_ptr(fmap1, "fmap1"), L.dev_ptr(fmap2, "fmap2"), L.dev_ptr(Pij, "Pij"),
+                                        L.dev_ptr(disp_in, "disp_in"), L.dev_ptr(vol, "vol"), L.dev_ptr(origin, "origin"),
+                                        V, h1, w1, h1, w1, C, D, rs, float(incre), int(bool(shift)), mode, L.cur_stream()),
+            "cost_build")
+    return vol, origin
+
+
+def pyramid(vol, D, num_levels, scale=1.0):
+    rs = vol.shape[-1]
+    rows = vol.numel() // rs
+    L.check(L.load().cer_pyramid_f32(L.dev_ptr(vol, "vol"), rows, D, rs, num_levels, float(scale), L.cur_stream()), "pyramid")
+    return vol
+
+
+def corr_lookup(vol, origin, disp, D, incre, num_levels, radius, per_view_disp=False):
+    """vol [nv,P,rs] or [P,rs]; origin [P]; disp [P] (or [nv,P]) -> [nv, L*(2r+1), P]."""
+    if vol.dim() == 2:
+        vol = vol[None]
+    nv, P, rs = vol.shape
+    out = torch.empty(nv, num_levels * (2 * radius + 1), P, device=vol.device, dtype=torch.float32)
+    L.check(L.load().cer_corr_lookup_f32(L.dev_ptr(vol, "vol"), L.dev_ptr(origin, "origin"), L.dev_ptr(disp, "disp"),
+                                         P if per_view_disp else 0, L.dev_ptr(out, "out"), nv, P, D, rs, float(incre),
+                                         num_levels, radius, L.cur_stream()), "corr_lookup")
+    return out
+
+
+def corr_encode(feats, w_t, b, out=None):
+    """feats [nv,K,P] planar; w_t [K,64]; b [64] -> [P,64] (mean over views, 1x1 conv, ReLU)."""
+    nv, K, P = feats.shape
+    if out is None:
+        out = torch.empty(P, 64, device=feats.device, dtype=torch.float32)
+    L.check(L.load().cer_corr_encode_f32(L.dev_ptr(feats, "feats"), L.dev_ptr(w_t, "w"), L.dev_ptr(b, "b"), L.dev_ptr(out, "out"),
+                                         nv, K, P, 64, L.cur_stream()), "corr_encode")
+    return out
+
+
+def lookup_encode(vol, origin, disp, w_t, b, D, incre, num_levels, radius, out=None):
+    """Folded volume [P,rs] -> relu(conv1x1(lookup)) [P,64]."""
+    P, rs = vol.shape
+    if out is None:
+        out = torch.empty(P, 64, device=vol.device, dtype=torch.float32)
+    L.check(L.load().cer_lookup_encode_f32(L.dev_ptr(vol, "vol"), L.dev_ptr(origin, "origin"), L.dev_ptr(disp, "disp"),
+                                           L.dev_ptr(w_t, "w"), L.dev_ptr(b, "b"), L.dev_ptr(out, "out"), P, D, rs, float(incre),
+                                           num_levels, radius, 64, L.cur_stream()), "lookup_encode")
+    return out
+
+
+class PackedConv3x3:
+    """A 3x3 conv's weights in MFMA B-fragment order for a given K-source list.
+    ``sources``: list of (channels, kind) with kind 0 = tensor, 1 = disparity encoder (49)."""
+
+    def __init__(self, weight, bias, sources, device):
+        lib = L.load()
+        w = weight.detach().to("cpu", torch.float32).contiguous()
+        Cout, Cin = w.shape[0], w.shape[1]
+        self.sources = list(sources)
+        n = len(sources)
+        ch = (ctypes.c_int * n)(*[c for c, _ in sources])
+        kind = (ctypes.c_int * n)(*[k for _, k in sources])
+        kpad = sum(64 if k == 1 else (c + 31) // 32 * 32 for c, k in sources)
+        size = lib.cer_conv3x3_packed_size(Cout, kpad)
+        if size <= 0:
+            raise RuntimeError(f"conv3x3 pack: unsupported shape Cout={Cout} Kpad={kpad}")
+        packed = torch.empty(size, dtype=torch.float32)
+        L.check(lib.cer_conv3x3_pack_f32(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(packed.data_ptr()), Cout, Cin, ch, kind, n),
+                "conv3x3_pack")
+        self.packed = packed.to(device)
+        self.bias = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
+        self.cout = Cout
+
+
+def conv3x3(pc, srcs, h, w, epi, out=None, out2=None, aux=None, aux2=None, init=None, use_bias=True):
+    """srcs: list of tensors matching ``pc.sources`` ([P,ch] for kind 0, disp [P] for kind 1)."""
+    dev = srcs[0].device
+    P = h * w
+    ci = L.ConvInputs()
+    ci.nsrc = len(srcs)
+    for i, (t, (c, k)) in enumerate(zip(srcs, pc.sources)):
+        ci.src[i] = t.data_ptr()
+        L.dev_ptr(t, f"src{i}")
+        ci.ch[i] = c
+        ci.kind[i] = k
+    oc = pc.cout // 2 if epi == L.EPI_GATES else pc.cout
+    if out is None:
+        out = torch.empty(P, oc, device=dev, dtype=torch.float32)
+    if epi == L.EPI_GATES and out2 is None:
+        out2 = torch.empty(P, oc, device=dev, dtype=torch.float32)
+    bias = pc.bias if (use_bias and init is None) else None
+    L.check(L.load().cer_conv3x3_f32(ctypes.byref(ci), L.dev_ptr(pc.packed, "packed_w"), L.dev_ptr(bias, "bias"), L.dev_ptr(init, "init"),
+                                     L.dev_ptr(out, "out"), L.dev_ptr(out2, "out2"), L.dev_ptr(aux, "aux"), L.dev_ptr(aux2, "aux2"),
+                                     h, w, pc.cout, epi, L.cur_stream()), "conv3x3")
+    return (out, out2) if epi == L.EPI_GATES else out
+
+
+def delta_tail(hid, w_tap_c, bias, disp_in, h, w, disp_out=None, want_delta=True):
+    """hid [P,C]; w_tap_c [9,C]; returns (disp_out [P], delta [P] or None)."""
+    P, C = hid.shape
+    if disp_out is None:
+        disp_out = torch.empty(P, device=hid.device, dtype=torch.float32)
+    delta = torch.empty(P, device=hid.device, dtype=torch.float32) if want_delta else None
+    L.check(L.load().cer_delta_tail_f32(L.dev_ptr(hid, "hid"), L.dev_ptr(w_tap_c, "w"), float(bias), L.dev_ptr(disp_in, "disp_in"),
+                                        L.dev_ptr(disp_out, "disp_out"), L.dev_ptr(delta, "delta"), h, w, C, L.cur_stream()),
+            "delta_tail")
+    return disp_out, delta
+
+
+def nchw_to_nhwc(x, scale=1.0):
+    """[C,h,w] (or [C,P]) -> [P,C] * scale."""
+    C = x.shape[0]
+    P = x.numel() // C
+    out = torch.empty(P, C, device=x.device, dtype=torch.float32)
+    L.check(L.load().cer_nchw_to_nhwc_f32(L.dev_ptr(x, "src"), L.dev_ptr(out, "dst"), C, P, float(scale), L.cur_stream()), "nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, scale=1.0):
+    """[P,C] -> [C,P] * scale."""
+    P, C = x.shape
+    out = torch.empty(C, P, device=x.device, dtype=torch.float32)
+    L.check(L.load().cer_nhwc_to_nchw_f32(L.dev_ptr(x, "src"), L.dev_ptr(out, "dst"), C, P, float(scale), L.cur_stream()), "nhwc_to_nchw")
+    return out

@@ -1,0 +1,160 @@
+"""RAFT orchestrator (reference: core/raft.py:13-108): same constructor, same
+``forward(images, poses, intrinsics, scale=None, do_report=False)``, same state_dict keys
+(fnet.*, cnet.*, update_block.*; a ``module.`` prefix from DataParallel checkpoints is accepted).
+
+Test-mode forward = encoders on PyTorch-ROCm, then per cascade stage one fused cost-volume build
+(view-mean folded) and T x 6 HIP kernels; see DESIGN.md for the data layout.  Differences from the
+reference that a caller can observe, all deliberate (SURVEY.md §8(a) "quirks"):
+  * `images` and `poses` are NOT mutated in place (reference: raft.py:35,40-41);
+  * `scale` may be a float or a tensor on any device (reference: raft.py:108 calls scale.cuda());
+  * computation is fp32 end to end by default (``precision="fp32"``); the reference's GPU path runs
+    encoders + GRU under fp16 autocast (raft.py:9,55), selectable with ``precision="amp"`` for the
+    encoders only.
+Multi-GPU: ``view_group`` = a torch.distributed process group over which source views are sharded
+(rank g owns views v with v % G == g); the level-0 view-sum volume is all-reduced once per stage
+(RCCL over xGMI) and everything after it is replicated."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .corr import CorrBlock, fmaps_to_nhwc, report
+from .extractor import BasicEncoder
+from .projective import pij_matrices
+from .update import UpdateBlock
+
+
+class RAFT(nn.Module):
+    def __init__(self, cascade=[(64, 64, 8), (-1, 320, 8)], encoder_type="HR", dim_fmap=64, dim_net=64, dim_inp=64,
+                 test_mode=False, precision="fp32", view_group=None):
+        super().__init__()
+        self.cascade = [tuple(c) for c in cascade]
+        self.encoder_type = encoder_type
+        self.dim_fmap, self.dim_net, self.dim_inp = dim_fmap, dim_net, dim_inp
+        self.test_mode = test_mode
+        self.precision = precision
+        self.view_group = view_group
+        self.fnet = BasicEncoder(output_dim=dim_fmap, norm_fn="instance", type=encoder_type)
+        self.cnet = BasicEncoder(output_dim=dim_net + dim_inp, norm_fn="none", type=encoder_type)
+        self.update_block = UpdateBlock(cascade=self.cascade, dim_net=dim_net, dim_inp=dim_inp)
+        self.last_timings = None
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """Accepts DataParallel-style ``module.``-prefixed checkpoints (reference: inference.py:31-35)."""
+        if state_dict and all(k.startswith("module.") for k in state_dict):
+            state_dict = {k[7:]: v for k, v in state_dict.items()}
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def stages(self):
+        """(D, incre, T) per cascade stage (reference: core/raft.py:76-81)."""
+        out = []
+        for nIncre, incre, nIters in self.cascade:
+            if nIncre == -1:
+                nIncre = (2 * self.update_block.radius + 1) * 2 ** (self.update_block.num_levels - 1)
+            out.append((nIncre, 0.0025 / incre, nIters))
+        return out
+
+    # ---------------------------------------------------------------- encoders (PyTorch-ROCm)
+    def encode(self, images):
+        """images [1,N,3,H,W] in [-1,1] -> (net [P,64], inp [P,64], fmaps NHWC [N,P,C] * 1/8)."""
+        amp = self.precision == "amp"
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            ctx = self.cnet(images[:, [0]])[0, 0].float()                       # [128,h,w]
+            fm = self.fnet(images[0]).float()                                  # [N,C,h,w] (instance norm is per image)
+        net = torch.tanh(ctx[: self.dim_net])
+        inp = torch.relu(ctx[self.dim_net:])
+        return ops.nchw_to_nhwc(net.contiguous()), ops.nchw_to_nhwc(inp.contiguous()), fmaps_to_nhwc(fm)
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, images, poses, intrinsics, scale=None, do_report=False):
+        if not images.is_cuda:
+            raise RuntimeError("RAFT.forward: images must be a CUDA tensor (there is no CPU path)")
+        if not self.test_mode:
+            raise NotImplementedError("RAFT.forward: only test_mode=True (inference) is built; training is SURVEY.md §8(f) 'next'")
+        if "mean" not in self.update_block.aggregation or len(self.update_block.aggregation) != 1:
+            return self._forward_literal(images, poses, intrinsics, scale, do_report)
+        dev = images.device
+        poses = poses.clone().float()
+        if scale is not None:
+            s = float(torch.as_tensor(scale).reshape(-1)[0])
+            poses[..., :3, 3] *= s
+        factor = 8 if self.encoder_type == "LR" else 4
+        intrinsics = intrinsics.clone().float()
+        intrinsics[:, :, :2] /= factor
+        batch, num, ch, ht, wd = images.shape
+        if batch != 1:
+            raise RuntimeError("RAFT.forward: batch must be 1 in test mode")
+        images = images.float() * (2 / 255.0) - 1
+        h, w = ht // factor, wd // factor
+        P = h * w
+        ub = self.update_block
+
+        net_l, inp_l, nhwc = self.encode(images)
+        del images
+        # ---- view sharding: this rank builds the partial view-sum over its own source views
+        V = num - 1
+        views = list(range(1, num))
+        G, g = 1, 0
+        if self.view_group is not None:
+            import torch.distributed as dist
+            G, g = dist.get_world_size(self.view_group), dist.get_rank(self.view_group)
+            views = [v for v in views if (v - 1) % G == g]
+        f1 = nhwc[0]
+        f2 = nhwc[views].contiguous() if views else None
+        Pij = pij_matrices(poses[0], intrinsics[0], [0] * len(views), views).to(dev) if views else None
+
+        disp = torch.zeros(P, device=dev, dtype=torch.float32)
+        hoisted = ub.hoist(inp_l, h, w)
+        ws = ub.workspace(P, dev)
+        for stage, (D, incre, T) in enumerate(self.stages()):
+            if views:
+                vol, origin = ops.cost_build(f1, f2, Pij, disp, D, incre, stage == 0, h, w, ub.num_levels, fold=True)
+            else:                      # more ranks than views: contribute zeros, still need origin
+                _, _, rs = ops.row_layout(D, ub.num_levels)
+                vol = torch.zeros(P, rs, device=dev)
+                lim = torch.tensor((D // 2) * incre, device=dev, dtype=torch.float32)
+                origin = torch.where(disp < lim, lim, disp) if stage == 0 else disp.clone()
+            if G > 1:
+                import torch.distributed as dist
+                dist.all_reduce(vol, op=dist.ReduceOp.SUM, group=self.view_group)
+            ops.pyramid(vol, D, ub.num_levels, scale=1.0 / V)
+            if do_report and stage > 0:
+                report()
+            for _ in range(T):
+                ub.step(vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws)
+        out = disp.view(1, 1, h, w)
+        if scale is None:
+            raise AssertionError("scale is required in test mode (reference: core/raft.py:107)")
+        return out * s
+
+    def _forward_literal(self, images, poses, intrinsics, scale, do_report):
+        """Reference control flow call for call (CorrBlock per stage, per-view lookup, UpdateBlock.forward):
+        used for non-"mean" aggregations and by the parity tests of the literal API."""
+        dev = images.device
+        poses = poses.clone().float()
+        s = None
+        if scale is not None:
+            s = float(torch.as_tensor(scale).reshape(-1)[0])
+            poses[..., :3, 3] *= s
+        factor = 8 if self.encoder_type == "LR" else 4
+        intrinsics = intrinsics.clone().float()
+        intrinsics[:, :, :2] /= factor
+        batch, num, ch, ht, wd = images.shape
+        images = images.float() * (2 / 255.0) - 1
+        ii = torch.zeros(num - 1, dtype=torch.long)
+        jj = torch.arange(1, num)
+        h, w = ht // factor, wd // factor
+        disp = torch.zeros(batch, 1, h, w, device=dev)
+        ctx = self.cnet(images[:, [0]]).float()
+        net, inp = ctx.split([self.dim_net, self.dim_inp], dim=2)
+        net, inp = torch.tanh(net), torch.relu(inp)
+        fmaps = self.fnet(images).float()
+        ub = self.update_block
+        for stage, (D, incre, T) in enumerate(self.stages()):
+            corr_fn = CorrBlock(fmaps, poses, intrinsics, ii, jj, nIncre=D, incre=incre, disps_input=disp.detach(),
+                                shift=(stage == 0), num_levels=ub.num_levels, radius=ub.radius, test_mode=True, do_report=do_report)
+            for _ in range(T):
+                corr_frames = corr_fn(disp[:, ii.to(dev)])
+                net, delta = ub(net, inp, disp, corr_frames, stage)
+                disp = disp + delta.float()
+        assert s is not None
+        return disp * s

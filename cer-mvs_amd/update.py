@@ -1,0 +1,219 @@
+"""UpdateBlock / ConvGRU (reference: core/update.py:9-25, 29-120) on the HIP conv kernels.
+
+Same constructor arguments, parameter names (state_dict keys) and ``forward(net, inp, disp,
+corr_frames, stage) -> (net, delta)`` as the reference.  Internally activations are channels-last
+[h*w, C]; one iteration of the update block is 6 kernel launches:
+
+  lookup+mean+1x1+ReLU -> 3x3 64->64 ReLU -> {z,r} 3x3 (sigmoid, r*net) -> q 3x3 (tanh, GRU blend)
+  -> delta 3x3 64->256 ReLU -> delta 3x3 256->1 (+ disp update)
+
+Two exact algebraic reductions are used on the fast path (``step``): the GRU's `inp` slice of
+convz/convr/convq is constant over iterations and stages, so its contribution is convolved once
+per forward and fed to the MFMA accumulators as their initial value (``hoist``); and the 49-channel
+disparity encoder is generated inside the conv kernel instead of being materialised."""
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+
+
+class ConvGRU(nn.Module):
+    """Parameter container + literal forward (reference: core/update.py:9-25)."""
+
+    def __init__(self, kernel_z=3, kernel_r=3, kernel_q=3, h_planes=None, i_planes=None):
+        super().__init__()
+        if (kernel_z, kernel_r, kernel_q) != (3, 3, 3):
+            raise NotImplementedError("ConvGRU: only the reference's default 3x3 kernels are built")
+        self.do_checkpoint = False
+        self.h_planes, self.i_planes = h_planes, i_planes
+        self.convz = nn.Conv2d(h_planes + i_planes, h_planes, 3, padding=1)
+        self.convr = nn.Conv2d(h_planes + i_planes, h_planes, 3, padding=1)
+        self.convq = nn.Conv2d(h_planes + i_planes, h_planes, 3, padding=1)
+        self._packed = None
+
+    def _invalidate(self):
+        self._packed = None
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def forward(self, net, *inputs):
+        """net [1,Ch,h,w], inputs: NCHW tensors concatenated along channels (any split)."""
+        x = torch.cat(inputs, dim=1)
+        _, ch, h, w = net.shape
+        cx = x.shape[1]
+        cpad = (cx + 31) // 32 * 32
+        dev = net.device
+        if self._packed is None or self._packed[0] != (cx, dev):
+            wzr = torch.cat([self.convz.weight, self.convr.weight], 0)
+            bzr = torch.cat([self.convz.bias, self.convr.bias], 0)
+            srcs = [(ch, 0), (cx, 0)]
+            self._packed = ((cx, dev), ops.PackedConv3x3(wzr, bzr, srcs, dev), ops.PackedConv3x3(self.convq.weight, self.convq.bias, srcs, dev))
+        _, pzr, pq = self._packed
+        net_l = ops.nchw_to_nhwc(net[0].float().contiguous())
+        xp = torch.zeros(h * w, cpad, device=dev, dtype=torch.float32)
+        xp[:, :cx] = ops.nchw_to_nhwc(x[0].float().contiguous())
+        pzr_run = _with_stride(pzr, [(ch, 0), (cpad, 0)])
+        pq_run = _with_stride(pq, [(ch, 0), (cpad, 0)])
+        z, rn = ops.conv3x3(pzr_run, [net_l, xp], h, w, L.EPI_GATES, aux=net_l)
+        new = ops.conv3x3(pq_run, [rn, xp], h, w, L.EPI_GRU, aux=net_l, aux2=z)
+        return ops.nhwc_to_nchw(new).view(1, ch, h, w)
+
+
+class _Strided:
+    """A PackedConv3x3 viewed with run-time source strides (padded tensors)."""
+
+    def __init__(self, pc, sources):
+        self.packed, self.bias, self.cout, self.sources = pc.packed, pc.bias, pc.cout, sources
+
+
+def _with_stride(pc, sources):
+    return _Strided(pc, sources)
+
+
+class UpdateBlock(nn.Module):
+    def __init__(self, kernel_corr=3, dim0_corr=64, dim1_corr=64, dim_net=None, dim_inp=None, dim0_delta=256,
+                 kernel0_delta=3, kernel1_delta=3, num_levels=3, radius=5, size_disp_enc=7, kernel0_vis=3, kernel1_vis=3,
+                 share_corr=True, share_gru=True, share_delta=False, aggregation=("mean",), cascade=None):
+        super().__init__()
+        if (kernel_corr, kernel0_delta, kernel1_delta, size_disp_enc) != (3, 3, 3, 7):
+            raise NotImplementedError("UpdateBlock: only the reference's default kernel sizes are built")
+        if (dim0_corr, dim1_corr, dim_net, dim_inp, dim0_delta) != (64, 64, 64, 64, 256):
+            raise NotImplementedError("UpdateBlock: only the reference's default widths (64/64/64/64/256) are built")
+        self.num_levels, self.radius, self.size_disp_enc = num_levels, radius, size_disp_enc
+        self.share_corr, self.share_gru, self.share_delta = share_corr, share_gru, share_delta
+        self.aggregation = list(aggregation)
+        self.cascade = cascade
+        self.dim_net, self.dim_inp = dim_net, dim_inp
+        cor_planes = len(self.aggregation) * num_levels * (2 * radius + 1)
+        n_cascade = len(cascade)
+        for i in (range(n_cascade) if not share_corr else [""]):
+            setattr(self, f"corr_encoder{i}", nn.Sequential(
+                nn.Conv2d(cor_planes, dim0_corr, 1, padding=0), nn.ReLU(inplace=True),
+                nn.Conv2d(dim0_corr, dim1_corr, 3, padding=1), nn.ReLU(inplace=True)))
+        for i in (range(n_cascade) if not share_delta else [""]):
+            setattr(self, f"delta{i}", nn.Sequential(
+                nn.Conv2d(dim_net, dim0_delta, 3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(dim0_delta, 1, 3, padding=1)))
+        i_planes = dim_inp + dim1_corr + size_disp_enc ** 2
+        for i in (range(n_cascade) if not share_gru else [""]):
+            setattr(self, f"gru{i}", ConvGRU(h_planes=dim_net, i_planes=i_planes))
+        self._packed = {}
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.refresh_weights())
+
+    # ------------------------------------------------------------------ weight packing
+    def refresh_weights(self):
+        """Drop packed weights (call after mutating parameters)."""
+        self._packed = {}
+        for m in self.modules():
+            if isinstance(m, ConvGRU):
+                m._invalidate()
+
+    def _apply(self, fn, *a, **k):
+        self._packed = {}
+        return super()._apply(fn, *a, **k)
+
+    def _names(self, stage):
+        return (f"corr_encoder{stage if not self.share_corr else ''}", f"gru{stage if not self.share_gru else ''}",
+                f"delta{stage if not self.share_delta else ''}")
+
+    def packed(self, stage, device):
+        """Packed weights for ``stage`` on ``device`` (built once, cached)."""
+        key = (stage, str(device))
+        if key in self._packed:
+            return self._packed[key]
+        cn, gn, dn = self._names(stage)
+        ce, gru, de = getattr(self, cn), getattr(self, gn), getattr(self, dn)
+        dn_, di = self.dim_net, self.dim_inp
+        f32 = lambda t: t.detach().to(device, torch.float32).contiguous()
+        p = {}
+        p["w0t"] = f32(ce[0].weight[:, :, 0, 0].t())                       # [K,64]
+        p["b0"] = f32(ce[0].bias)
+        p["corr2"] = ops.PackedConv3x3(ce[2].weight, ce[2].bias, [(64, 0)], device)
+        wzr = torch.cat([gru.convz.weight, gru.convr.weight], 0).detach()
+        bzr = torch.cat([gru.convz.bias, gru.convr.bias], 0).detach()
+        wq, bq = gru.convq.weight.detach(), gru.convq.bias.detach()
+        # input channel order of the GRU convs (core/update.py:18-19,112): net | inp | disp49 | corr
+        s_net, s_inp = slice(0, dn_), slice(dn_, dn_ + di)
+        rest = list(range(0, dn_)) + list(range(dn_ + di, wzr.shape[1]))
+        full_src = [(dn_, 0), (di, 0), (49, 1), (64, 0)]
+        rest_src = [(dn_, 0), (49, 1), (64, 0)]
+        p["zr_full"] = ops.PackedConv3x3(wzr, bzr, full_src, device)
+        p["q_full"] = ops.PackedConv3x3(wq, bq, full_src, device)
+        p["zr_rest"] = ops.PackedConv3x3(wzr[:, rest], None, rest_src, device)
+        p["q_rest"] = ops.PackedConv3x3(wq[:, rest], None, rest_src, device)
+        p["zr_inp"] = ops.PackedConv3x3(wzr[:, s_inp], bzr, [(di, 0)], device)
+        p["q_inp"] = ops.PackedConv3x3(wq[:, s_inp], bq, [(di, 0)], device)
+        p["d1"] = ops.PackedConv3x3(de[0].weight, de[0].bias, [(dn_, 0)], device)
+        p["d2w"] = f32(de[2].weight[0].permute(1, 2, 0).reshape(9, -1))    # [tap, C]
+        p["d2b"] = float(de[2].bias.detach().float().cpu()[0])
+        self._packed[key] = p
+        return p
+
+    # ------------------------------------------------------------------ fast path (channels-last)
+    def hoist(self, inp_l, h, w, stage=0):
+        """Contribution of the constant `inp` slice (+ biases) to the z|r and q pre-activations."""
+        p = self.packed(stage, inp_l.device)
+        return (ops.conv3x3(p["zr_inp"], [inp_l], h, w, L.EPI_LINEAR), ops.conv3x3(p["q_inp"], [inp_l], h, w, L.EPI_LINEAR))
+
+    def step(self, vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws):
+        """One GRU iteration on the folded volume; updates ``net_l`` [P,64] and ``disp`` [P] in place.
+        ``ws``: dict of scratch tensors (c1, c2, z, rn, hid) reused across iterations."""
+        p = self.packed(stage, net_l.device)
+        hzr, hq = hoisted
+        ops.lookup_encode(vol, origin, disp, p["w0t"], p["b0"], D, incre, self.num_levels, self.radius, out=ws["c1"])
+        ops.conv3x3(p["corr2"], [ws["c1"]], h, w, L.EPI_RELU, out=ws["c2"])
+        ops.conv3x3(p["zr_rest"], [net_l, disp, ws["c2"]], h, w, L.EPI_GATES, out=ws["z"], out2=ws["rn"], aux=net_l, init=hzr)
+        ops.conv3x3(p["q_rest"], [ws["rn"], disp, ws["c2"]], h, w, L.EPI_GRU, out=net_l, aux=net_l, aux2=ws["z"], init=hq)
+        ops.conv3x3(p["d1"], [net_l], h, w, L.EPI_RELU, out=ws["hid"])
+        ops.delta_tail(ws["hid"], p["d2w"], p["d2b"], disp, h, w, disp_out=disp, want_delta=False)
+
+    @staticmethod
+    def workspace(P, device):
+        e = lambda c: torch.empty(P, c, device=device, dtype=torch.float32)
+        return {"c1": e(64), "c2": e(64), "z": e(64), "rn": e(64), "hid": e(256)}
+
+    # ------------------------------------------------------------------ literal API
+    def disp_encoder(self, disp):
+        """[B,1,h,w] -> [B,49,h,w] (reference: core/update.py:80-85); not used by the HIP path, which
+        generates these channels inside the conv kernel."""
+        batch, _, ht, wd = disp.shape
+        k = self.size_disp_enc
+        u = torch.nn.functional.unfold(disp, [k, k], padding=k // 2).view(batch, k * k, ht, wd)
+        return u - disp.view(batch, 1, ht, wd)
+
+    def forward(self, net, inp, disp, corr_frames, stage):
+        """net, inp [B,num,64,h,w]; disp [B,1,h,w]; corr_frames [B,V,33,h,w] -> (net [B,num,64,h,w], delta [B,num,h,w])."""
+        if not net.is_cuda:
+            raise RuntimeError("net must be a CUDA tensor")
+        batch, num, ch, ht, wd = net.shape
+        if batch * num != 1:
+            raise RuntimeError("UpdateBlock.forward: batch*num must be 1")
+        P = ht * wd
+        dev = net.device
+        p = self.packed(stage, dev)
+        net_l = ops.nchw_to_nhwc(net.reshape(ch, P).float().contiguous())
+        inp_l = ops.nchw_to_nhwc(inp.reshape(-1, P).float().contiguous())
+        disp_l = disp.reshape(P).float().contiguous()
+        feats = corr_frames[0].float()
+        parts = []
+        if "mean" in self.aggregation and len(self.aggregation) == 1:
+            c1 = ops.corr_encode(feats.reshape(feats.shape[0], -1, P).contiguous(), p["w0t"], p["b0"])
+        else:
+            if "mean" in self.aggregation:
+                parts.append(torch.mean(feats, dim=0))
+            if "max" in self.aggregation:
+                parts.append(torch.max(feats, dim=0).values)
+            if "std" in self.aggregation:
+                parts.append(torch.std(feats, dim=0))
+            # stack(dim=2).view(...) in the reference interleaves [part][channel]: channel-major then part
+            agg = torch.stack(parts, dim=1).reshape(1, -1, P).contiguous()
+            c1 = ops.corr_encode(agg, p["w0t"], p["b0"])
+        c2 = ops.conv3x3(p["corr2"], [c1], ht, wd, L.EPI_RELU)
+        z, rn = ops.conv3x3(p["zr_full"], [net_l, inp_l, disp_l, c2], ht, wd, L.EPI_GATES, aux=net_l)
+        new = ops.conv3x3(p["q_full"], [rn, inp_l, disp_l, c2], ht, wd, L.EPI_GRU, aux=net_l, aux2=z)
+        hid = ops.conv3x3(p["d1"], [new], ht, wd, L.EPI_RELU)
+        _, delta = ops.delta_tail(hid, p["d2w"], p["d2b"], disp_l, ht, wd)
+        net_out = ops.nhwc_to_nchw(new).view(batch, num, ch, ht, wd)
+        return net_out, delta.view(batch, num, ht, wd)

@@ -1,0 +1,172 @@
+/*
+ * cer_mvs.h - C ABI of libcermvs.so: the MI355X (gfx950) kernels behind the CER-MVS
+ * depth-inference hot path.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller (a torch tensor's data_ptr());
+ *     tensors are dense, row-major, float32 unless stated; nothing is allocated inside
+ *     (workspace is passed in) and nothing is retained after return;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); the call only
+ *     enqueues work on it and returns (asynchronous), so it is hipGraph-capturable;
+ *   - return 0 on success, a negative CER_E* for an argument error (nothing was launched),
+ *     or a positive hipError_t from the launch; never throws; stateless and re-entrant.
+ *
+ * Each function cites the reference interface (file:line under the reference tree) it
+ * replaces.  INTEGRATION.md shows the binding a reference maintainer would add.
+ */
+#ifndef CER_MVS_H
+#define CER_MVS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CER_OK 0
+#define CER_EINVAL (-1)   /* null pointer / non-positive size                       */
+#define CER_ESHAPE (-2)   /* shape not supported by this build (e.g. C % 64 != 0)   */
+#define CER_EALIGN (-3)   /* pointer not 16-byte aligned                            */
+
+/* ABI version: major*1000 + minor.  Bumped on any signature change. */
+int cer_abi_version(void);
+/* Static description of the last-resort error codes above / hipError_t names. */
+const char* cer_error_string(int code);
+/* Number of visible HIP devices (>=1) or a negative CER_E*; used by loaders to fail loudly. */
+int cer_device_count(void);
+
+/* ------------------------------------------------------------------------------------
+ * alt_cuda_corr.forward  (reference: alt_cuda_corr/correlation.cpp:23-33,
+ * correlation_kernel.cu:18-119,260-286).  Literal semantics, any radius:
+ *   corr[b,n,ky+rd*kx,h,w] = sum_c fmap1[b,h,w,c] * bilerp(fmap2[b], x-r+kx, y-r+ky),
+ *   (x,y) = coords[b,n,h,w,:], rd = 2r+1, texels outside fmap2 read as 0.
+ * fmap1 [B,H1,W1,C]  fmap2 [B,H2,W2,C]  coords [B,N,H1,W1,2]  corr [B,N,rd*rd,H1,W1].
+ * corr is fully overwritten (the reference zero-fills then accumulates, :273).  C % 64 == 0, C <= 256.
+ */
+int cer_alt_corr_forward_f32(const float* fmap1, const float* fmap2, const float* coords, float* corr,
+                             int B, int N, int H1, int W1, int H2, int W2, int C, int radius, void* stream);
+
+/* alt_cuda_corr.backward (correlation.cpp:36-48, correlation_kernel.cu:122-256,288-324), radius 0:
+ * fmap1_grad [B,H1,W1,C] and fmap2_grad [B,H2,W2,C] are overwritten (fmap2_grad is zero-filled
+ * inside, then accumulated with atomics); coords_grad is zero-filled, as in the reference (:307).
+ */
+int cer_alt_corr_backward_f32(const float* fmap1, const float* fmap2, const float* coords, const float* corr_grad,
+                              float* fmap1_grad, float* fmap2_grad, float* coords_grad,
+                              int B, int N, int H1, int W1, int H2, int W2, int C, int radius, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Epipolar cost-volume build, one cascade stage (reference: CorrBlock.__init__
+ * core/corr.py:56-91, projective_transform utils/projective_ops.py:16-28, direct_corr
+ * core/corr.py:28-43 and the kernel above), fused: no coordinate tensors are materialised.
+ *
+ *   origin[p]   = shift ? (disp_in[p] < (D/2)*incre ? (D/2)*incre : disp_in[p]) : disp_in[p]
+ *   hyp[p,k]    = (float)(k - D/2) * incre + origin[p],                       k = 0..D-1
+ *   (X,Y,Z,_)   = Pij[v] * (x, y, 1, hyp[p,k]);  (u,w) = clamp((X/Z, Y/Z), +-1e4)
+ *   c[v,p,k]    = sum_c fmap1[p,c] * bilerp(fmap2[v], u, w)      (texels outside -> 0;
+ *                                                                 non-finite (u,w) -> 0)
+ * fmap1 [h1*w1, C] and fmap2 [V, h2*w2, C] are NHWC and already carry the reference's 1/8
+ * scaling (core/corr.py:30-31).  Pij [V,4,4] row-major = K_j P_j P_i^-1 K_i^-1.
+ *
+ * Output rows have `row_stride` floats (>= D, multiple of 4); only columns [0,D) are written
+ * here (cer_pyramid_f32 fills the pooled levels behind them).
+ *   mode 0: vol [V, P, row_stride], vol[v,p,k] = c[v,p,k]               (per-view, literal)
+ *   mode 1: vol [P, row_stride],    vol[p,k]   = sum_v c[v,p,k]         (view-sum fold)
+ *   mode 2: as mode 1 but adds into the existing vol (accumulate across calls)
+ * origin_out [P] may be NULL.  C % 64 == 0.
+ */
+int cer_cost_build_f32(const float* fmap1, const float* fmap2, const float* Pij, const float* disp_in,
+                       float* vol, float* origin_out,
+                       int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride,
+                       float incre, int shift, int mode, void* stream);
+
+/* Correlation pyramid (reference: core/corr.py:94-97, F.avg_pool2d([1,2]) x (L-1)), in place on
+ * rows laid out [level0 (D) | level1 (D/2) | level2 (D/4) | ... | pad]: first level0 *= scale
+ * (1/V for the view-mean fold, 1 otherwise), then each level = pairwise mean of the previous.
+ * vol [rows, row_stride].
+ */
+int cer_pyramid_f32(float* vol, long rows, int D, int row_stride, int num_levels, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Multi-level correlation lookup (reference: CorrBlock.__call__ core/corr.py:102-143 with
+ * bilinear_sampler1 utils/bilinear_sampler.py:6-25):
+ *   c        = max((disp[p] - origin[p]) / incre + D/2, 0)
+ *   out[v, i*(2r+1) + (dx+r), p] = lerp(level_i[v,p,:], c/2^i + dx)   (zero outside the row)
+ * vol [nv, P, row_stride] (nv = V per-view, or 1 for the folded volume); out [nv, L*(2r+1), P].
+ */
+int cer_corr_lookup_f32(const float* vol, const float* origin, const float* disp, long disp_view_stride,
+                        float* out, int nv, long P, int D, int row_stride, float incre, int num_levels, int radius,
+                        void* stream);
+/* disp is [P] shared by all views (disp_view_stride = 0; RAFT.forward passes V identical copies,
+ * core/raft.py:99) or [nv, P] (disp_view_stride = P). */
+
+/* View aggregation "mean" + first corr_encoder layer on already looked-up features (reference:
+ * core/update.py:103,61-62): out[p, co] = relu(b[co] + sum_k w[k, co] * mean_v feats[v, k, p]).
+ * feats [nv, K, P] planar (the CorrBlock.__call__ layout), w [K, Cout], out [P, Cout]; Cout == 64. */
+int cer_corr_encode_f32(const float* feats, const float* w, const float* b, float* out,
+                        int nv, int K, long P, int Cout, void* stream);
+
+/* Same lookup on the folded (view-mean) volume fused with the first corr_encoder layer
+ * (reference: core/update.py:103 mean, :61-62 Conv2d(33,64,1)+ReLU): out [P, Cout] NHWC.
+ * w [Cin=L*(2r+1), Cout] (transposed 1x1 weight), b [Cout].  Cout == 64.
+ */
+int cer_lookup_encode_f32(const float* vol, const float* origin, const float* disp,
+                          const float* w, const float* b, float* out,
+                          long P, int D, int row_stride, float incre, int num_levels, int radius, int Cout,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * 3x3, stride 1, zero-padded convolution as an implicit GEMM on exact-fp32 MFMA
+ * (v_mfma_f32_16x16x4_f32), channels-last.  This one kernel family carries every 3x3 of the
+ * update block (reference: core/update.py:13-15,63-64,69-71).
+ *
+ * The K dimension is the concatenation of up to CER_CONV_MAX_SRC sources; source s is
+ *   kind 0: a tensor [h*w, ch[s]]                              (ch multiple of 16)
+ *   kind 1: the disparity encoder of disp [h*w] (update.py:80-85,97): 49 channels
+ *           100*(disp0[y+uy-3, x+ux-3] - disp[y,x]) (disp0 = zero-padded disp), padded to 64
+ * Weights are pre-packed by cer_conv3x3_pack_f32.  acc is initialised from `init` [h*w, Cout]
+ * when non-NULL, else from bias [Cout] (or 0).  Epilogues (epi):
+ *   0 LINEAR  out[p,co]  = acc
+ *   1 RELU    out[p,co]  = max(acc, 0)
+ *   2 GATES   co <  Cout/2: out [p,co] = sigmoid(acc)                (z)
+ *             co >= Cout/2: out2[p,co-Cout/2] = sigmoid(acc) * aux[p,co-Cout/2]   (r * net)
+ *   3 GRU     q = tanh(acc); out[p,co] = (1 - aux2[p,co]) * aux[p,co] + aux2[p,co] * q
+ *             (aux = net, aux2 = z; update.py:23-24)
+ */
+#define CER_CONV_MAX_SRC 4
+#define CER_EPI_LINEAR 0
+#define CER_EPI_RELU 1
+#define CER_EPI_GATES 2
+#define CER_EPI_GRU 3
+
+typedef struct {
+    const float* src[CER_CONV_MAX_SRC];
+    int ch[CER_CONV_MAX_SRC];     /* logical channels of each source (49 for kind 1) */
+    int kind[CER_CONV_MAX_SRC];
+    int nsrc;
+} cer_conv_inputs;
+
+/* Number of floats cer_conv3x3_pack_f32 writes for (Cout, padded K channels). */
+long cer_conv3x3_packed_size(int Cout, int Kpad);
+/* Pack OIHW weights [Cout, Cin, 3, 3] whose Cin is the concatenation described by (ch, kind)
+ * into the MFMA B-fragment order.  HOST pointers (done once at model load). */
+int cer_conv3x3_pack_f32(const float* w_oihw, float* packed, int Cout, int Cin,
+                         const int* ch, const int* kind, int nsrc);
+
+int cer_conv3x3_f32(const cer_conv_inputs* in, const float* packed_w, const float* bias, const float* init,
+                    float* out, float* out2, const float* aux, const float* aux2,
+                    int h, int w, int Cout, int epi, void* stream);
+
+/* delta head tail (reference: core/update.py:70-71,114 and core/raft.py:101):
+ *   delta[p] = 0.01 * (b + sum_{tap,c} w[tap,c] * hid[p+tap, c]);  disp_out[p] = disp_in[p] + delta[p]
+ * hid [h*w, C] (already ReLU'd), w [9, C] (tap-major), C % 256 == 0.  delta may be NULL.
+ */
+int cer_delta_tail_f32(const float* hid, const float* w, float bias, const float* disp_in,
+                       float* disp_out, float* delta, int h, int w_, int C, void* stream);
+
+/* NCHW [C,h,w] -> NHWC [h*w,C] with a scale (feature maps: scale = 1/8, core/corr.py:30-31)
+ * and NHWC -> NCHW; C % 4 == 0. */
+int cer_nchw_to_nhwc_f32(const float* src, float* dst, int C, long P, float scale, void* stream);
+int cer_nhwc_to_nchw_f32(const float* src, float* dst, int C, long P, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CER_MVS_H */

@@ -1,0 +1,325 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the golden fixtures.
+Run on the GPU box: pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l1
+from test_oracle_golden import blank_state_dict, hashed
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4          # BASELINE.md §3 parity bar (relative L1); kernels typically land at 1e-6..1e-7
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def test_library_sees_gpu():
+    from cer_mvs_amd import _lib
+    assert _lib.load().cer_device_count() >= 1
+
+
+# ------------------------------------------------------------------------------------ alt_cuda_corr
+@pytest.mark.parametrize("shape", [(1, 5, 12, 20, 12, 20, 64), (2, 3, 9, 13, 11, 7, 128)])
+def test_alt_corr_forward_radius0(dev, shape):
+    from cer_mvs_amd import alt_cuda_corr
+    from oracle import cer_oracle as O
+    B, N, H1, W1, H2, W2, C = shape
+    f1 = hashed((B, H1, W1, C), 51)
+    f2 = hashed((B, H2, W2, C), 52)
+    xy = torch.stack([hashed((B, N, H1, W1), 53, -3.0, W2 + 2.0), hashed((B, N, H1, W1), 54, -3.0, H2 + 2.0)], -1).contiguous()
+    xy[0, 0, 0, 0] = torch.tensor([1e4, -1e4])       # clamped extremes
+    xy[0, 0, 0, 1] = torch.tensor([2.0, 3.0])         # exactly on a texel
+    ref = O.alt_corr_forward(f1, f2, xy)
+    out, = alt_cuda_corr.forward(f1.to(dev), f2.to(dev), xy.to(dev), 0)
+    assert out.shape == ref.shape
+    assert rel_l1(out.cpu(), ref) < 1e-5
+
+
+def test_alt_corr_forward_radius1(dev):
+    """General radius: channel ky + rd*kx samples at (x - r + kx, y - r + ky) (correlation_kernel.cu:92-114)."""
+    from cer_mvs_amd import alt_cuda_corr
+    from oracle import cer_oracle as O
+    B, N, H, W, C, r = 1, 2, 10, 14, 64, 1
+    f1, f2 = hashed((B, H, W, C), 61), hashed((B, H, W, C), 62)
+    xy = torch.stack([hashed((B, N, H, W), 63, -2.0, W + 1.0), hashed((B, N, H, W), 64, -2.0, H + 1.0)], -1).contiguous()
+    out, = alt_cuda_corr.forward(f1.to(dev), f2.to(dev), xy.to(dev), r)
+    rd = 2 * r + 1
+    assert out.shape == (B, N, rd * rd, H, W)
+    for kx in range(rd):
+        for ky in range(rd):
+            # integer offsets keep floor/frac unchanged, so shifting the coordinates is the same sample
+            ref = O.alt_corr_forward(f1, f2, xy + torch.tensor([kx - r, ky - r], dtype=torch.float32))[:, :, 0]
+            assert rel_l1(out[:, :, ky + rd * kx].cpu(), ref) < 1e-5
+
+
+def test_alt_corr_backward(dev):
+    """Gradients of the radius-0 op wrt fmap1/fmap2 equal autograd through the oracle's grid_sample form."""
+    from cer_mvs_amd import alt_cuda_corr
+    from oracle import cer_oracle as O
+    B, N, H, W, C = 1, 3, 8, 12, 64
+    f1, f2 = hashed((B, H, W, C), 71), hashed((B, H, W, C), 72)
+    xy = torch.stack([hashed((B, N, H, W), 73, -1.0, W + 0.5), hashed((B, N, H, W), 74, -1.0, H + 0.5)], -1).contiguous()
+    g = hashed((B, N, 1, H, W), 75)
+    a, b = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+    (O.alt_corr_forward(a, b, xy) * g).sum().backward()
+    g1, g2, gc = alt_cuda_corr.backward(f1.to(dev), f2.to(dev), xy.to(dev), g.to(dev), 0)
+    assert rel_l1(g1.cpu(), a.grad) < 1e-5
+    assert rel_l1(g2.cpu(), b.grad) < 1e-5
+    assert float(gc.abs().max()) == 0.0               # the reference never writes coords_grad (correlation_kernel.cu:307)
+
+
+def test_alt_corr_rejects_bad_inputs(dev):
+    from cer_mvs_amd import alt_cuda_corr
+    f = torch.zeros(1, 4, 4, 64)
+    xy = torch.zeros(1, 1, 4, 4, 2)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        alt_cuda_corr.forward(f, f.to(dev), xy.to(dev), 0)
+    with pytest.raises(RuntimeError, match="must be contiguous"):
+        alt_cuda_corr.forward(f.to(dev).permute(0, 2, 1, 3), f.to(dev), xy.to(dev), 0)
+
+
+# ------------------------------------------------------------------------------------ CorrBlock
+def _corrblock_inputs(golden):
+    g = golden("corrblock")
+    h1, w1, V = int(g["h1"]), int(g["w1"]), int(g["V"])
+    fmaps = hashed((1, V + 1, 64, h1, w1), 11, -2.0, 2.0)
+    return g, h1, w1, V, fmaps, torch.from_numpy(g["poses"]), torch.from_numpy(g["intrinsics"])
+
+
+@pytest.mark.parametrize("stage", [0, 1])
+def test_corrblock_matches_reference_capture(dev, golden, stage):
+    from cer_mvs_amd import CorrBlock
+    g, h1, w1, V, fmaps, poses, intr = _corrblock_inputs(golden)
+    D, N, shift = ((64, 64, True), (44, 320, False))[stage]
+    incre = 0.0025 / N
+    disp_in = torch.from_numpy(g[f"disp_in{stage}"])
+    cb = CorrBlock(fmaps.to(dev), poses.to(dev), intr.to(dev), torch.zeros(V, dtype=torch.long), torch.arange(1, V + 1),
+                   nIncre=D, incre=incre, disps_input=disp_in.to(dev), shift=shift, num_levels=3, radius=5)
+    assert torch.equal(cb.disps_origin.cpu().reshape(h1, w1), torch.from_numpy(g[f"origin{stage}"]))
+    for lv in range(3):
+        ref = torch.from_numpy(g[f"pyr{stage}_{lv}"])
+        got = cb.corr_pyramid[lv].cpu().reshape(V, h1 * w1, -1)
+        assert got.shape == ref.shape
+        assert rel_l1(got, ref) < 1e-5, (stage, lv)
+    zinv = torch.from_numpy(g[f"zinv{stage}"])
+    feats = cb(zinv[:, [0] * V].to(dev))
+    ref = torch.from_numpy(g[f"feats{stage}"])
+    assert feats.shape == ref.shape and feats.is_contiguous()
+    assert rel_l1(feats.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("stage", [0, 1])
+def test_view_mean_fold_is_exact(dev, golden, stage):
+    """lookup(mean_v volume) == mean_v lookup(volume_v) (first reduction)."""
+    from cer_mvs_amd import CorrBlock
+    g, h1, w1, V, fmaps, poses, intr = _corrblock_inputs(golden)
+    D, N, shift = ((64, 64, True), (44, 320, False))[stage]
+    args = (fmaps.to(dev), poses.to(dev), intr.to(dev), torch.zeros(V, dtype=torch.long), torch.arange(1, V + 1))
+    kw = dict(nIncre=D, incre=0.0025 / N, disps_input=torch.from_numpy(g[f"disp_in{stage}"]).to(dev), shift=shift, num_levels=3, radius=5)
+    zinv = torch.from_numpy(g[f"zinv{stage}"])[:, [0] * V].to(dev)
+    per_view = CorrBlock(*args, **kw)(zinv).mean(1)
+    folded = CorrBlock(*args, fold_views=True, **kw)(zinv)[:, 0]
+    assert rel_l1(folded.cpu(), per_view.cpu()) < 1e-5
+    ref = torch.from_numpy(g[f"feats{stage}"]).mean(1)
+    assert rel_l1(folded.cpu(), ref) < 1e-5
+
+
+def test_cost_build_edge_cases(dev):
+    """Ragged sizes (P not a multiple of 16, D not a multiple of 16), a single view, views that project
+    entirely out of bounds and a degenerate Pij (Z = 0 -> non-finite coordinates)."""
+    from cer_mvs_amd import ops
+    from oracle import cer_oracle as O
+    h1, w1, V, C, D, incre = 7, 13, 2, 64, 20, 0.0025 / 64
+    fm = hashed((V + 1, C, h1, w1), 81, -2, 2)
+    poses = torch.eye(4).repeat(V + 1, 1, 1)
+    poses[1, 0, 3] = 40.0
+    poses[2, 0, 3] = 1e7                              # projects far outside: all zeros
+    intr = torch.tensor([[90.0, 0, 6.5], [0, 90.0, 3.5], [0, 0, 1]]).repeat(V + 1, 1, 1)
+    disp_in = hashed((h1, w1), 82, 0.0, 0.002)
+    vol_ref, origin_ref = O.cost_volume(fm, poses, intr, D, incre, disp_in, True)
+    nhwc = (fm.permute(0, 2, 3, 1) / 8.0).reshape(V + 1, h1 * w1, C).contiguous().to(dev)
+    Pij = O.pij_matrices(poses, intr, [0] * V, [1, 2]).contiguous()
+    vol, origin = ops.cost_build(nhwc[0], nhwc[1:].contiguous(), Pij.to(dev), disp_in.reshape(-1).to(dev), D, incre, True, h1, w1, 3, fold=False)
+    assert torch.equal(origin.cpu().view(h1, w1), origin_ref)
+    assert rel_l1(vol[..., :D].cpu(), vol_ref) < 1e-5
+    assert float(vol[1, :, :D].abs().max()) == 0.0
+    bad = Pij.clone()
+    bad[0, 2] = 0.0                                    # Z == 0 everywhere
+    vol2, _ = ops.cost_build(nhwc[0], nhwc[1:].contiguous(), bad.to(dev), disp_in.reshape(-1).to(dev), D, incre, True, h1, w1, 3, fold=False)
+    assert torch.isfinite(vol2).all() and float(vol2[0].abs().max()) == 0.0
+
+
+def test_lookup_edge_cases(dev):
+    """Index below 0 (clamped), far beyond the row (all taps zero), exactly integral, and a ragged P."""
+    from cer_mvs_amd import ops
+    from oracle import cer_oracle as O
+    P, D, incre, L, r = 37, 44, 0.0025 / 320, 3, 5
+    offs, lens, rs = ops.row_layout(D, L)
+    vol0 = hashed((1, P, D), 91)
+    levels = O.pyramid(vol0, L)
+    packed = torch.zeros(1, P, rs)
+    for o, n, lv in zip(offs, lens, levels):
+        packed[..., o:o + n] = lv
+    origin = hashed((P,), 92, 0.001, 0.002)
+    steps = hashed((P,), 93, -40.0, 60.0)
+    steps[0], steps[1], steps[2], steps[3] = -100.0, 1e6, 3.0, -22.0
+    disp = origin + steps * incre
+    ref = O.lookup(levels, origin.view(1, P), disp.view(1, P), D, incre, r)
+    out = ops.corr_lookup(packed.to(dev), origin.to(dev), disp.to(dev), D, incre, L, r)
+    assert rel_l1(out.cpu().view(1, -1, 1, P), ref) < 1e-5
+
+
+# ------------------------------------------------------------------------------------ conv kernels
+@pytest.mark.parametrize("h,w,cout", [(8, 16, 64), (11, 21, 64), (9, 17, 128), (16, 32, 256)])
+def test_conv3x3_matches_torch(dev, h, w, cout):
+    from cer_mvs_amd import _lib as L, ops
+    cin = 64
+    x = hashed((1, cin, h, w), 101)
+    wt = hashed((cout, cin, 3, 3), 102, -0.1, 0.1)
+    b = hashed((cout,), 103)
+    ref = F.conv2d(x, wt, b, padding=1)[0].permute(1, 2, 0).reshape(h * w, cout)
+    pc = ops.PackedConv3x3(wt, b, [(cin, 0)], dev)
+    xl = x[0].permute(1, 2, 0).reshape(h * w, cin).contiguous().to(dev)
+    out = ops.conv3x3(pc, [xl], h, w, L.EPI_LINEAR)
+    assert rel_l1(out.cpu(), ref) < 1e-5
+    out = ops.conv3x3(pc, [xl], h, w, L.EPI_RELU)
+    assert rel_l1(out.cpu(), F.relu(ref)) < 1e-5
+
+
+def test_conv3x3_disp_encoder_source(dev):
+    """Source kind 1 generates 100*(unfold7x7(disp) - disp) on the fly (core/update.py:80-85,97)."""
+    from cer_mvs_amd import _lib as L, ops
+    from oracle import cer_oracle as O
+    h, w, cout = 13, 19, 64
+    disp = hashed((1, 1, h, w), 111, 0.0, 0.0025)
+    a = hashed((1, 32, h, w), 112)
+    feat = 100 * O.disp_features(disp)
+    wt = hashed((cout, 32 + 49, 3, 3), 113, -0.1, 0.1)
+    ref = F.conv2d(torch.cat([a, feat], 1), wt, None, padding=1)[0].permute(1, 2, 0).reshape(h * w, cout)
+    pc = ops.PackedConv3x3(wt, None, [(32, 0), (49, 1)], dev)
+    al = a[0].permute(1, 2, 0).reshape(h * w, 32).contiguous().to(dev)
+    out = ops.conv3x3(pc, [al, disp.reshape(-1).to(dev)], h, w, L.EPI_LINEAR)
+    assert rel_l1(out.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("stage", [0, 1])
+def test_update_block_matches_reference_capture(dev, golden, stage):
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.synthetic import fill_state_dict
+    g = golden("update")
+    h1, w1, V = int(g["h1"]), int(g["w1"]), int(g["V"])
+    model = RAFT(cascade=[(64, 64, 1), (-1, 320, 1)], test_mode=True)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(g["weight_seed"])))
+    ub = model.update_block.to(dev)
+    net = torch.tanh(hashed((1, 1, 64, h1, w1), 31, -2, 2))
+    inp = torch.relu(hashed((1, 1, 64, h1, w1), 32, -1, 2))
+    disp = hashed((1, 1, h1, w1), 33, 0.0, 0.0025)
+    corr = hashed((1, V, 33, h1, w1), 34, -1.5, 3.0)
+    n2, delta = ub(net.to(dev), inp.to(dev), disp.to(dev), corr.to(dev), stage)
+    assert n2.shape == (1, 1, 64, h1, w1) and delta.shape == (1, 1, h1, w1)
+    assert rel_l1(n2.cpu(), torch.from_numpy(g[f"net{stage}"])) < 1e-5
+    assert rel_l1(delta.cpu(), torch.from_numpy(g[f"delta{stage}"])) < 1e-5
+
+
+# ------------------------------------------------------------------------------------ end to end
+def _run_e2e(dev, golden, name, literal=False):
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene, tensor_checksum
+    g = golden(name)
+    H, W, V = int(g["H"]), int(g["W"]), int(g["V"])
+    cascade = [tuple(int(x) for x in c) for c in g["cascade"]]
+    images, poses, intr, scale = synthetic_scene(H, W, V, seed=int(g["scene_seed"]))
+    assert tensor_checksum(images) == int(g["images_checksum"])
+    model = RAFT(cascade=cascade, test_mode=True)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(g["weight_seed"])))
+    model = model.to(dev).eval()
+    before = images.clone()
+    with torch.no_grad():
+        if literal:
+            disp = model._forward_literal(images.to(dev), poses.to(dev), intr.to(dev), scale, False)
+        else:
+            disp = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale)
+    assert torch.equal(images, before)
+    ref = torch.from_numpy(g["disp"])
+    assert disp.shape == ref.shape
+    d = disp.cpu()
+    depth, depth_ref = torch.where(d == 0, d, 1 / d), torch.where(ref == 0, ref, 1 / ref)
+    return rel_l1(d, ref), rel_l1(depth, depth_ref)
+
+
+def test_end_to_end_tiny(dev, golden):
+    e_disp, e_depth = _run_e2e(dev, golden, "e2e_tiny")
+    print(f"e2e_tiny rel-L1 disp {e_disp:.3e} depth {e_depth:.3e}")
+    assert e_disp < TOL and e_depth < TOL
+
+
+def test_end_to_end_tiny_literal_api(dev, golden):
+    e_disp, e_depth = _run_e2e(dev, golden, "e2e_tiny", literal=True)
+    print(f"e2e_tiny (literal) rel-L1 disp {e_disp:.3e} depth {e_depth:.3e}")
+    assert e_disp < TOL and e_depth < TOL
+
+
+def test_end_to_end_cfg1(dev, golden):
+    """BASELINE.json configs[0] shape: 640x480, 1 ref + 2 src views, 4 GRU iterations."""
+    e_disp, e_depth = _run_e2e(dev, golden, "e2e_cfg1")
+    print(f"e2e_cfg1 rel-L1 disp {e_disp:.3e} depth {e_depth:.3e}")
+    assert e_disp < TOL and e_depth < TOL
+
+
+def test_odd_image_size_vs_oracle(dev):
+    """h1, w1 not multiples of the 8x16 conv tile, V = 1."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+    from oracle import cer_oracle as O
+    cascade = [(64, 64, 2), (-1, 320, 1)]
+    images, poses, intr, scale = synthetic_scene(76, 108, 1, seed=6)
+    model = RAFT(cascade=cascade, test_mode=True)
+    sd = fill_state_dict(model.state_dict(), seed=12)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        disp = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale).cpu()
+        ref = O.raft_forward(sd, images, poses, intr, scale, cascade=cascade)
+    assert rel_l1(disp, ref) < TOL
+
+
+def test_full_size_properties(dev):
+    """BASELINE.json configs[1] size (1600x1184, 10 source views) is too slow for the CPU oracle inside the test
+    budget, so check size-independent properties at full size: finiteness, determinism (bitwise), invariance to
+    a permutation of the source views (view-mean is symmetric; fp32 sum order changes -> tolerance), and
+    linearity of the folded volume in fmap2."""
+    from cer_mvs_amd import RAFT, ops
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+    H, W, V = 1184, 1600, 10
+    cascade = [(64, 64, 2), (-1, 320, 2)]
+    images, poses, intr, scale = synthetic_scene(H, W, V, seed=3)
+    model = RAFT(cascade=cascade, test_mode=True)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=5))
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        a = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale)
+        b = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale)
+        perm = [0] + list(range(V, 0, -1))
+        c = model(images[:, perm].to(dev), poses[:, perm].to(dev), intr[:, perm].to(dev), scale=scale)
+    assert a.shape == (1, 1, H // 4, W // 4)
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b)
+    assert rel_l1(c.cpu(), a.cpu()) < TOL
+    # linearity: build(f2a + f2b) == build(f2a) + build(f2b)
+    h1, w1, P, C, D = 296, 400, 296 * 400, 64, 64
+    f1 = torch.randn(P, C, device=dev) * 0.1
+    f2a, f2b = torch.randn(2, P, C, device=dev) * 0.1, torch.randn(2, P, C, device=dev) * 0.1
+    Pij = torch.eye(4).repeat(2, 1, 1)
+    Pij[0, 0, 3], Pij[1, 0, 3] = 9000.0, -14000.0
+    Pij = Pij.to(dev)
+    d0 = torch.zeros(P, device=dev)
+    va, _ = ops.cost_build(f1, f2a, Pij, d0, D, 0.0025 / 64, True, h1, w1, 3, fold=True)
+    vb, _ = ops.cost_build(f1, f2b, Pij, d0, D, 0.0025 / 64, True, h1, w1, 3, fold=True)
+    vab, _ = ops.cost_build(f1, f2a + f2b, Pij, d0, D, 0.0025 / 64, True, h1, w1, 3, fold=True)
+    assert rel_l1((va + vb).cpu(), vab.cpu()) < 1e-5

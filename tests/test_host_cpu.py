@@ -1,0 +1,166 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/cer_mvs.h declares,
+argument errors are reported without touching a device, the host-side weight packing / geometry / driver
+transforms are right, and the product path refuses to run without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, rel_l1
+from test_oracle_golden import blank_state_dict, hashed
+
+
+def header_symbols():
+    text = open(os.path.join(REPO, "include", "cer_mvs.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cer_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cer_mvs_amd import _lib
+    lib = _lib.load()
+    syms = header_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/cer_mvs.h but not exported"
+    assert sorted(_lib.exported_symbols()) == syms, "python binding table and header disagree"
+    assert lib.cer_abi_version() == _lib.ABI_VERSION
+
+
+def test_argument_errors_without_device():
+    from cer_mvs_amd import _lib
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    assert lib.cer_alt_corr_forward_f32(null, null, null, null, 1, 1, 4, 4, 4, 4, 64, 0, null) == -1
+    assert lib.cer_cost_build_f32(null, null, null, null, null, null, 1, 4, 4, 4, 4, 64, 64, 112, 0.1, 1, 1, null) == -1
+    assert lib.cer_pyramid_f32(null, 10, 64, 112, 3, 1.0, null) == -1
+    fake = ctypes.c_void_p(0x1000)
+    assert lib.cer_alt_corr_forward_f32(fake, fake, fake, fake, 1, 1, 4, 4, 4, 4, 60, 0, null) == -2      # C % 64
+    assert lib.cer_pyramid_f32(fake, 10, 64, 100, 3, 1.0, null) == -2                                      # row too short
+    misaligned = ctypes.c_void_p(0x1004)
+    assert lib.cer_alt_corr_forward_f32(misaligned, fake, fake, fake, 1, 1, 4, 4, 4, 4, 64, 0, null) == -3
+    assert b"CER_ESHAPE" in lib.cer_error_string(-2)
+
+
+def test_product_path_refuses_cpu_tensors():
+    from cer_mvs_amd import RAFT, CorrBlock, alt_cuda_corr
+    m = RAFT(test_mode=True)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        m(torch.zeros(1, 3, 3, 32, 32), torch.eye(4).repeat(1, 3, 1, 1), torch.eye(3).repeat(1, 3, 1, 1), scale=1.0)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        alt_cuda_corr.forward(torch.zeros(1, 4, 4, 64), torch.zeros(1, 4, 4, 64), torch.zeros(1, 1, 4, 4, 2), 0)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        CorrBlock(torch.zeros(1, 2, 64, 4, 4), torch.eye(4).repeat(1, 2, 1, 1), torch.eye(3).repeat(1, 2, 1, 1), [0], [1], 64, 0.1,
+                  torch.zeros(1, 1, 4, 4), True, 3, 5)
+
+
+def test_missing_library_is_a_hard_error(monkeypatch, tmp_path):
+    from cer_mvs_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_no_product_module_imports_the_oracle():
+    pkg = os.path.join(REPO, "cer-mvs_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("the oracle", "").replace("oracle's", "") or "import" not in \
+                    "\n".join(l for l in src.splitlines() if "oracle" in l), f"{f} references the oracle"
+
+
+def test_state_dict_is_reference_compatible():
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.synthetic import fill_state_dict
+    m = RAFT(test_mode=True)
+    sd = m.state_dict()
+    want = blank_state_dict()
+    assert sorted(sd) == sorted(want)
+    for k in want:
+        assert tuple(sd[k].shape) == tuple(want[k].shape), k
+    filled = fill_state_dict(sd, seed=1)
+    m.load_state_dict(filled, strict=True)
+    m.load_state_dict({"module." + k: v for k, v in filled.items()}, strict=True)      # DataParallel checkpoints
+    assert torch.equal(m.state_dict()["update_block.gru.convq.weight"], filled["update_block.gru.convq.weight"])
+
+
+def test_cascade_resolution_matches_oracle():
+    from cer_mvs_amd import RAFT
+    from oracle import cer_oracle as O
+    for cascade in ([(64, 64, 8), (-1, 320, 8)], [(64, 64, 16), (-1, 320, 16)], [(32, 32, 4)]):
+        assert RAFT(cascade=cascade, test_mode=True).stages() == O.resolve_cascade(cascade)
+
+
+def test_pij_matches_oracle():
+    from cer_mvs_amd.projective import pij_matrices
+    from cer_mvs_amd.synthetic import synthetic_scene
+    from oracle import cer_oracle as O
+    _, poses, intr, _ = synthetic_scene(8, 8, 5, seed=2)
+    a = pij_matrices(poses[0], intr[0], [0] * 5, [1, 2, 3, 4, 5])
+    b = O.pij_matrices(poses[0], intr[0], [0] * 5, [1, 2, 3, 4, 5])
+    assert torch.equal(a, b)
+
+
+def test_row_layout():
+    from cer_mvs_amd.ops import row_layout
+    assert row_layout(64, 3) == ([0, 64, 96], [64, 32, 16], 112)
+    assert row_layout(44, 3) == ([0, 44, 66], [44, 22, 11], 80)
+
+
+def test_conv_weight_packing_order():
+    """cer_conv3x3_pack_f32 (host code) puts W[co, ci, ky, kx] at [kc16][tap][ntile][lane][s] with
+    co = ntile*16 + lane%16, padded-K index = kc16*16 + (lane//16)*4 + s, zero in the padding."""
+    from cer_mvs_amd import _lib
+    lib = _lib.load()
+    cout, srcs = 32, [(32, 0), (49, 1)]
+    cin = 81
+    w = hashed((cout, cin, 3, 3), 7)
+    kpad = 32 + 64
+    size = lib.cer_conv3x3_packed_size(cout, kpad)
+    assert size == (kpad // 16) * 9 * (cout // 16) * 256
+    packed = torch.empty(size)
+    ch = (ctypes.c_int * 2)(32, 49)
+    kind = (ctypes.c_int * 2)(0, 1)
+    assert lib.cer_conv3x3_pack_f32(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(packed.data_ptr()), cout, cin, ch, kind, 2) == 0
+    pk = packed.view(kpad // 16, 9, cout // 16, 64, 4)
+    kmap = list(range(32)) + list(range(32, 81)) + [-1] * 15
+    for kc, tap, nt, lane, s in [(0, 0, 0, 0, 0), (1, 4, 1, 37, 2), (2, 8, 0, 63, 3), (5, 3, 1, 50, 1), (4, 7, 0, 17, 0)]:
+        co = nt * 16 + lane % 16
+        ci = kmap[kc * 16 + (lane // 16) * 4 + s]
+        want = 0.0 if ci < 0 else float(w[co, ci, tap // 3, tap % 3])
+        assert float(pk[kc, tap, nt, lane, s]) == want
+    assert lib.cer_conv3x3_pack_f32(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(packed.data_ptr()), cout, cin + 1, ch, kind, 2) == -2
+
+
+def test_driver_transforms_match_reference_capture(golden, tmp_path):
+    from cer_mvs_amd import inference as I
+    g = golden("caller")
+    im, k = torch.from_numpy(g["images"]), torch.from_numpy(g["intrinsics"])
+    k0 = k.clone()
+    im2, k2 = I.scale_operation(im, k, 1.5)
+    assert torch.equal(k, k0)                                     # out of place
+    assert np.allclose(im2.numpy(), g["scaled_images"], rtol=0, atol=1e-4) and np.array_equal(k2.numpy(), g["scaled_intrinsics"])
+    im3, k3 = I.crop_operation(im2, k2, 24, 32)
+    assert np.array_equal(im3.numpy(), g["cropped_images"]) and np.array_equal(k3.numpy(), g["cropped_intrinsics"])
+    depth = I.disp_to_depth(g["disp"])
+    assert depth.dtype == np.float32 and np.array_equal(depth, g["depth"])
+    p = tmp_path / "d.pfm"
+    I.write_pfm(p, depth)
+    assert open(p, "rb").read() == g["pfm"].tobytes()
+    with pytest.raises(Exception, match="float32"):
+        I.write_pfm(p, depth.astype(np.float64))
+
+
+def test_synthetic_scene_is_reproducible(golden):
+    from cer_mvs_amd.synthetic import synthetic_scene, tensor_checksum
+    g = golden("e2e_tiny")
+    images, poses, intr, scale = synthetic_scene(int(g["H"]), int(g["W"]), int(g["V"]), seed=int(g["scene_seed"]))
+    assert tensor_checksum(images) == int(g["images_checksum"])
+    assert images.shape == (1, 4, 3, 64, 96) and float(images.min()) >= 0 and float(images.max()) <= 255
+    assert float(scale) == 1.0
