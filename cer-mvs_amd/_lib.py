@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcermvs.so")
-ABI_VERSION = 1000
+ABI_VERSION = 1001
 CONV_MAX_SRC = 4
 EPI_LINEAR, EPI_RELU, EPI_GATES, EPI_GRU = 0, 1, 2, 3
 
@@ -18,6 +18,7 @@ _P = _c.c_void_p
 _I = _c.c_int
 _L = _c.c_long
 _F = _c.c_float
+_D = _c.c_double
 
 
 class ConvInputs(ctypes.Structure):
@@ -30,11 +31,11 @@ _SIGNATURES = {
     "cer_device_count": (_I, []),
     "cer_alt_corr_forward_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cer_alt_corr_backward_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "cer_cost_build_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
+    "cer_cost_build_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _D, _I, _I, _P]),
     "cer_pyramid_f32": (_I, [_P, _L, _I, _I, _I, _F, _P]),
-    "cer_corr_lookup_f32": (_I, [_P, _P, _P, _L, _P, _I, _L, _I, _I, _F, _I, _I, _P]),
+    "cer_corr_lookup_f32": (_I, [_P, _P, _P, _L, _P, _I, _L, _I, _I, _D, _I, _I, _P]),
     "cer_corr_encode_f32": (_I, [_P, _P, _P, _P, _I, _I, _L, _I, _P]),
-    "cer_lookup_encode_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _I, _I, _I, _P]),
+    "cer_lookup_encode_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _D, _I, _I, _I, _P]),
     "cer_conv3x3_packed_size": (_L, [_I, _I]),
     "cer_conv3x3_pack_f32": (_I, [_P, _P, _I, _I, _c.POINTER(_I), _c.POINTER(_I), _I]),
     "cer_conv3x3_f32": (_I, [_c.POINTER(ConvInputs), _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -66,9 +66,10 @@ __global__ __launch_bounds__(256) void cost_build_kernel(const float* __restrict
 
 template <int NQ>
 static int launch_build(const float* f1, const float* f2, const float* Pij, const float* disp_in, float* vol, float* origin_out, int V,
-                        int h1, int w1, int h2, int w2, int C, int D, int rs, float incre, int shift, int mode, hipStream_t st) {
+                        int h1, int w1, int h2, int w2, int C, int D, int rs, double incre_d, int shift, int mode, hipStream_t st) {
     const long P = (long)h1 * w1;
-    const float lim = (float)((D / 2) * (double)incre);
+    const float lim = (float)((D / 2) * incre_d);
+    const float incre = (float)incre_d;
     const unsigned gx = (unsigned)((P + 15) / 16);
     if (mode == 0)
         hipLaunchKernelGGL((cost_build_kernel<NQ, false>), dim3(gx, (unsigned)V), dim3(256), 0, st, f1, f2, Pij, disp_in, vol, origin_out, V,
@@ -81,7 +82,7 @@ static int launch_build(const float* f1, const float* f2, const float* Pij, cons
 }
 
 extern "C" int cer_cost_build_f32(const float* fmap1, const float* fmap2, const float* Pij, const float* disp_in, float* vol,
-                                  float* origin_out, int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride, float incre,
+                                  float* origin_out, int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride, double incre,
                                   int shift, int mode, void* stream) {
     if (!fmap1 || !fmap2 || !Pij || !disp_in || !vol) return CER_EINVAL;
     if (V <= 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || C <= 0 || D <= 0 || row_stride < D || mode < 0 || mode > 2) return CER_EINVAL;

@@ -142,7 +142,7 @@ static int level_info(int D, int rs, int L, int r, LevelInfo* li) {
 }
 
 extern "C" int cer_corr_lookup_f32(const float* vol, const float* origin, const float* disp, long disp_view_stride, float* out, int nv,
-                                   long P, int D, int row_stride, float incre, int num_levels, int radius, void* stream) {
+                                   long P, int D, int row_stride, double incre, int num_levels, int radius, void* stream) {
     if (!vol || !origin || !disp || !out || nv <= 0 || P <= 0 || D <= 0) return CER_EINVAL;
     if (!cer_aligned16(vol)) return CER_EALIGN;
     LevelInfo li;
@@ -150,13 +150,13 @@ extern "C" int cer_corr_lookup_f32(const float* vol, const float* origin, const 
     if (rc) return rc;
     hipLaunchKernelGGL(lookup_kernel, dim3((unsigned)((P + LK_PIX - 1) / LK_PIX), (unsigned)nv), dim3(256),
                        sizeof(float) * LK_PIX * (row_stride + 4), (hipStream_t)stream, vol, origin,
-                       disp, disp_view_stride, out, P, D, row_stride, incre, num_levels, radius, li);
+                       disp, disp_view_stride, out, P, D, row_stride, (float)incre, num_levels, radius, li);
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }
 
 extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, const float* disp, const float* w, const float* b, float* out,
-                                     long P, int D, int row_stride, float incre, int num_levels, int radius, int Cout, void* stream) {
+                                     long P, int D, int row_stride, double incre, int num_levels, int radius, int Cout, void* stream) {
     if (!vol || !origin || !disp || !w || !b || !out || P <= 0 || D <= 0) return CER_EINVAL;
     if (Cout != 64) return CER_ESHAPE;
     if (!cer_aligned16(vol) || !cer_aligned16(out)) return CER_EALIGN;
@@ -166,7 +166,7 @@ extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, cons
     hipLaunchKernelGGL(lookup_encode_kernel, dim3((unsigned)((P + LK_PIX - 1) / LK_PIX)), dim3(256),
                        sizeof(float) * (LK_PIX * (row_stride + 4) + num_levels * (2 * radius + 1) * 64 + LK_PIX * (LK_MAX_TAPS + 1)),
                        (hipStream_t)stream, vol, origin, disp, w,
-                       b, out, P, D, row_stride, incre, num_levels, radius, li);
+                       b, out, P, D, row_stride, (float)incre, num_levels, radius, li);
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }

@@ -70,12 +70,13 @@ int cer_alt_corr_backward_f32(const float* fmap1, const float* fmap2, const floa
  *   mode 0: vol [V, P, row_stride], vol[v,p,k] = c[v,p,k]               (per-view, literal)
  *   mode 1: vol [P, row_stride],    vol[p,k]   = sum_v c[v,p,k]         (view-sum fold)
  *   mode 2: as mode 1 but adds into the existing vol (accumulate across calls)
- * origin_out [P] may be NULL.  C % 64 == 0.
+ * origin_out [P] may be NULL.  C % 64 == 0.  `incre` is the reference's Python float (core/raft.py:81): the kernel
+ * uses (float)incre for the hypothesis spacing and (float)((D/2)*incre) for the shift limit, as torch does.
  */
 int cer_cost_build_f32(const float* fmap1, const float* fmap2, const float* Pij, const float* disp_in,
                        float* vol, float* origin_out,
                        int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride,
-                       float incre, int shift, int mode, void* stream);
+                       double incre, int shift, int mode, void* stream);
 
 /* Correlation pyramid (reference: core/corr.py:94-97, F.avg_pool2d([1,2]) x (L-1)), in place on
  * rows laid out [level0 (D) | level1 (D/2) | level2 (D/4) | ... | pad]: first level0 *= scale
@@ -92,7 +93,7 @@ int cer_pyramid_f32(float* vol, long rows, int D, int row_stride, int num_levels
  * vol [nv, P, row_stride] (nv = V per-view, or 1 for the folded volume); out [nv, L*(2r+1), P].
  */
 int cer_corr_lookup_f32(const float* vol, const float* origin, const float* disp, long disp_view_stride,
-                        float* out, int nv, long P, int D, int row_stride, float incre, int num_levels, int radius,
+                        float* out, int nv, long P, int D, int row_stride, double incre, int num_levels, int radius,
                         void* stream);
 /* disp is [P] shared by all views (disp_view_stride = 0; RAFT.forward passes V identical copies,
  * core/raft.py:99) or [nv, P] (disp_view_stride = P). */
@@ -109,7 +110,7 @@ int cer_corr_encode_f32(const float* feats, const float* w, const float* b, floa
  */
 int cer_lookup_encode_f32(const float* vol, const float* origin, const float* disp,
                           const float* w, const float* b, float* out,
-                          long P, int D, int row_stride, float incre, int num_levels, int radius, int Cout,
+                          long P, int D, int row_stride, double incre, int num_levels, int radius, int Cout,
                           void* stream);
 
 /* ------------------------------------------------------------------------------------

@@ -35,7 +35,7 @@ def test_argument_errors_without_device():
     lib = _lib.load()
     null = ctypes.c_void_p(0)
     assert lib.cer_alt_corr_forward_f32(null, null, null, null, 1, 1, 4, 4, 4, 4, 64, 0, null) == -1
-    assert lib.cer_cost_build_f32(null, null, null, null, null, null, 1, 4, 4, 4, 4, 64, 64, 112, 0.1, 1, 1, null) == -1
+    assert lib.cer_cost_build_f32(null, null, null, null, null, null, 1, 4, 4, 4, 4, 64, 64, 112, ctypes.c_double(0.1), 1, 1, null) == -1
     assert lib.cer_pyramid_f32(null, 10, 64, 112, 3, 1.0, null) == -1
     fake = ctypes.c_void_p(0x1000)
     assert lib.cer_alt_corr_forward_f32(fake, fake, fake, fake, 1, 1, 4, 4, 4, 4, 60, 0, null) == -2      # C % 64
@@ -66,13 +66,13 @@ def test_missing_library_is_a_hard_error(monkeypatch, tmp_path):
 
 
 def test_no_product_module_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under cer-mvs_amd/ may import, link or execute it."""
     pkg = os.path.join(REPO, "cer-mvs_amd")
+    pat = re.compile(r"^\s*(from|import)\s+[\w.]*oracle|cer_oracle|oracle/", re.M)
     for root, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".h")):
-                src = open(os.path.join(root, f)).read()
-                assert "oracle" not in src.replace("the oracle", "").replace("oracle's", "") or "import" not in \
-                    "\n".join(l for l in src.splitlines() if "oracle" in l), f"{f} references the oracle"
+            if f.endswith((".py", ".hip", ".hpp", ".h", "Makefile")):
+                assert not pat.search(open(os.path.join(root, f)).read()), f"{f} references the oracle"
 
 
 def test_state_dict_is_reference_compatible():
