@@ -16,6 +16,7 @@ Multi-GPU: ``view_group`` = a torch.distributed process group over which source 
 import torch
 import torch.nn as nn
 
+from . import dist as cdist
 from . import ops
 from .corr import CorrBlock, fmaps_to_nhwc, report
 from .extractor import BasicEncoder
@@ -54,12 +55,14 @@ class RAFT(nn.Module):
         return out
 
     # ---------------------------------------------------------------- encoders (PyTorch-ROCm)
-    def encode(self, images):
-        """images [1,N,3,H,W] in [-1,1] -> (net [P,64], inp [P,64], fmaps NHWC [N,P,C] * 1/8)."""
+    def encode(self, images, views):
+        """images [1,N,3,H,W] in [-1,1]; ``views`` = source-view indices this rank owns
+        -> (net [P,64], inp [P,64], NHWC feature maps [1+len(views), P, C] * 1/8 with the reference view first)."""
         amp = self.precision == "amp"
+        idx = [0] + list(views)
         with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
             ctx = self.cnet(images[:, [0]])[0, 0].float()                       # [128,h,w]
-            fm = self.fnet(images[0]).float()                                  # [N,C,h,w] (instance norm is per image)
+            fm = self.fnet(images[0, idx]).float()                             # [n,C,h,w] (instance norm is per image)
         net = torch.tanh(ctx[: self.dim_net])
         inp = torch.relu(ctx[self.dim_net:])
         return ops.nchw_to_nhwc(net.contiguous()), ops.nchw_to_nhwc(inp.contiguous()), fmaps_to_nhwc(fm)
@@ -88,18 +91,13 @@ class RAFT(nn.Module):
         P = h * w
         ub = self.update_block
 
-        net_l, inp_l, nhwc = self.encode(images)
-        del images
-        # ---- view sharding: this rank builds the partial view-sum over its own source views
+        # ---- view sharding: this rank encodes and builds the partial view-sum over its own source views only
         V = num - 1
-        views = list(range(1, num))
-        G, g = 1, 0
-        if self.view_group is not None:
-            import torch.distributed as dist
-            G, g = dist.get_world_size(self.view_group), dist.get_rank(self.view_group)
-            views = [v for v in views if (v - 1) % G == g]
+        views = cdist.local_views(V, self.view_group)
+        net_l, inp_l, nhwc = self.encode(images, views)
+        del images
         f1 = nhwc[0]
-        f2 = nhwc[views].contiguous() if views else None
+        f2 = nhwc[1:] if views else None
         Pij = pij_matrices(poses[0], intrinsics[0], [0] * len(views), views).to(dev) if views else None
 
         disp = torch.zeros(P, device=dev, dtype=torch.float32)
@@ -108,14 +106,11 @@ class RAFT(nn.Module):
         for stage, (D, incre, T) in enumerate(self.stages()):
             if views:
                 vol, origin = ops.cost_build(f1, f2, Pij, disp, D, incre, stage == 0, h, w, ub.num_levels, fold=True)
-            else:                      # more ranks than views: contribute zeros, still need origin
+            else:                      # more ranks than views: contribute zeros
                 _, _, rs = ops.row_layout(D, ub.num_levels)
                 vol = torch.zeros(P, rs, device=dev)
-                lim = torch.tensor((D // 2) * incre, device=dev, dtype=torch.float32)
-                origin = torch.where(disp < lim, lim, disp) if stage == 0 else disp.clone()
-            if G > 1:
-                import torch.distributed as dist
-                dist.all_reduce(vol, op=dist.ReduceOp.SUM, group=self.view_group)
+                origin = cdist.stage_origin(disp, D, incre, stage == 0)
+            cdist.reduce_volume(vol, self.view_group)
             ops.pyramid(vol, D, ub.num_levels, scale=1.0 / V)
             if do_report and stage > 0:
                 report()
