@@ -29,15 +29,19 @@ class DirectCorr(torch.autograd.Function):
         return ops.alt_corr_backward(fmap1, fmap2, coords, grad_output.contiguous(), 0)
 
 
-def fmaps_to_nhwc(fmaps):
-    """[N,C,h,w] -> [N,h*w,C] * (1/8)  (core/corr.py:29-35: permute, /8.0, contiguous, float)."""
+def fmaps_to_nhwc(fmaps, border=0):
+    """[N,C,h,w] -> [N,(h+2b)*(w+2b),C] * (1/8)  (core/corr.py:29-35: permute, /8.0, contiguous, float);
+    ``border`` zero texels on every side (the cost-build kernel wants 2 on the source maps)."""
     N, C, h, w = fmaps.shape
-    return (fmaps.float().permute(0, 2, 3, 1) / 8.0).reshape(N, h * w, C).contiguous()
+    x = fmaps.float() / 8.0
+    if border:
+        x = torch.nn.functional.pad(x, (border, border, border, border))
+    return x.permute(0, 2, 3, 1).reshape(N, (h + 2 * border) * (w + 2 * border), C).contiguous()
 
 
 class CorrBlock:
     def __init__(self, fmaps, poses, intrinsics, ii, jj, nIncre, incre, disps_input, shift, num_levels, radius,
-                 test_mode=True, do_report=False, fold_views=False, nhwc_fmaps=None, view_weight=None):
+                 test_mode=True, do_report=False, fold_views=False, view_weight=None):
         if not fmaps.is_cuda:
             raise RuntimeError("fmaps must be a CUDA tensor")
         batch, num_frames, ch, h1, w1 = fmaps.shape
@@ -52,12 +56,11 @@ class CorrBlock:
         if len(set(ii_l)) != 1:
             raise RuntimeError("CorrBlock: all pairs must share one reference view (ii constant), as in core/raft.py:45")
         self.num_views = len(jj_l)
-        nhwc = fmaps_to_nhwc(fmaps[0]) if nhwc_fmaps is None else nhwc_fmaps
-        f1 = nhwc[ii_l[0]]
-        f2 = nhwc[jj_l] if jj_l != list(range(jj_l[0], jj_l[0] + len(jj_l))) else nhwc[jj_l[0]:jj_l[0] + len(jj_l)]
+        f1 = fmaps_to_nhwc(fmaps[0, ii_l[0]:ii_l[0] + 1])[0]
+        f2 = fmaps_to_nhwc(fmaps[0, jj_l], border=2)
         Pij = pij_matrices(poses[0], intrinsics[0], ii_l, jj_l).to(fmaps.device)
         disp_in = disps_input.reshape(-1).float().contiguous()
-        vol, origin = ops.cost_build(f1, f2.contiguous(), Pij, disp_in, nIncre, incre, shift, h1, w1, num_levels, fold=fold_views)
+        vol, origin = ops.cost_build(f1, f2, Pij, disp_in, nIncre, incre, shift, h1, w1, num_levels, fold=fold_views)
         total_views = self.num_views if view_weight is None else view_weight
         ops.pyramid(vol, nIncre, num_levels, scale=(1.0 / total_views) if fold_views else 1.0)
         self.volume = vol                                           # [V,P,rs] or [P,rs]

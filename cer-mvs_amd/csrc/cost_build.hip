@@ -2,13 +2,23 @@
 // (reference: core/corr.py:56-91 + utils/projective_ops.py:5-28 + core/corr.py:28-43 +
 //  alt_cuda_corr/correlation_kernel.cu:18-119), and the correlation pyramid (core/corr.py:94-97).
 //
-// v1 mapping: one 16-lane DPP row per reference pixel; the row walks hypotheses k (and, in the
-// view-sum modes, views v inside k).  Lane `sub` owns channel quads {4*sub + 64*q}, so every
-// wave load instruction fetches four whole 256-B texels; coordinates are computed in registers
-// from Pij (no coordinate tensors, unlike projective_ops.py:13-28 which materialises 3 x 121 MB
-// per view at 1600x1184).  The lane-partial dots of all local views are summed BEFORE the single
-// cross-lane DPP reduction; results for 16 consecutive hypotheses are parked one per lane and
-// stored as one 64-B segment.
+// v2 mapping - one WAVE per reference pixel:
+//   * projection: lane l computes the source coordinate of hypothesis kb + l, so all (up to) 64
+//     hypotheses of a view are projected by ONE pass of straight-line VALU code (two IEEE divisions
+//     per lane instead of per sample-row); no coordinate tensor exists (projective_ops.py:13-28
+//     materialises 3 x 121 MB per view at 1600x1184);
+//   * sampling: the wave then walks the 64 samples; a sample's integer texel, fractions and
+//     validity are pulled out of lane j with v_readlane into SGPRs, so addressing and the
+//     "same texel as the previous hypothesis?" test run on the scalar unit.  The four 16-lane rows
+//     of the wave own the four bilinear corners, lane (row, sub) owns channel quad `sub` of its
+//     corner: one 16-B load per lane fetches the whole 2x2 footprint (4 x 256 B) of the sample;
+//   * source maps carry a 2-texel zero border so that clamped cells never need a bounds test;
+//   * reuse: when consecutive hypotheses fall into the same texel cell (stage 1: 0.17-0.56 texel
+//     steps) the lane-partial dot is reused and only the bilinear weights change (bilinearity:
+//     <f1, bilerp(f2)> = bilerp(<f1, f2_texel>)) - no load, no dot;
+//   * accumulation: acc[j] (one VGPR per hypothesis) sums weighted lane-partials over all local
+//     views; a single 63-shuffle butterfly then leaves the total of hypothesis k on lane k, and the
+//     wave writes its pixel's row with one coalesced 256-B store.
 #include "common.hpp"
 
 template <int NQ, bool SUM>
@@ -17,49 +27,104 @@ __global__ __launch_bounds__(256) void cost_build_kernel(const float* __restrict
                                                          float* __restrict__ vol, float* __restrict__ origin_out, int V, int h1, int w1,
                                                          int h2, int w2, int C, int D, int rs, float incre, float lim, int shift,
                                                          int accumulate) {
-    const int sub = threadIdx.x & 15;
+    const int lane = threadIdx.x & 63;
     const long P = (long)h1 * w1;
-    const long p = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (p >= P) return;
+    const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;                                    // wave-uniform
+    const int sub = lane & 15, cx = (lane >> 4) & 1, cy = lane >> 5;
     const float px = (float)(p % w1), py = (float)(p / w1);
     float origin = disp_in[p];
     if (shift && origin < lim) origin = lim;
-    if (origin_out && sub == 0 && blockIdx.y == 0) origin_out[p] = origin;
+    if (origin_out && lane == 0 && blockIdx.y == 0) origin_out[p] = origin;
     float4 f1q[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) f1q[q] = cer_ld4(fmap1 + p * C + 4 * sub + 64 * q);
     const int half = D / 2;
-    const long P2C = (long)h2 * w2 * C;
-    // SUM: blockIdx.y == 0 handles all views; else blockIdx.y is the view
+    // source maps carry a 2-texel zero border: [V, h2+4, w2+4, C].  Clamping the integer texel to
+    // [-2, w2] x [-2, h2] keeps all four bilinear corners inside the padded map and reproduces the
+    // reference's "texel outside -> 0" (correlation_kernel.cu:80-83) without any bounds test here.
+    const int wp = w2 + 4;
+    const long P2C = (long)(h2 + 4) * wp * C;
+    const int loff = (cy * wp + cx) * C + 4 * sub;         // this lane's corner + channel quad
+    // bilinear weight of this lane's corner: wy = cy ? dw : 1 - dw (as one exact fma), same for x
+    const float sy = cy ? 1.0f : -1.0f, by = cy ? 0.0f : 1.0f, sx = cx ? 1.0f : -1.0f, bx = cx ? 0.0f : 1.0f;
     const int v_lo = SUM ? 0 : (int)blockIdx.y, v_hi = SUM ? V : (int)blockIdx.y + 1;
     float* orow = SUM ? vol + p * rs : vol + ((long)blockIdx.y * P + p) * rs;
-    for (int k0 = 0; k0 < D; k0 += 16) {
-        float mine = 0.f;
-        const int kend = min(16, D - k0);
-        for (int j = 0; j < kend; ++j) {
-            // two roundings, as torch computes (arange(D) - D//2) * incre + origin (core/corr.py:56,65): no fma contraction
-            const float hyp = __fadd_rn(__fmul_rn((float)(k0 + j - half), incre), origin);
-            float tot = 0.f;
-            for (int v = v_lo; v < v_hi; ++v) {
-                const float* m = Pij + v * 16;
-                const float X = fmaf(m[3], hyp, fmaf(m[1], py, m[0] * px) + m[2]);
-                const float Y = fmaf(m[7], hyp, fmaf(m[5], py, m[4] * px) + m[6]);
-                const float Z = fmaf(m[11], hyp, fmaf(m[9], py, m[8] * px) + m[10]);
-                float u = X / Z, w = Y / Z;
-                const bool ok = (u == u) && (w == w);        // NaN (0/0) samples nothing
-                u = fminf(fmaxf(u, -1e4f), 1e4f);             // core/corr.py:88
-                w = fminf(fmaxf(w, -1e4f), 1e4f);
-                if (ok) {
-                    const float fu = floorf(u), fw = floorf(w);
-                    tot += cer_bilerp_dot<NQ>(fmap2 + (long)v * P2C, h2, w2, C, sub, fu, fw, u - fu, w - fw, f1q);
+
+    for (int kb = 0; kb < D; kb += 64) {
+        float acc[64];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) acc[j] = 0.f;
+        const int nk = min(64, D - kb);
+        for (int v = v_lo; v < v_hi; ++v) {
+            const float* m = Pij + v * 16;
+            const float* f2v = fmap2 + (long)v * P2C + loff;
+            // ---- projection of hypothesis kb + lane (utils/projective_ops.py:26-28, core/corr.py:56,65,88)
+            const float hyp = __fadd_rn(__fmul_rn((float)(kb + lane - half), incre), origin);
+            const float X = fmaf(m[3], hyp, fmaf(m[1], py, m[0] * px) + m[2]);
+            const float Y = fmaf(m[7], hyp, fmaf(m[5], py, m[4] * px) + m[6]);
+            const float Z = fmaf(m[11], hyp, fmaf(m[9], py, m[8] * px) + m[10]);
+            float u = X / Z, w = Y / Z;
+            const bool ok = (u == u) && (w == w);          // 0/0 samples nothing
+            u = fminf(fmaxf(u, -1e4f), 1e4f);
+            w = fminf(fmaxf(w, -1e4f), 1e4f);
+            const float fu = floorf(u), fw = floorf(w);
+            const float du = ok ? u - fu : 0.f, dw = ok ? w - fw : 0.f;
+            const int iu = ok ? min(max((int)fu, -2), w2) : -2, iw = ok ? min(max((int)fw, -2), h2) : -2;
+            const int off = ((iw + 2) * wp + (iu + 2)) * C;    // element offset of the cell's top-left texel
+            int coff = -1;                                 // cell of the previous sample (offsets are >= 0)
+            float sdot = 0.f;
+            // samples are walked in groups of 8: first all (needed) texel loads of the group are issued,
+            // then consumed - 8 loads in flight per wave instead of one dependent load per sample
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                if (g * 8 < nk) {                          // wave-uniform
+                    int soff[8];
+                    float sdu[8], sdw[8];
+                    bool need[8];
+                    float4 t[8][NQ];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        soff[i] = __builtin_amdgcn_readlane(off, g * 8 + i);
+                        sdu[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(du), g * 8 + i));
+                        sdw[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dw), g * 8 + i));
+                        need[i] = soff[i] != (i ? soff[i - 1] : coff);      // scalar: new texel cell?
+                    }
+                    coff = soff[7];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (need[i]) {
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) t[i][q] = cer_ld4(f2v + soff[i] + 64 * q);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (need[i]) {
+                            sdot = 0.f;
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) sdot = cer_dot4(f1q[q], t[i][q], sdot);
+                        }
+                        const float wy = fmaf(sy, sdw[i], by), wx = fmaf(sx, sdu[i], bx);
+                        acc[g * 8 + i] = fmaf(sdot * wy, wx, acc[g * 8 + i]);
+                    }
                 }
             }
-            tot = cer_row16_sum(tot);
-            if (sub == j) mine = tot;
         }
-        if (sub < kend) {
-            float* o = orow + k0 + sub;
-            *o = accumulate ? (*o + mine) : mine;
+        // ---- butterfly: after the six exchange steps lane l holds the wave total of acc[l]
+#pragma unroll
+        for (int hb = 32; hb >= 1; hb >>= 1) {
+            const bool up = (lane & hb) != 0;
+#pragma unroll
+            for (int i = 0; i < hb; ++i) {
+                const float send = up ? acc[i] : acc[i + hb];
+                const float keep = up ? acc[i + hb] : acc[i];
+                acc[i] = keep + __shfl_xor(send, hb);
+            }
+        }
+        if (lane < nk) {
+            float* o = orow + kb + lane;
+            *o = accumulate ? (*o + acc[0]) : acc[0];
         }
     }
 }
@@ -70,7 +135,7 @@ static int launch_build(const float* f1, const float* f2, const float* Pij, cons
     const long P = (long)h1 * w1;
     const float lim = (float)((D / 2) * incre_d);
     const float incre = (float)incre_d;
-    const unsigned gx = (unsigned)((P + 15) / 16);
+    const unsigned gx = (unsigned)((P + 3) / 4);
     if (mode == 0)
         hipLaunchKernelGGL((cost_build_kernel<NQ, false>), dim3(gx, (unsigned)V), dim3(256), 0, st, f1, f2, Pij, disp_in, vol, origin_out, V,
                            h1, w1, h2, w2, C, D, rs, incre, lim, shift, 0);
@@ -87,6 +152,7 @@ extern "C" int cer_cost_build_f32(const float* fmap1, const float* fmap2, const 
     if (!fmap1 || !fmap2 || !Pij || !disp_in || !vol) return CER_EINVAL;
     if (V <= 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || C <= 0 || D <= 0 || row_stride < D || mode < 0 || mode > 2) return CER_EINVAL;
     if (C % 64 != 0 || C > 256 || V > 65535) return CER_ESHAPE;
+    if ((long)(h2 + 4) * (w2 + 4) * C >= (1L << 31)) return CER_ESHAPE;
     if (!cer_aligned16(fmap1) || !cer_aligned16(fmap2)) return CER_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     switch (C / 64) {

@@ -45,10 +45,12 @@ def alt_corr_backward(fmap1, fmap2, coords, corr_grad, radius):
 
 
 def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, fold, vol=None, accumulate=False):
-    """fmap1 [P,C], fmap2 [V,P2,C] (NHWC, pre-scaled), Pij [V,4,4], disp_in [P].
+    """fmap1 [P,C], fmap2 [V,(h1+4)*(w1+4),C] (NHWC, pre-scaled, 2-texel zero border), Pij [V,4,4], disp_in [P].
     Returns (vol [V,P,rs] or [P,rs], origin [P]).  Level 0 only; call ``pyramid`` next."""
     V, P2, C = fmap2.shape
     P = h1 * w1
+    if P2 != (h1 + 4) * (w1 + 4):
+        raise RuntimeError("cost_build: fmap2 must carry a 2-texel zero border ([V,(h+4)*(w+4),C])")
     _, _, rs = row_layout(D, num_levels)
     if vol is None:
         shape = (P, rs) if fold else (V, P, rs)

@@ -57,7 +57,8 @@ class RAFT(nn.Module):
     # ---------------------------------------------------------------- encoders (PyTorch-ROCm)
     def encode(self, images, views):
         """images [1,N,3,H,W] in [-1,1]; ``views`` = source-view indices this rank owns
-        -> (net [P,64], inp [P,64], NHWC feature maps [1+len(views), P, C] * 1/8 with the reference view first)."""
+        -> (net [P,64], inp [P,64], reference features [P,C], source features [len(views),(h+4)*(w+4),C]);
+        features are channels-last, scaled by 1/8, source maps with a 2-texel zero border."""
         amp = self.precision == "amp"
         idx = [0] + list(views)
         with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
@@ -65,7 +66,8 @@ class RAFT(nn.Module):
             fm = self.fnet(images[0, idx]).float()                             # [n,C,h,w] (instance norm is per image)
         net = torch.tanh(ctx[: self.dim_net])
         inp = torch.relu(ctx[self.dim_net:])
-        return ops.nchw_to_nhwc(net.contiguous()), ops.nchw_to_nhwc(inp.contiguous()), fmaps_to_nhwc(fm)
+        f2 = fmaps_to_nhwc(fm[1:], border=2) if views else None
+        return ops.nchw_to_nhwc(net.contiguous()), ops.nchw_to_nhwc(inp.contiguous()), fmaps_to_nhwc(fm[:1])[0], f2
 
     # ---------------------------------------------------------------- forward
     def forward(self, images, poses, intrinsics, scale=None, do_report=False):
@@ -94,10 +96,8 @@ class RAFT(nn.Module):
         # ---- view sharding: this rank encodes and builds the partial view-sum over its own source views only
         V = num - 1
         views = cdist.local_views(V, self.view_group)
-        net_l, inp_l, nhwc = self.encode(images, views)
+        net_l, inp_l, f1, f2 = self.encode(images, views)
         del images
-        f1 = nhwc[0]
-        f2 = nhwc[1:] if views else None
         Pij = pij_matrices(poses[0], intrinsics[0], [0] * len(views), views).to(dev) if views else None
 
         disp = torch.zeros(P, device=dev, dtype=torch.float32)

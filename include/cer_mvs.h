@@ -62,8 +62,10 @@ int cer_alt_corr_backward_f32(const float* fmap1, const float* fmap2, const floa
  *   (X,Y,Z,_)   = Pij[v] * (x, y, 1, hyp[p,k]);  (u,w) = clamp((X/Z, Y/Z), +-1e4)
  *   c[v,p,k]    = sum_c fmap1[p,c] * bilerp(fmap2[v], u, w)      (texels outside -> 0;
  *                                                                 non-finite (u,w) -> 0)
- * fmap1 [h1*w1, C] and fmap2 [V, h2*w2, C] are NHWC and already carry the reference's 1/8
- * scaling (core/corr.py:30-31).  Pij [V,4,4] row-major = K_j P_j P_i^-1 K_i^-1.
+ * fmap1 [h1*w1, C] and fmap2 [V, h2+4, w2+4, C] are NHWC and already carry the reference's 1/8
+ * scaling (core/corr.py:30-31); fmap2 has a 2-texel ZERO BORDER on every side (texel (y,x) of view v at
+ * ((v*(h2+4) + y+2)*(w2+4) + x+2)*C) - the kernel clamps cells into the border instead of testing bounds.
+ * Pij [V,4,4] row-major = K_j P_j P_i^-1 K_i^-1.
  *
  * Output rows have `row_stride` floats (>= D, multiple of 4); only columns [0,D) are written
  * here (cer_pyramid_f32 fills the pooled levels behind them).

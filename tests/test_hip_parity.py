@@ -143,15 +143,16 @@ def test_cost_build_edge_cases(dev):
     intr = torch.tensor([[90.0, 0, 6.5], [0, 90.0, 3.5], [0, 0, 1]]).repeat(V + 1, 1, 1)
     disp_in = hashed((h1, w1), 82, 0.0, 0.002)
     vol_ref, origin_ref = O.cost_volume(fm, poses, intr, D, incre, disp_in, True)
-    nhwc = (fm.permute(0, 2, 3, 1) / 8.0).reshape(V + 1, h1 * w1, C).contiguous().to(dev)
+    from cer_mvs_amd.corr import fmaps_to_nhwc
+    f1, f2 = fmaps_to_nhwc(fm[:1].to(dev))[0], fmaps_to_nhwc(fm[1:].to(dev), border=2)
     Pij = O.pij_matrices(poses, intr, [0] * V, [1, 2]).contiguous()
-    vol, origin = ops.cost_build(nhwc[0], nhwc[1:].contiguous(), Pij.to(dev), disp_in.reshape(-1).to(dev), D, incre, True, h1, w1, 3, fold=False)
+    vol, origin = ops.cost_build(f1, f2, Pij.to(dev), disp_in.reshape(-1).to(dev), D, incre, True, h1, w1, 3, fold=False)
     assert torch.equal(origin.cpu().view(h1, w1), origin_ref)
     assert rel_l1(vol[..., :D].cpu(), vol_ref) < 1e-5
     assert float(vol[1, :, 1:D].abs().max()) == 0.0      # hypothesis 0 can be exactly d = 0, which projects onto itself
     bad = Pij.clone()
     bad[0, 2] = 0.0                                    # Z == 0 everywhere
-    vol2, _ = ops.cost_build(nhwc[0], nhwc[1:].contiguous(), bad.to(dev), disp_in.reshape(-1).to(dev), D, incre, True, h1, w1, 3, fold=False)
+    vol2, _ = ops.cost_build(f1, f2, bad.to(dev), disp_in.reshape(-1).to(dev), D, incre, True, h1, w1, 3, fold=False)
     assert torch.isfinite(vol2).all() and float(vol2[0].abs().max()) == 0.0
 
 
@@ -314,7 +315,9 @@ def test_full_size_properties(dev):
     # linearity: build(f2a + f2b) == build(f2a) + build(f2b)
     h1, w1, P, C, D = 296, 400, 296 * 400, 64, 64
     f1 = torch.randn(P, C, device=dev) * 0.1
-    f2a, f2b = torch.randn(2, P, C, device=dev) * 0.1, torch.randn(2, P, C, device=dev) * 0.1
+    from cer_mvs_amd.corr import fmaps_to_nhwc
+    f2a = fmaps_to_nhwc(torch.randn(2, C, h1, w1, device=dev) * 0.8, border=2)
+    f2b = fmaps_to_nhwc(torch.randn(2, C, h1, w1, device=dev) * 0.8, border=2)
     Pij = torch.eye(4).repeat(2, 1, 1)
     Pij[0, 0, 3], Pij[1, 0, 3] = 9000.0, -14000.0
     Pij = Pij.to(dev)
