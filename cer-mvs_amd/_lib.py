@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcermvs.so")
-ABI_VERSION = 1001
+ABI_VERSION = 1002
 CONV_MAX_SRC = 4
 EPI_LINEAR, EPI_RELU, EPI_GATES, EPI_GRU = 0, 1, 2, 3
 
@@ -39,6 +39,9 @@ _SIGNATURES = {
     "cer_conv3x3_packed_size": (_L, [_I, _I]),
     "cer_conv3x3_pack_f32": (_I, [_P, _P, _I, _I, _c.POINTER(_I), _c.POINTER(_I), _I]),
     "cer_conv3x3_f32": (_I, [_c.POINTER(ConvInputs), _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cer_conv3x3_f16x3_packed_size": (_L, [_I, _I]),
+    "cer_conv3x3_f16x3_pack": (_I, [_P, _P, _I, _I, _c.POINTER(_I), _c.POINTER(_I), _I]),
+    "cer_conv3x3_f16x3": (_I, [_c.POINTER(ConvInputs), _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cer_delta_tail_f32": (_I, [_P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "cer_nchw_to_nhwc_f32": (_I, [_P, _P, _I, _L, _F, _P]),
     "cer_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _L, _F, _P]),

@@ -105,8 +105,10 @@ def lookup_encode(vol, origin, disp, w_t, b, D, incre, num_levels, radius, out=N
 
 
 class PackedConv3x3:
-    """A 3x3 conv's weights in MFMA B-fragment order for a given K-source list.
-    ``sources``: list of (channels, kind) with kind 0 = tensor, 1 = disparity encoder (49)."""
+    """A 3x3 conv's weights packed for the MFMA kernels, for a given K-source list.
+    ``sources``: list of (channels, kind) with kind 0 = tensor, 1 = disparity encoder (49).
+    Two packings are kept: exact-fp32 B fragments (``packed``, v_mfma_f32_16x16x4_f32) and split
+    hi|lo f16 fragments (``packed_x``, 3 x v_mfma_f32_32x32x16_f16, fp32-equivalent accuracy)."""
 
     def __init__(self, weight, bias, sources, device):
         lib = L.load()
@@ -124,12 +126,23 @@ class PackedConv3x3:
         L.check(lib.cer_conv3x3_pack_f32(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(packed.data_ptr()), Cout, Cin, ch, kind, n),
                 "conv3x3_pack")
         self.packed = packed.to(device)
+        size_x = lib.cer_conv3x3_f16x3_packed_size(Cout, kpad)
+        if size_x <= 0:
+            raise RuntimeError(f"conv3x3 f16x3 pack: unsupported shape Cout={Cout} Kpad={kpad}")
+        packed_x = torch.empty(size_x, dtype=torch.float16)
+        L.check(lib.cer_conv3x3_f16x3_pack(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(packed_x.data_ptr()), Cout, Cin, ch, kind, n),
+                "conv3x3_f16x3_pack")
+        self.packed_x = packed_x.to(device)
         self.bias = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
         self.cout = Cout
 
 
-def conv3x3(pc, srcs, h, w, epi, out=None, out2=None, aux=None, aux2=None, init=None, use_bias=True):
+CONV_MODE = "f16x3"      # default arithmetic of ops.conv3x3: "f16x3" (split-f16 MFMA, fp32-equivalent) or "fp32" (exact fp32 MFMA)
+
+
+def conv3x3(pc, srcs, h, w, epi, out=None, out2=None, aux=None, aux2=None, init=None, use_bias=True, mode=None):
     """srcs: list of tensors matching ``pc.sources`` ([P,ch] for kind 0, disp [P] for kind 1)."""
+    mode = mode or CONV_MODE
     dev = srcs[0].device
     P = h * w
     ci = L.ConvInputs()
@@ -145,9 +158,15 @@ def conv3x3(pc, srcs, h, w, epi, out=None, out2=None, aux=None, aux2=None, init=
     if epi == L.EPI_GATES and out2 is None:
         out2 = torch.empty(P, oc, device=dev, dtype=torch.float32)
     bias = pc.bias if (use_bias and init is None) else None
-    L.check(L.load().cer_conv3x3_f32(ctypes.byref(ci), L.dev_ptr(pc.packed, "packed_w"), L.dev_ptr(bias, "bias"), L.dev_ptr(init, "init"),
-                                     L.dev_ptr(out, "out"), L.dev_ptr(out2, "out2"), L.dev_ptr(aux, "aux"), L.dev_ptr(aux2, "aux2"),
-                                     h, w, pc.cout, epi, L.cur_stream()), "conv3x3")
+    if mode == "f16x3":
+        fn, wts = L.load().cer_conv3x3_f16x3, L.dev_ptr(pc.packed_x, "packed_w", torch.float16)
+    elif mode == "fp32":
+        fn, wts = L.load().cer_conv3x3_f32, L.dev_ptr(pc.packed, "packed_w")
+    else:
+        raise ValueError(f"conv3x3: unknown mode {mode!r}")
+    L.check(fn(ctypes.byref(ci), wts, L.dev_ptr(bias, "bias"), L.dev_ptr(init, "init"),
+               L.dev_ptr(out, "out"), L.dev_ptr(out2, "out2"), L.dev_ptr(aux, "aux"), L.dev_ptr(aux2, "aux2"),
+               h, w, pc.cout, epi, L.cur_stream()), f"conv3x3[{mode}]")
     return (out, out2) if epi == L.EPI_GATES else out
 
 

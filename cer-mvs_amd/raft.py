@@ -9,7 +9,9 @@ reference that a caller can observe, all deliberate (SURVEY.md §8(a) "quirks"):
   * `scale` may be a float or a tensor on any device (reference: raft.py:108 calls scale.cuda());
   * computation is fp32 end to end by default (``precision="fp32"``); the reference's GPU path runs
     encoders + GRU under fp16 autocast (raft.py:9,55), selectable with ``precision="amp"`` for the
-    encoders only.
+    encoders only.  ``gru_precision`` picks the arithmetic of the update block's 3x3 convolutions:
+    "f16x3" (default: split-f16 MFMA with two fp32 accumulators, fp32-equivalent accuracy, 5.3x the
+    fp32-MFMA rate) or "fp32" (exact v_mfma_f32_16x16x4_f32).
 Multi-GPU: ``view_group`` = a torch.distributed process group over which source views are sharded
 (rank g owns views v with v % G == g); the level-0 view-sum volume is all-reduced once per stage
 (RCCL over xGMI) and everything after it is replicated."""
@@ -26,7 +28,7 @@ from .update import UpdateBlock
 
 class RAFT(nn.Module):
     def __init__(self, cascade=[(64, 64, 8), (-1, 320, 8)], encoder_type="HR", dim_fmap=64, dim_net=64, dim_inp=64,
-                 test_mode=False, precision="fp32", view_group=None):
+                 test_mode=False, precision="fp32", view_group=None, gru_precision="f16x3"):
         super().__init__()
         self.cascade = [tuple(c) for c in cascade]
         self.encoder_type = encoder_type
@@ -37,6 +39,7 @@ class RAFT(nn.Module):
         self.fnet = BasicEncoder(output_dim=dim_fmap, norm_fn="instance", type=encoder_type)
         self.cnet = BasicEncoder(output_dim=dim_net + dim_inp, norm_fn="none", type=encoder_type)
         self.update_block = UpdateBlock(cascade=self.cascade, dim_net=dim_net, dim_inp=dim_inp)
+        self.update_block.conv_mode = gru_precision
         self.last_timings = None
 
     def load_state_dict(self, state_dict, strict=True, **kw):

@@ -66,7 +66,7 @@ class _Strided:
     """A PackedConv3x3 viewed with run-time source strides (padded tensors)."""
 
     def __init__(self, pc, sources):
-        self.packed, self.bias, self.cout, self.sources = pc.packed, pc.bias, pc.cout, sources
+        self.packed, self.packed_x, self.bias, self.cout, self.sources = pc.packed, pc.packed_x, pc.bias, pc.cout, sources
 
 
 def _with_stride(pc, sources):
@@ -99,6 +99,7 @@ class UpdateBlock(nn.Module):
         i_planes = dim_inp + dim1_corr + size_disp_enc ** 2
         for i in (range(n_cascade) if not share_gru else [""]):
             setattr(self, f"gru{i}", ConvGRU(h_planes=dim_net, i_planes=i_planes))
+        self.conv_mode = "f16x3"          # "f16x3" (split-f16 MFMA, fp32-equivalent) or "fp32" (exact fp32 MFMA)
         self._packed = {}
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.refresh_weights())
 
@@ -155,7 +156,7 @@ class UpdateBlock(nn.Module):
     def hoist(self, inp_l, h, w, stage=0):
         """Contribution of the constant `inp` slice (+ biases) to the z|r and q pre-activations."""
         p = self.packed(stage, inp_l.device)
-        return (ops.conv3x3(p["zr_inp"], [inp_l], h, w, L.EPI_LINEAR), ops.conv3x3(p["q_inp"], [inp_l], h, w, L.EPI_LINEAR))
+        return (ops.conv3x3(p["zr_inp"], [inp_l], h, w, L.EPI_LINEAR, mode=self.conv_mode), ops.conv3x3(p["q_inp"], [inp_l], h, w, L.EPI_LINEAR, mode=self.conv_mode))
 
     def step(self, vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws):
         """One GRU iteration on the folded volume; updates ``net_l`` [P,64] and ``disp`` [P] in place.
@@ -166,7 +167,7 @@ class UpdateBlock(nn.Module):
         ops.conv3x3(p["corr2"], [ws["c1"]], h, w, L.EPI_RELU, out=ws["c2"])
         ops.conv3x3(p["zr_rest"], [net_l, disp, ws["c2"]], h, w, L.EPI_GATES, out=ws["z"], out2=ws["rn"], aux=net_l, init=hzr)
         ops.conv3x3(p["q_rest"], [ws["rn"], disp, ws["c2"]], h, w, L.EPI_GRU, out=net_l, aux=net_l, aux2=ws["z"], init=hq)
-        ops.conv3x3(p["d1"], [net_l], h, w, L.EPI_RELU, out=ws["hid"])
+        ops.conv3x3(p["d1"], [net_l], h, w, L.EPI_RELU, mode=self.conv_mode, out=ws["hid"])
         ops.delta_tail(ws["hid"], p["d2w"], p["d2b"], disp, h, w, disp_out=disp, want_delta=False)
 
     @staticmethod
@@ -210,10 +211,10 @@ class UpdateBlock(nn.Module):
             # stack(dim=2).view(...) in the reference interleaves [part][channel]: channel-major then part
             agg = torch.stack(parts, dim=1).reshape(1, -1, P).contiguous()
             c1 = ops.corr_encode(agg, p["w0t"], p["b0"])
-        c2 = ops.conv3x3(p["corr2"], [c1], ht, wd, L.EPI_RELU)
-        z, rn = ops.conv3x3(p["zr_full"], [net_l, inp_l, disp_l, c2], ht, wd, L.EPI_GATES, aux=net_l)
-        new = ops.conv3x3(p["q_full"], [rn, inp_l, disp_l, c2], ht, wd, L.EPI_GRU, aux=net_l, aux2=z)
-        hid = ops.conv3x3(p["d1"], [new], ht, wd, L.EPI_RELU)
+        c2 = ops.conv3x3(p["corr2"], [c1], ht, wd, L.EPI_RELU, mode=self.conv_mode)
+        z, rn = ops.conv3x3(p["zr_full"], [net_l, inp_l, disp_l, c2], ht, wd, L.EPI_GATES, mode=self.conv_mode, aux=net_l)
+        new = ops.conv3x3(p["q_full"], [rn, inp_l, disp_l, c2], ht, wd, L.EPI_GRU, mode=self.conv_mode, aux=net_l, aux2=z)
+        hid = ops.conv3x3(p["d1"], [new], ht, wd, L.EPI_RELU, mode=self.conv_mode)
         _, delta = ops.delta_tail(hid, p["d2w"], p["d2b"], disp_l, ht, wd)
         net_out = ops.nhwc_to_nchw(new).view(batch, num, ch, ht, wd)
         return net_out, delta.view(batch, num, ht, wd)

@@ -157,6 +157,18 @@ int cer_conv3x3_f32(const cer_conv_inputs* in, const float* packed_w, const floa
                     float* out, float* out2, const float* aux, const float* aux2,
                     int h, int w, int Cout, int epi, void* stream);
 
+/* Same convolution on the f16 matrix cores with fp32-equivalent accuracy ("f16x3": every fp32 operand is
+ * split x = f16(x) + 2^-11 * f16((x - f16(x)) * 2^11); three v_mfma_f32_32x32x16_f16 per tile into two fp32
+ * accumulators; the dropped lo*lo term is 2^-22 relative).  Same arguments and epilogues as cer_conv3x3_f32;
+ * weights packed by cer_conv3x3_f16x3_pack (size in 2-byte halves from cer_conv3x3_f16x3_packed_size;
+ * Kpad = sum over sources of channels rounded up to 32, 64 for kind 1).  Cout % 64 == 0. */
+long cer_conv3x3_f16x3_packed_size(int Cout, int Kpad);
+int cer_conv3x3_f16x3_pack(const float* w_oihw, void* packed, int Cout, int Cin,
+                           const int* ch, const int* kind, int nsrc);
+int cer_conv3x3_f16x3(const cer_conv_inputs* in, const void* packed_w, const float* bias, const float* init,
+                      float* out, float* out2, const float* aux, const float* aux2,
+                      int h, int w, int Cout, int epi, void* stream);
+
 /* delta head tail (reference: core/update.py:70-71,114 and core/raft.py:101):
  *   delta[p] = 0.01 * (b + sum_{tap,c} w[tap,c] * hid[p+tap, c]);  disp_out[p] = disp_in[p] + delta[p]
  * hid [h*w, C] (already ReLU'd), w [9, C] (tap-major), C % 256 == 0.  delta may be NULL.

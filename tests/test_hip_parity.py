@@ -177,8 +177,9 @@ def test_lookup_edge_cases(dev):
 
 
 # ------------------------------------------------------------------------------------ conv kernels
-@pytest.mark.parametrize("h,w,cout", [(8, 16, 64), (11, 21, 64), (9, 17, 128), (16, 32, 256)])
-def test_conv3x3_matches_torch(dev, h, w, cout):
+@pytest.mark.parametrize("mode", ["fp32", "f16x3"])
+@pytest.mark.parametrize("h,w,cout", [(8, 16, 64), (11, 21, 64), (9, 17, 128), (16, 32, 256), (5, 70, 128)])
+def test_conv3x3_matches_torch(dev, h, w, cout, mode):
     from cer_mvs_amd import _lib as L, ops
     cin = 64
     x = hashed((1, cin, h, w), 101)
@@ -187,10 +188,40 @@ def test_conv3x3_matches_torch(dev, h, w, cout):
     ref = F.conv2d(x, wt, b, padding=1)[0].permute(1, 2, 0).reshape(h * w, cout)
     pc = ops.PackedConv3x3(wt, b, [(cin, 0)], dev)
     xl = x[0].permute(1, 2, 0).reshape(h * w, cin).contiguous().to(dev)
-    out = ops.conv3x3(pc, [xl], h, w, L.EPI_LINEAR)
-    assert rel_l1(out.cpu(), ref) < 1e-5
-    out = ops.conv3x3(pc, [xl], h, w, L.EPI_RELU)
-    assert rel_l1(out.cpu(), F.relu(ref)) < 1e-5
+    out = ops.conv3x3(pc, [xl], h, w, L.EPI_LINEAR, mode=mode)
+    assert rel_l1(out.cpu(), ref) < 2e-6
+    out = ops.conv3x3(pc, [xl], h, w, L.EPI_RELU, mode=mode)
+    assert rel_l1(out.cpu(), F.relu(ref)) < 2e-6
+
+
+def test_conv3x3_f16x3_dynamic_range(dev):
+    """The split keeps fp32-class accuracy for tiny and large activations (fp16 subnormal / near-overflow ranges)
+    and saturates beyond +-65504 instead of producing inf."""
+    from cer_mvs_amd import _lib as L, ops
+    h, w, cin, cout = 8, 32, 32, 64
+    x = hashed((1, cin, h, w), 121)
+    scale = torch.logspace(-4, 4, h * w).view(1, 1, h, w)           # 1e-4 .. 1e4 per pixel
+    x = x * scale
+    wt = hashed((cout, cin, 3, 3), 122, -0.2, 0.2)
+    ref = F.conv2d(x.double(), wt.double(), None, padding=1)[0].permute(1, 2, 0).reshape(h * w, cout)
+    pc = ops.PackedConv3x3(wt, None, [(cin, 0)], dev)
+    xl = x[0].permute(1, 2, 0).reshape(h * w, cin).contiguous().to(dev)
+    got = ops.conv3x3(pc, [xl], h, w, L.EPI_LINEAR, mode="f16x3").cpu().double()
+    exact = ops.conv3x3(pc, [xl], h, w, L.EPI_LINEAR, mode="fp32").cpu().double()
+    mag = F.conv2d(x.abs().double(), wt.abs().double(), None, padding=1)[0].permute(1, 2, 0).reshape(h * w, cout)
+    assert float(((got - ref).abs() / mag).max()) < 2e-6            # error relative to sum |x||w| per output
+    assert float(((exact - ref).abs() / mag).max()) < 2e-6
+    # below the f16 normal range the split has an ABSOLUTE resolution of 2^-25 * 2^-11 ~ 1.5e-11 per operand
+    # (f16 subnormal step on the scaled lo half): error <= 2e-6 * sum|x||w| + 3e-11 * sum|w|
+    tiny = (hashed((h * w, cin), 123) * torch.logspace(-8, -5, h * w).view(-1, 1)).contiguous()
+    tref = F.conv2d(tiny.t().reshape(1, cin, h, w).double(), wt.double(), None, padding=1)[0].permute(1, 2, 0).reshape(h * w, cout)
+    tmag = F.conv2d(tiny.t().reshape(1, cin, h, w).abs().double(), wt.abs().double(), None, padding=1)[0].permute(1, 2, 0).reshape(h * w, cout)
+    tgot = ops.conv3x3(pc, [tiny.to(dev)], h, w, L.EPI_LINEAR, mode="f16x3").cpu().double()
+    wsum = F.conv2d(torch.ones(1, cin, h, w).double(), wt.abs().double(), None, padding=1)[0].permute(1, 2, 0).reshape(h * w, cout)
+    assert bool(((tgot - tref).abs() <= 2e-6 * tmag + 3e-11 * wsum).all())
+    big = torch.full((h * w, cin), 1e6, device=dev)
+    out = ops.conv3x3(pc, [big], h, w, L.EPI_LINEAR, mode="f16x3")
+    assert torch.isfinite(out).all()
 
 
 def test_conv3x3_disp_encoder_source(dev):
@@ -205,12 +236,14 @@ def test_conv3x3_disp_encoder_source(dev):
     ref = F.conv2d(torch.cat([a, feat], 1), wt, None, padding=1)[0].permute(1, 2, 0).reshape(h * w, cout)
     pc = ops.PackedConv3x3(wt, None, [(32, 0), (49, 1)], dev)
     al = a[0].permute(1, 2, 0).reshape(h * w, 32).contiguous().to(dev)
-    out = ops.conv3x3(pc, [al, disp.reshape(-1).to(dev)], h, w, L.EPI_LINEAR)
-    assert rel_l1(out.cpu(), ref) < 1e-5
+    for mode in ("fp32", "f16x3"):
+        out = ops.conv3x3(pc, [al, disp.reshape(-1).to(dev)], h, w, L.EPI_LINEAR, mode=mode)
+        assert rel_l1(out.cpu(), ref) < 2e-6, mode
 
 
+@pytest.mark.parametrize("mode", ["fp32", "f16x3"])
 @pytest.mark.parametrize("stage", [0, 1])
-def test_update_block_matches_reference_capture(dev, golden, stage):
+def test_update_block_matches_reference_capture(dev, golden, stage, mode):
     from cer_mvs_amd import RAFT
     from cer_mvs_amd.synthetic import fill_state_dict
     g = golden("update")
@@ -218,6 +251,7 @@ def test_update_block_matches_reference_capture(dev, golden, stage):
     model = RAFT(cascade=[(64, 64, 1), (-1, 320, 1)], test_mode=True)
     model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(g["weight_seed"])))
     ub = model.update_block.to(dev)
+    ub.conv_mode = mode
     net = torch.tanh(hashed((1, 1, 64, h1, w1), 31, -2, 2))
     inp = torch.relu(hashed((1, 1, 64, h1, w1), 32, -1, 2))
     disp = hashed((1, 1, h1, w1), 33, 0.0, 0.0025)
@@ -229,7 +263,7 @@ def test_update_block_matches_reference_capture(dev, golden, stage):
 
 
 # ------------------------------------------------------------------------------------ end to end
-def _run_e2e(dev, golden, name, literal=False):
+def _run_e2e(dev, golden, name, literal=False, gru_precision="f16x3"):
     from cer_mvs_amd import RAFT
     from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene, tensor_checksum
     g = golden(name)
@@ -237,7 +271,7 @@ def _run_e2e(dev, golden, name, literal=False):
     cascade = [tuple(int(x) for x in c) for c in g["cascade"]]
     images, poses, intr, scale = synthetic_scene(H, W, V, seed=int(g["scene_seed"]))
     assert tensor_checksum(images) == int(g["images_checksum"])
-    model = RAFT(cascade=cascade, test_mode=True)
+    model = RAFT(cascade=cascade, test_mode=True, gru_precision=gru_precision)
     model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(g["weight_seed"])))
     model = model.to(dev).eval()
     before = images.clone()
@@ -266,10 +300,11 @@ def test_end_to_end_tiny_literal_api(dev, golden):
     assert e_disp < TOL and e_depth < TOL
 
 
-def test_end_to_end_cfg1(dev, golden):
+@pytest.mark.parametrize("gru_precision", ["f16x3", "fp32"])
+def test_end_to_end_cfg1(dev, golden, gru_precision):
     """BASELINE.json configs[0] shape: 640x480, 1 ref + 2 src views, 4 GRU iterations."""
-    e_disp, e_depth = _run_e2e(dev, golden, "e2e_cfg1")
-    print(f"e2e_cfg1 rel-L1 disp {e_disp:.3e} depth {e_depth:.3e}")
+    e_disp, e_depth = _run_e2e(dev, golden, "e2e_cfg1", gru_precision=gru_precision)
+    print(f"e2e_cfg1[{gru_precision}] rel-L1 disp {e_disp:.3e} depth {e_depth:.3e}")
     assert e_disp < TOL and e_depth < TOL
 
 
