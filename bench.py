@@ -77,9 +77,9 @@ def kernel_timing(model, inputs, scale):
         return inner
 
     def conv_label(pc, srcs, h, w, epi, **k):
-        return {0: "conv3x3_linear", 1: f"conv3x3_relu_{pc.cout}", 2: "conv3x3_gates_zr", 3: "conv3x3_gru_q"}[epi]
+        return {0: "conv3x3_linear", 1: f"conv3x3_relu_{pc.cout}", 2: "conv3x3_gates_zr", 3: "conv3x3_gru_q", 4: "conv3x3_delta_fused"}[epi]
 
-    for name in ("cost_build", "pyramid", "lookup_encode", "delta_tail"):
+    for name in ("cost_build", "pyramid", "lookup_encode", "delta_tail", "delta_sum"):
         originals[name] = getattr(ops, name)
         setattr(ops, name, wrap(name, originals[name]))
     originals["conv3x3"] = ops.conv3x3
@@ -234,7 +234,7 @@ def main():
         achieved = flops_zr / (t_zr / n_zr * 1e-3) / 1e12
         if args.gru_precision == "f16x3":
             # every fp32 product costs 3 f16 MFMA products -> ceiling = f16 dense peak / 3 in fp32-equivalent flops
-            peak, kname = F16_MFMA_PEAK_TFLOPS / 3, "conv3x3_f16x3_kernel<2,2,2,2,GATES> (z|r gates, 3x3, K=177, N=128; 3 f16 MFMAs per fp32 product)"
+            peak, kname = F16_MFMA_PEAK_TFLOPS / 3, "conv3x3_f16x3_kernel<4,2,1,2,3,4,GATES> (z|r gates, 3x3, K=177, N=128; 3 f16 MFMAs per fp32 product)"
         else:
             peak, kname = FP32_MFMA_PEAK_TFLOPS, "conv3x3_kernel<2,2,4,4,GATES> (z|r gates, 3x3, K=177, N=128; exact fp32 MFMA)"
         roofline = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,

@@ -8,10 +8,10 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcermvs.so")
-ABI_VERSION = 1002
+LIB_PATH = os.environ.get("CER_MVS_LIB") or os.path.join(_HERE, "csrc", "libcermvs.so")
+ABI_VERSION = 1003
 CONV_MAX_SRC = 4
-EPI_LINEAR, EPI_RELU, EPI_GATES, EPI_GRU = 0, 1, 2, 3
+EPI_LINEAR, EPI_RELU, EPI_GATES, EPI_GRU, EPI_DELTA = 0, 1, 2, 3, 4
 
 _c = ctypes
 _P = _c.c_void_p
@@ -42,6 +42,9 @@ _SIGNATURES = {
     "cer_conv3x3_f16x3_packed_size": (_L, [_I, _I]),
     "cer_conv3x3_f16x3_pack": (_I, [_P, _P, _I, _I, _c.POINTER(_I), _c.POINTER(_I), _I]),
     "cer_conv3x3_f16x3": (_I, [_c.POINTER(ConvInputs), _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cer_delta_proj_packed_size": (_L, [_I]),
+    "cer_delta_proj_pack": (_I, [_P, _P, _I]),
+    "cer_delta_sum_f32": (_I, [_P, _I, _F, _P, _P, _P, _I, _I, _P]),
     "cer_delta_tail_f32": (_I, [_P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "cer_nchw_to_nhwc_f32": (_I, [_P, _P, _I, _L, _F, _P]),
     "cer_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _L, _F, _P]),

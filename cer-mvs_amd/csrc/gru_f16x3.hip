@@ -21,7 +21,11 @@
 //     3 MFMAs per 32x32 output tile;
 //   * gate math in the epilogue, identical to the fp32 kernel.
 #include "common.hpp"
+#include <stdlib.h>
 #include <string.h>
+#ifndef HX_ABL
+#define HX_ABL 0      // profiling ablations, compile time: 1 no MFMA, 2 no barriers, 4 no staging, 8 no init/epilogue, 16 no weight DMA
+#endif
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -34,6 +38,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define HX_KC 32                       // channels per chunk
 #define HX_AS 144                      // LDS bytes per halo pixel: 32 hi | 32 lo | 16 pad
 #define HX_A_BYTES (HX_ROWS * HX_AS)   // 29376
+#define HX_EPI_DELTA 4                 // conv + ReLU + projection onto the 9 taps of the 256->1 delta conv (cer_mvs.h: CER_EPI_DELTA)
+#define HX_HS 272                      // LDS bytes per pixel row of the hidden tile (128 f16 + 16 pad: conflict-free b128 reads)
 
 struct ConvArgsX {
     const float* src[CER_CONV_MAX_SRC];
@@ -60,71 +66,109 @@ __device__ __forceinline__ void hx_split(float v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)((x - (float)hi) * 2048.0f);
 }
 
-// stage one 32-channel chunk of source s (channel offset c0) for the tile at (ty0, tx0): fp32 -> hi|lo f16
-__device__ __forceinline__ void hx_stage(char* __restrict__ ldsA, const ConvArgsX& a, int s, int c0, int ty0, int tx0) {
-    const int kind = a.kind[s];
-    for (int idx = threadIdx.x; idx < HX_ROWS * 4; idx += 256) {
+#define HX_DT_H (HX_HH + 6)            // disparity tile rows (halo + 3 each side for the 7x7 unfold)
+#define HX_DT_W (HX_HW + 6)
+#define HX_D_BYTES (HX_DT_H * HX_DT_W * 4)
+
+__device__ __forceinline__ void hx_write8(char* __restrict__ ldsA, int row, int g, const float (&v)[8]) {
+    half8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        _Float16 h, l;
+        hx_split(v[i], h, l);
+        hi[i] = h;
+        lo[i] = l;
+    }
+    *reinterpret_cast<half8*>(ldsA + row * HX_AS + g * 16) = hi;
+    *reinterpret_cast<half8*>(ldsA + row * HX_AS + 64 + g * 16) = lo;
+}
+
+// kind-0 chunk: every thread first issues ALL its loads (addresses clamped into the image so the loads are
+// unconditional and independent), then splits fp32 -> hi|lo f16 and writes the LDS tile (zero padding here).
+template <int NTHR>
+__device__ __forceinline__ void hx_stage_tensor(char* __restrict__ ldsA, const ConvArgsX& a, int s, int c0, int ty0, int tx0) {
+    constexpr int ITEMS = (HX_ROWS * 4 + NTHR - 1) / NTHR;
+    float4 raw[ITEMS][2];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int idx = min((int)threadIdx.x + NTHR * i, HX_ROWS * 4 - 1);
         const int row = idx >> 2, g = idx & 3;
         const int hy = row / HX_HW, hx = row - hy * HX_HW;
-        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-        const bool inside = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
-        float v[8];
+        const int gy = min(max(ty0 + hy - 1, 0), a.h - 1), gx = min(max(tx0 + hx - 1, 0), a.w - 1);
+        const float* p = a.src[s] + ((long)gy * a.w + gx) * a.ch[s] + c0 + 8 * g;
+        raw[i][0] = cer_ld4(p);
+        raw[i][1] = cer_ld4(p + 4);
+    }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = 0.f;
-        if (inside) {
-            if (kind == 0) {
-                const float* p = a.src[s] + ((long)gy * a.w + gx) * a.ch[s] + c0 + 8 * g;
-                const float4 lo4 = cer_ld4(p), hi4 = cer_ld4(p + 4);
-                v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w;
-                v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
-            } else {
-                const float* d = a.src[s];
-                const float ctr = d[(long)gy * a.w + gx];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int c = c0 + 8 * g + i;
-                    if (c < 49) {
-                        const int uy = c / 7, ux = c - uy * 7;
-                        const int yy = gy + uy - 3, xx = gx + ux - 3;
-                        const float nb = (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) ? d[(long)yy * a.w + xx] : 0.f;
-                        v[i] = 100.0f * (nb - ctr);
-                    }
-                }
-            }
+    for (int i = 0; i < ITEMS; ++i) {
+        const int idx = threadIdx.x + NTHR * i;
+        if (idx < HX_ROWS * 4) {
+            const int row = idx >> 2;
+            const int hy = row / HX_HW, hx = row - hy * HX_HW;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            const float m = (gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) ? 1.0f : 0.0f;
+            const float v[8] = {raw[i][0].x * m, raw[i][0].y * m, raw[i][0].z * m, raw[i][0].w * m,
+                                raw[i][1].x * m, raw[i][1].y * m, raw[i][1].z * m, raw[i][1].w * m};
+            hx_write8(ldsA, row, idx & 3, v);
         }
-        half8 hi, lo;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            _Float16 h, l;
-            hx_split(v[i], h, l);
-            hi[i] = h;
-            lo[i] = l;
-        }
-        *reinterpret_cast<half8*>(ldsA + row * HX_AS + g * 16) = hi;
-        *reinterpret_cast<half8*>(ldsA + row * HX_AS + 64 + g * 16) = lo;
     }
 }
 
-// DMA the block's weight slice of (chunk, tap) into an LDS buffer: NB/8 KiB = NB/8 pieces of 1 KiB
-template <int NB>
+// disparity tile (zero outside the image) -> LDS, once per block; feeds the on-the-fly disparity encoder
+template <int NTHR>
+__device__ __forceinline__ void hx_load_disp_tile(float* __restrict__ ldsD, const float* __restrict__ d, int h, int w, int ty0, int tx0) {
+    for (int idx = threadIdx.x; idx < HX_DT_H * HX_DT_W; idx += NTHR) {
+        const int r = idx / HX_DT_W, c = idx - r * HX_DT_W;
+        const int gy = ty0 + r - 4, gx = tx0 + c - 4;
+        ldsD[idx] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? d[(long)gy * w + gx] : 0.f;
+    }
+}
+
+// kind-1 chunk: 100 * (unfold7x7(disp) - disp) (core/update.py:80-85,97) generated from the LDS disparity tile
+template <int NTHR>
+__device__ __forceinline__ void hx_stage_disp(char* __restrict__ ldsA, const float* __restrict__ ldsD, const ConvArgsX& a, int c0, int ty0,
+                                              int tx0) {
+    for (int idx = threadIdx.x; idx < HX_ROWS * 4; idx += NTHR) {
+        const int row = idx >> 2, g = idx & 3;
+        const int hy = row / HX_HW, hx = row - hy * HX_HW;
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        const bool inside = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;      // the 3x3 conv zero-pads the FEATURE map
+        const float ctr = ldsD[(hy + 3) * HX_DT_W + hx + 3];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + 8 * g + e;
+            const int uy = c / 7, ux = c - uy * 7;
+            v[e] = (inside && c < 49) ? 100.0f * (ldsD[(hy + uy) * HX_DT_W + hx + ux] - ctr) : 0.f;
+        }
+        hx_write8(ldsA, row, g, v);
+    }
+}
+
+// DMA the block's weight slice of one (chunk, tap) step into an LDS ring slot: NB/8 pieces of 1 KiB
+template <int NB, int NWAVES>
 __device__ __forceinline__ void hx_issue_B(char* __restrict__ ldsB, const _Float16* __restrict__ slice) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < NB / 32; ++i) {
-        const int piece = wave + 4 * i;
+    for (int i = 0; i < NB / 8 / NWAVES; ++i) {
+        const int piece = wave + NWAVES * i;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slice + piece * 512 + lane * 8),
                                          (__attribute__((address_space(3))) void*)(ldsB + piece * 1024), 16, 0, 0);
     }
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int EPI>
-__global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const ConvArgsX a) {
-    static_assert(WAVES_M * WAVES_N == 4 && WAVES_M * WM == HX_TH, "tile config");
+// WAVES_M x WAVES_N waves, each owning WM x WN MFMA tiles of 32 pixels x 32 channels; NBUF = weight ring depth
+template <int WAVES_M, int WAVES_N, int WM, int WN, int NBUF, int MINW, int EPI>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_kernel(const ConvArgsX a) {
+    static_assert(WAVES_M * WM == HX_TH, "tile config");
+    constexpr int NWAVES = WAVES_M * WAVES_N, NTHR = 64 * NWAVES;
     constexpr int NB = WAVES_N * WN * 32;                  // output channels per block
-    constexpr int B_BYTES = NB * 128;                      // per (chunk, tap): NB/32 n-tiles x 4 KiB
+    constexpr int B_BYTES = NB * 128;                      // per (chunk, tap) step: NB/32 n-tiles x 4 KiB
+    constexpr int DMA_PER_WAVE = NB / 8 / NWAVES;          // global_load_lds instructions per wave per step
     extern __shared__ __attribute__((aligned(16))) char hx_smem[];
     char* ldsA = hx_smem;
-    char* ldsB = hx_smem + HX_A_BYTES;                     // two buffers of B_BYTES
+    char* ldsB = hx_smem + HX_A_BYTES;                     // NBUF ring slots of B_BYTES
+    float* ldsD = reinterpret_cast<float*>(hx_smem + HX_A_BYTES + NBUF * B_BYTES);
 
     const int tile = blockIdx.x;
     const int ty0 = (tile / a.tiles_x) * HX_TH, tx0 = (tile % a.tiles_x) * HX_TW;
@@ -133,6 +177,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const ConvArgsX a
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int li = lane & 31, kg = lane >> 5;
     const int NT = a.cout / 32;
+
+    // ---- pipeline prologue: the weight DMA ring runs NBUF-1 steps ahead of the multiply, across chunk boundaries
+    int nsteps = 0;
+    for (int s = 0; s < a.nsrc; ++s) nsteps += (a.chpad[s] / HX_KC) * 9;
+    const _Float16* wbase = a.wpk + (long)(nb0 / 32) * 2048;      // + step * NT * 2048, step = chunk * 9 + tap
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i)
+        if (i < nsteps && !(HX_ABL & 16)) hx_issue_B<NB, NWAVES>(ldsB + i * B_BYTES, wbase + (long)i * NT * 2048);
+    for (int s = 0; s < a.nsrc; ++s)
+        if (a.kind[s] == 1) hx_load_disp_tile<NTHR>(ldsD, a.src[s], a.h, a.w, ty0, tx0);
 
     floatx16 accm[WM][WN], accl[WM][WN];
 #pragma unroll
@@ -144,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const ConvArgsX a
             floatx16 v;
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = 0.f;
-            if (a.init) {
+            if (a.init && !(HX_ABL & 8)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int gx = tx0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
@@ -161,19 +215,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const ConvArgsX a
         }
     }
 
-    int chunk = 0;
+    int step = 0;                                          // chunk * 9 + tap; ring slot = step % NBUF
     for (int s = 0; s < a.nsrc; ++s) {
-        for (int c0 = 0; c0 < a.chpad[s]; c0 += HX_KC, ++chunk) {
-            const _Float16* wchunk = a.wpk + ((long)chunk * 9 * NT + nb0 / 32) * 2048;    // halves: 4 KiB per n-tile
-            __syncthreads();                               // previous chunk fully consumed (A and both B buffers)
-            hx_stage(ldsA, a, s, c0, ty0, tx0);
-            hx_issue_B<NB>(ldsB, wchunk);
+        for (int c0 = 0; c0 < a.chpad[s]; c0 += HX_KC) {
+            __syncthreads();                               // every wave has finished reading A (previous chunk, tap 8); ldsD visible
+            if (!(HX_ABL & 4)) {
+                if (a.kind[s] == 0) hx_stage_tensor<NTHR>(ldsA, a, s, c0, ty0, tx0);
+                else hx_stage_disp<NTHR>(ldsA, ldsD, a, c0, ty0, tx0);
+            }
 #pragma unroll 1
-            for (int tap = 0; tap < 9; ++tap) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of B[tap] has landed in LDS
-                __syncthreads();                           // everyone's share landed, A visible, tap-1 consumed
-                if (tap < 8) hx_issue_B<NB>(ldsB + ((tap + 1) & 1) * B_BYTES, wchunk + (long)(tap + 1) * NT * 2048);
-                const char* B = ldsB + (tap & 1) * B_BYTES;
+            for (int tap = 0; tap < 9; ++tap, ++step) {
+                // B[step] was DMA'd NBUF-1 steps ago.  VMEM ops retire in order, so leaving the DMAs of the NBUF-2 younger
+                // steps in flight still guarantees B[step].  (Builtin waits: hipcc's own scoreboard must see them.)
+                const int younger = min(NBUF - 2, nsteps - 1 - step);
+                if (NBUF >= 3 && younger >= 1) __builtin_amdgcn_s_waitcnt(0x0F70 | DMA_PER_WAVE);
+                else __builtin_amdgcn_s_waitcnt(0x0F70);
+                __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): this wave's LDS writes (A tile) are done
+                if (!(HX_ABL & 2)) __builtin_amdgcn_s_barrier();   // all shares of B[step] + A visible; slot of B[step-1] free
+                if (step + NBUF - 1 < nsteps && !(HX_ABL & 16))
+                    hx_issue_B<NB, NWAVES>(ldsB + ((step + NBUF - 1) % NBUF) * B_BYTES, wbase + (long)(step + NBUF - 1) * NT * 2048);
+                const char* B = ldsB + (step % NBUF) * B_BYTES;
                 const int dy = tap / 3, dx = tap - dy * 3;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -195,9 +256,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const ConvArgsX a
                     for (int m = 0; m < WM; ++m)
 #pragma unroll
                         for (int n = 0; n < WN; ++n) {
-                            accm[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], accm[m][n], 0, 0, 0);
-                            accl[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], accl[m][n], 0, 0, 0);
-                            accl[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], accl[m][n], 0, 0, 0);
+                            if (HX_ABL & 1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                                asm volatile("" ::"v"(ah[m]), "v"(al[m]), "v"(bh[n]), "v"(bl[n]));
+#endif
+                            } else {
+                                accm[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], accm[m][n], 0, 0, 0);
+                                accl[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], accl[m][n], 0, 0, 0);
+                                accl[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], accl[m][n], 0, 0, 0);
+                            }
                         }
                 }
             }
@@ -206,6 +273,62 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const ConvArgsX a
 
     // ---- epilogue: lane holds channel co, pixels x = tx0 + (r&3) + 8*(r>>2) + 4*kg of row gy
     const int half = a.cout / 2;
+    if (HX_ABL & 8) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        for (int m = 0; m < WM; ++m) for (int n = 0; n < WN; ++n) asm volatile("" ::"v"(accm[m][n]), "v"(accl[m][n]));
+#endif
+        return;
+    }
+    if constexpr (EPI == HX_EPI_DELTA) {
+        // delta head, fused: hid = relu(conv) never leaves the CU.  The block's 128 x 128 (pixel x channel) hidden tile is
+        // split to hi|lo f16 into LDS (A-operand order) and multiplied by the 256->1 conv's weights arranged as a
+        // [channel x 9 taps] matrix: T[tap][p] = sum_c w2[tap][c] * hid[p][c] over this block's 128 channels, again with
+        // 3 f16 MFMAs per product.  cer_delta_sum_f32 then gathers the 9 tap planes of both channel halves.
+        static_assert(EPI != HX_EPI_DELTA || (NB == 128 && WM == 1), "DELTA epilogue is built for the 128-channel config");
+        char* Hhi = hx_smem;
+        char* Hlo = hx_smem + 128 * HX_HS;
+        __syncthreads();                                   // main loop finished everywhere: A/B LDS can be reused
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const int col = (wn * WN + n) * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int prow = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const float v = fmaxf(fmaf(accl[0][n][r], 1.0f / 2048.0f, accm[0][n][r]), 0.f);
+                _Float16 h, l;
+                hx_split(v, h, l);
+                *reinterpret_cast<_Float16*>(Hhi + prow * HX_HS + col * 2) = h;
+                *reinterpret_cast<_Float16*>(Hlo + prow * HX_HS + col * 2) = l;
+            }
+        }
+        __syncthreads();
+        if (wave < 4) {                                    // one M-tile (image row of the tile) per wave
+            const _Float16* w2 = reinterpret_cast<const _Float16*>(a.aux) + (long)blockIdx.y * 8 * 2 * 512;
+            floatx16 tm, tl;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { tm[r] = 0.f; tl[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const half8 ah = *reinterpret_cast<const half8*>(Hhi + (wave * 32 + li) * HX_HS + ks * 32 + kg * 16);
+                const half8 al = *reinterpret_cast<const half8*>(Hlo + (wave * 32 + li) * HX_HS + ks * 32 + kg * 16);
+                const half8 bh = *reinterpret_cast<const half8*>(w2 + (ks * 2 + 0) * 512 + lane * 8);
+                const half8 bl = *reinterpret_cast<const half8*>(w2 + (ks * 2 + 1) * 512 + lane * 8);
+                tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, tm, 0, 0, 0);
+                tl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, tl, 0, 0, 0);
+                tl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, tl, 0, 0, 0);
+            }
+            const int gy = ty0 + wave;
+            if (li < 9 && gy < a.h) {
+                float* T = a.out + ((long)blockIdx.y * 9 + li) * a.h * a.w + (long)gy * a.w;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gx = tx0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    if (gx < a.w) T[gx] = fmaf(tl[r], 1.0f / 2048.0f, tm[r]);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
         const int gy = ty0 + wm * WM + m;
@@ -227,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_kernel(const ConvArgsX a
                     const float g = hx_sigmoid(v);
                     if (co < half) a.out[pix * half + co] = g;
                     else a.out2[pix * half + (co - half)] = g * a.aux[pix * half + (co - half)];
-                } else {   // CER_EPI_GRU
+                } else if (EPI == CER_EPI_GRU) {
                     const float q = tanhf(v);
                     const float z = a.aux2[pix * a.cout + co], hprev = a.aux[pix * a.cout + co];
                     a.out[pix * a.cout + co] = (1.0f - z) * hprev + z * q;
@@ -286,17 +409,24 @@ extern "C" int cer_conv3x3_f16x3_pack(const float* w, void* packed_v, int Cout, 
     return CER_OK;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int NBUF, int MINW>
 static int hx_launch(const ConvArgsX& a, int epi, int nby, hipStream_t st) {
     constexpr int NB = WAVES_N * WN * 32;
-    const size_t smem = HX_A_BYTES + 2 * NB * 128;
+    const size_t smem = HX_A_BYTES + NBUF * NB * 128 + HX_D_BYTES;
     const int tiles_y = (a.h + HX_TH - 1) / HX_TH;
-    dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)nby);
+    dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)nby), block(64 * WAVES_M * WAVES_N);
     switch (epi) {
-        case CER_EPI_LINEAR: hipLaunchKernelGGL((conv3x3_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, CER_EPI_LINEAR>), grid, dim3(256), smem, st, a); break;
-        case CER_EPI_RELU: hipLaunchKernelGGL((conv3x3_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, CER_EPI_RELU>), grid, dim3(256), smem, st, a); break;
-        case CER_EPI_GATES: hipLaunchKernelGGL((conv3x3_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, CER_EPI_GATES>), grid, dim3(256), smem, st, a); break;
-        case CER_EPI_GRU: hipLaunchKernelGGL((conv3x3_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, CER_EPI_GRU>), grid, dim3(256), smem, st, a); break;
+        case CER_EPI_LINEAR: hipLaunchKernelGGL((conv3x3_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, CER_EPI_LINEAR>), grid, block, smem, st, a); break;
+        case CER_EPI_RELU: hipLaunchKernelGGL((conv3x3_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, CER_EPI_RELU>), grid, block, smem, st, a); break;
+        case CER_EPI_GATES: hipLaunchKernelGGL((conv3x3_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, CER_EPI_GATES>), grid, block, smem, st, a); break;
+        case CER_EPI_GRU: hipLaunchKernelGGL((conv3x3_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, CER_EPI_GRU>), grid, block, smem, st, a); break;
+        case HX_EPI_DELTA:
+            if constexpr (WAVES_N * WN * 32 == 128 && WM == 1) {
+                hipLaunchKernelGGL((conv3x3_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, HX_EPI_DELTA>), grid, block, smem, st, a);
+                break;
+            } else {
+                return CER_ESHAPE;
+            }
         default: return CER_EINVAL;
     }
     CER_RETURN_IF_LAUNCH_FAILED();
@@ -309,6 +439,7 @@ extern "C" int cer_conv3x3_f16x3(const cer_conv_inputs* in, const void* packed_w
     if (in->nsrc <= 0 || in->nsrc > CER_CONV_MAX_SRC) return CER_EINVAL;
     if (epi == CER_EPI_GATES && (!out2 || !aux)) return CER_EINVAL;
     if (epi == CER_EPI_GRU && (!aux || !aux2)) return CER_EINVAL;
+    if (epi == HX_EPI_DELTA && (!aux || Cout % 128 != 0)) return CER_EINVAL;
     if (Cout % 64 != 0) return CER_ESHAPE;
     ConvArgsX a;
     memset(&a, 0, sizeof(a));
@@ -336,6 +467,62 @@ extern "C" int cer_conv3x3_f16x3(const cer_conv_inputs* in, const void* packed_w
     a.cout = Cout;
     a.tiles_x = (w + HX_TW - 1) / HX_TW;
     hipStream_t st = (hipStream_t)stream;
-    if (Cout % 128 == 0) return hx_launch<2, 2, 2, 2>(a, epi, Cout / 128, st);
-    return hx_launch<4, 1, 1, 2>(a, epi, Cout / 64, st);
+    // 128 output channels per block: 8 waves (4 x 2) of 32 px x 64 ch, 3-slot weight ring, 2 blocks (16 waves) per CU;
+    //  64 output channels per block: 8 waves (4 x 2) of 32 px x 32 ch, 3-slot ring, 2 blocks (16 waves) per CU.
+    if (Cout % 128 == 0) return hx_launch<4, 2, 1, 2, 3, 4>(a, epi, Cout / 128, st);
+    return hx_launch<4, 2, 1, 1, 3, 4>(a, epi, Cout / 64, st);
+}
+
+// ---- delta head tail for the fused path ------------------------------------------------------------------
+// w2 OIHW [1, C, 3, 3] -> B fragments of the [C x 9 (padded to 32)] projection, per 128-channel half:
+// [half][k16-step 8][hi|lo][lane 64][8] halves; lane (tap = lane & 31, kg = lane >> 5) holds channels
+// half*128 + ks*16 + kg*8 + e.
+extern "C" long cer_delta_proj_packed_size(int C) { return C % 128 ? CER_ESHAPE : (long)(C / 128) * 8 * 2 * 512; }
+
+extern "C" int cer_delta_proj_pack(const float* w2, void* packed_v, int C) {
+    if (!w2 || !packed_v) return CER_EINVAL;
+    if (C % 128) return CER_ESHAPE;
+    _Float16* packed = (_Float16*)packed_v;
+    for (int hf = 0; hf < C / 128; ++hf)
+        for (int ks = 0; ks < 8; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int tap = lane & 31, c = hf * 128 + ks * 16 + (lane >> 5) * 8 + e;
+                    float v = tap < 9 ? w2[(long)c * 9 + tap] : 0.f;
+                    v = v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v);
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
+                    packed[(((long)hf * 8 + ks) * 2 + 0) * 512 + lane * 8 + e] = hi;
+                    packed[(((long)hf * 8 + ks) * 2 + 1) * 512 + lane * 8 + e] = lo;
+                }
+    return CER_OK;
+}
+
+// delta[p] = 0.01 * (bias + sum_half sum_tap T[half][tap][p + (ky-1, kx-1)]) (zero outside), disp_out = disp_in + delta
+__global__ __launch_bounds__(256) void delta_sum_kernel(const float* __restrict__ T, int nhalf, float bias, const float* __restrict__ disp_in,
+                                                        float* __restrict__ disp_out, float* __restrict__ delta, int h, int w) {
+    const long P = (long)h * w;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int y = (int)(p / w), x = (int)(p % w);
+    float s = 0.f;
+    for (int hf = 0; hf < nhalf; ++hf)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if (yy >= 0 && yy < h && xx >= 0 && xx < w) s += T[((long)hf * 9 + tap) * P + (long)yy * w + xx];
+        }
+    const float dl = 0.01f * (s + bias);
+    if (delta) delta[p] = dl;
+    disp_out[p] = disp_in[p] + dl;
+}
+
+extern "C" int cer_delta_sum_f32(const float* T, int nhalf, float bias, const float* disp_in, float* disp_out, float* delta, int h, int w,
+                                 void* stream) {
+    if (!T || !disp_in || !disp_out || nhalf <= 0 || h <= 0 || w <= 0) return CER_EINVAL;
+    const long P = (long)h * w;
+    hipLaunchKernelGGL(delta_sum_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, T, nhalf, bias, disp_in, disp_out,
+                       delta, h, w);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
 }

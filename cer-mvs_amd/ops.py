@@ -153,6 +153,11 @@ def conv3x3(pc, srcs, h, w, epi, out=None, out2=None, aux=None, aux2=None, init=
         ci.ch[i] = c
         ci.kind[i] = k
     oc = pc.cout // 2 if epi == L.EPI_GATES else pc.cout
+    if epi == L.EPI_DELTA:
+        if mode != "f16x3":
+            raise ValueError("EPI_DELTA is only built for the f16x3 kernel")
+        if out is None:
+            out = torch.empty(pc.cout // 128, 9, P, device=dev, dtype=torch.float32)
     if out is None:
         out = torch.empty(P, oc, device=dev, dtype=torch.float32)
     if epi == L.EPI_GATES and out2 is None:
@@ -164,10 +169,35 @@ def conv3x3(pc, srcs, h, w, epi, out=None, out2=None, aux=None, aux2=None, init=
         fn, wts = L.load().cer_conv3x3_f32, L.dev_ptr(pc.packed, "packed_w")
     else:
         raise ValueError(f"conv3x3: unknown mode {mode!r}")
+    aux_p = L.dev_ptr(aux, "aux", torch.float16) if epi == L.EPI_DELTA else L.dev_ptr(aux, "aux")
     L.check(fn(ctypes.byref(ci), wts, L.dev_ptr(bias, "bias"), L.dev_ptr(init, "init"),
-               L.dev_ptr(out, "out"), L.dev_ptr(out2, "out2"), L.dev_ptr(aux, "aux"), L.dev_ptr(aux2, "aux2"),
+               L.dev_ptr(out, "out"), L.dev_ptr(out2, "out2"), aux_p, L.dev_ptr(aux2, "aux2"),
                h, w, pc.cout, epi, L.cur_stream()), f"conv3x3[{mode}]")
     return (out, out2) if epi == L.EPI_GATES else out
+
+
+def delta_proj_pack(w2, device):
+    """w2 [1,C,3,3] (delta{s}.2.weight) -> packed projection fragments for EPI_DELTA."""
+    lib = L.load()
+    w = w2.detach().to("cpu", torch.float32).contiguous()
+    C = w.shape[1]
+    size = lib.cer_delta_proj_packed_size(C)
+    if size <= 0:
+        raise RuntimeError(f"delta projection pack: unsupported C={C}")
+    packed = torch.empty(size, dtype=torch.float16)
+    L.check(lib.cer_delta_proj_pack(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(packed.data_ptr()), C), "delta_proj_pack")
+    return packed.to(device)
+
+
+def delta_sum(T, bias, disp_in, h, w, disp_out=None, want_delta=True):
+    """T [nhalf,9,P] tap planes -> (disp_out [P], delta [P] or None)."""
+    nhalf, _, P = T.shape
+    if disp_out is None:
+        disp_out = torch.empty(P, device=T.device, dtype=torch.float32)
+    delta = torch.empty(P, device=T.device, dtype=torch.float32) if want_delta else None
+    L.check(L.load().cer_delta_sum_f32(L.dev_ptr(T, "T"), nhalf, float(bias), L.dev_ptr(disp_in, "disp_in"), L.dev_ptr(disp_out, "disp_out"),
+                                       L.dev_ptr(delta, "delta"), h, w, L.cur_stream()), "delta_sum")
+    return disp_out, delta
 
 
 def delta_tail(hid, w_tap_c, bias, disp_in, h, w, disp_out=None, want_delta=True):

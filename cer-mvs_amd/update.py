@@ -148,6 +148,7 @@ class UpdateBlock(nn.Module):
         p["q_inp"] = ops.PackedConv3x3(wq[:, s_inp], bq, [(di, 0)], device)
         p["d1"] = ops.PackedConv3x3(de[0].weight, de[0].bias, [(dn_, 0)], device)
         p["d2w"] = f32(de[2].weight[0].permute(1, 2, 0).reshape(9, -1))    # [tap, C]
+        p["d2proj"] = ops.delta_proj_pack(de[2].weight, device)
         p["d2b"] = float(de[2].bias.detach().float().cpu()[0])
         self._packed[key] = p
         return p
@@ -167,13 +168,18 @@ class UpdateBlock(nn.Module):
         ops.conv3x3(p["corr2"], [ws["c1"]], h, w, L.EPI_RELU, out=ws["c2"])
         ops.conv3x3(p["zr_rest"], [net_l, disp, ws["c2"]], h, w, L.EPI_GATES, out=ws["z"], out2=ws["rn"], aux=net_l, init=hzr)
         ops.conv3x3(p["q_rest"], [ws["rn"], disp, ws["c2"]], h, w, L.EPI_GRU, out=net_l, aux=net_l, aux2=ws["z"], init=hq)
-        ops.conv3x3(p["d1"], [net_l], h, w, L.EPI_RELU, mode=self.conv_mode, out=ws["hid"])
-        ops.delta_tail(ws["hid"], p["d2w"], p["d2b"], disp, h, w, disp_out=disp, want_delta=False)
+        if self.conv_mode == "f16x3":       # fused delta head: the 256-channel hidden map never reaches HBM
+            ops.conv3x3(p["d1"], [net_l], h, w, L.EPI_DELTA, mode="f16x3", out=ws["T"], aux=p["d2proj"])
+            ops.delta_sum(ws["T"], p["d2b"], disp, h, w, disp_out=disp, want_delta=False)
+        else:
+            ops.conv3x3(p["d1"], [net_l], h, w, L.EPI_RELU, mode=self.conv_mode, out=ws["hid"])
+            ops.delta_tail(ws["hid"], p["d2w"], p["d2b"], disp, h, w, disp_out=disp, want_delta=False)
 
     @staticmethod
     def workspace(P, device):
         e = lambda c: torch.empty(P, c, device=device, dtype=torch.float32)
-        return {"c1": e(64), "c2": e(64), "z": e(64), "rn": e(64), "hid": e(256)}
+        return {"c1": e(64), "c2": e(64), "z": e(64), "rn": e(64), "hid": e(256),
+                "T": torch.empty(2, 9, P, device=device, dtype=torch.float32)}
 
     # ------------------------------------------------------------------ literal API
     def disp_encoder(self, disp):
@@ -214,7 +220,11 @@ class UpdateBlock(nn.Module):
         c2 = ops.conv3x3(p["corr2"], [c1], ht, wd, L.EPI_RELU, mode=self.conv_mode)
         z, rn = ops.conv3x3(p["zr_full"], [net_l, inp_l, disp_l, c2], ht, wd, L.EPI_GATES, mode=self.conv_mode, aux=net_l)
         new = ops.conv3x3(p["q_full"], [rn, inp_l, disp_l, c2], ht, wd, L.EPI_GRU, mode=self.conv_mode, aux=net_l, aux2=z)
-        hid = ops.conv3x3(p["d1"], [new], ht, wd, L.EPI_RELU, mode=self.conv_mode)
-        _, delta = ops.delta_tail(hid, p["d2w"], p["d2b"], disp_l, ht, wd)
+        if self.conv_mode == "f16x3":
+            T = ops.conv3x3(p["d1"], [new], ht, wd, L.EPI_DELTA, mode="f16x3", aux=p["d2proj"])
+            _, delta = ops.delta_sum(T, p["d2b"], disp_l, ht, wd)
+        else:
+            hid = ops.conv3x3(p["d1"], [new], ht, wd, L.EPI_RELU, mode=self.conv_mode)
+            _, delta = ops.delta_tail(hid, p["d2w"], p["d2b"], disp_l, ht, wd)
         net_out = ops.nhwc_to_nchw(new).view(batch, num, ch, ht, wd)
         return net_out, delta.view(batch, num, ht, wd)

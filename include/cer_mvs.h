@@ -138,6 +138,7 @@ int cer_lookup_encode_f32(const float* vol, const float* origin, const float* di
 #define CER_EPI_RELU 1
 #define CER_EPI_GATES 2
 #define CER_EPI_GRU 3
+#define CER_EPI_DELTA 4   /* cer_conv3x3_f16x3 only - see cer_delta_proj_pack */
 
 typedef struct {
     const float* src[CER_CONV_MAX_SRC];
@@ -168,6 +169,19 @@ int cer_conv3x3_f16x3_pack(const float* w_oihw, void* packed, int Cout, int Cin,
 int cer_conv3x3_f16x3(const cer_conv_inputs* in, const void* packed_w, const float* bias, const float* init,
                       float* out, float* out2, const float* aux, const float* aux2,
                       int h, int w, int Cout, int epi, void* stream);
+
+/* Fused delta head (reference: core/update.py:68-71,114; core/raft.py:101).  cer_conv3x3_f16x3 with epi =
+ * CER_EPI_DELTA computes hid = relu(conv3x3(net)) (Cout = 256) but never writes it: each 128-channel block
+ * projects its hidden tile onto the nine taps of the following 256->1 conv,
+ *   T[half][tap][p] = sum_{c in half} w2[0, c, tap] * hid[p, c],           out = T [Cout/128, 9, h*w],
+ * with `aux` = the projection weights packed by cer_delta_proj_pack (2-byte halves, size from
+ * cer_delta_proj_packed_size).  cer_delta_sum_f32 finishes:
+ *   delta[p] = 0.01 * (bias + sum_half sum_tap T[half][tap][p + tap offset]) (zero padding),
+ *   disp_out[p] = disp_in[p] + delta[p]   (delta may be NULL; disp_out may alias disp_in). */
+long cer_delta_proj_packed_size(int C);
+int cer_delta_proj_pack(const float* w2_oihw, void* packed, int C);
+int cer_delta_sum_f32(const float* T, int nhalf, float bias, const float* disp_in, float* disp_out, float* delta,
+                      int h, int w, void* stream);
 
 /* delta head tail (reference: core/update.py:70-71,114 and core/raft.py:101):
  *   delta[p] = 0.01 * (b + sum_{tap,c} w[tap,c] * hid[p+tap, c]);  disp_out[p] = disp_in[p] + delta[p]
