@@ -25,6 +25,7 @@ def _make_norm(kind, planes):
 class ResidualBlock(nn.Module):
     def __init__(self, in_planes, planes, norm_fn="group", stride=1):
         super().__init__()
+        self.kind = norm_fn
         self.conv1 = nn.Conv2d(in_planes, planes, 3, padding=1, stride=stride)
         self.conv2 = nn.Conv2d(planes, planes, 3, padding=1)
         self.norm1 = _make_norm(norm_fn, planes)
@@ -35,11 +36,29 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, 1, stride=stride), self.norm3)
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and self.kind in ("instance", "none"):
+            return self._forward_fused(x)
         y = F.relu(self.norm1(self.conv1(x)))
         y = F.relu(self.norm2(self.conv2(y)))
         if self.downsample is not None:
             x = self.downsample(x)
         return F.relu(x + y)
+
+    def _forward_fused(self, x):
+        """Same arithmetic with the statistics / normalise / ReLU / add / ReLU passes fused into HIP kernels
+        (csrc/encoder_ops.hip): 7 tensor passes per block instead of 15.  Convolutions stay on MIOpen."""
+        from . import ops
+        inorm = self.kind == "instance"
+        y = self.conv1(x).contiguous()
+        y = ops.norm_act(y, ops.plane_stats(y) if inorm else None, relu_a=True, out=y)
+        y = self.conv2(y).contiguous()
+        ys = ops.plane_stats(y) if inorm else None
+        if self.downsample is not None:
+            r = self.downsample[0](x).contiguous()
+            rs = ops.plane_stats(r) if inorm else None
+        else:
+            r, rs = x.contiguous(), None
+        return ops.norm_act(y, ys, res=r, res_stats=rs, relu_a=True, relu_out=True, out=y)
 
 
 class BasicEncoder(nn.Module):
@@ -65,7 +84,12 @@ class BasicEncoder(nn.Module):
     def forward(self, x):
         lead = x.shape[:-3]
         x = x.reshape((-1,) + tuple(x.shape[-3:]))
-        x = F.relu(self.norm1(self.conv1(x)))
+        if x.is_cuda and x.dtype == torch.float32 and self.norm_fn in ("instance", "none"):
+            from . import ops
+            x = self.conv1(x).contiguous()
+            x = ops.norm_act(x, ops.plane_stats(x) if self.norm_fn == "instance" else None, relu_a=True, out=x)
+        else:
+            x = F.relu(self.norm1(self.conv1(x)))
         x = self.layer2(self.layer1(x))
         if self.type == "LR":
             x = self.layer3(x)

@@ -227,3 +227,22 @@ def nhwc_to_nchw(x, scale=1.0):
     out = torch.empty(C, P, device=x.device, dtype=torch.float32)
     L.check(L.load().cer_nhwc_to_nchw_f32(L.dev_ptr(x, "src"), L.dev_ptr(out, "dst"), C, P, float(scale), L.cur_stream()), "nhwc_to_nchw")
     return out
+
+
+def plane_stats(x, eps=1e-5):
+    """x [N,C,H,W] contiguous -> stats [N*C,2] = (mean, rstd) per (image, channel) plane."""
+    N, C, H, W = x.shape
+    stats = torch.empty(N * C, 2, device=x.device, dtype=torch.float32)
+    L.check(L.load().cer_plane_stats_f32(L.dev_ptr(x, "x"), L.dev_ptr(stats, "stats"), N * C, H * W, float(eps), L.cur_stream()), "plane_stats")
+    return stats
+
+
+def norm_act(x, x_stats=None, res=None, res_stats=None, relu_a=False, relu_b=False, relu_out=False, out=None):
+    """out = relu_out( relu_a(norm(x)) + relu_b(norm_r(res)) ) on NCHW tensors; ``out`` may be ``x``."""
+    N, C, H, W = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    flags = (1 if relu_a else 0) | (2 if relu_b else 0) | (4 if relu_out else 0)
+    L.check(L.load().cer_norm_act_f32(L.dev_ptr(x, "x"), L.dev_ptr(x_stats, "x_stats"), L.dev_ptr(res, "res"), L.dev_ptr(res_stats, "res_stats"),
+                                      L.dev_ptr(out, "out"), N * C, H * W, flags, L.cur_stream()), "norm_act")
+    return out

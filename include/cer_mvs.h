@@ -190,6 +190,16 @@ int cer_delta_sum_f32(const float* T, int nhalf, float bias, const float* disp_i
 int cer_delta_tail_f32(const float* hid, const float* w, float bias, const float* disp_in,
                        float* disp_out, float* delta, int h, int w_, int C, void* stream);
 
+/* Fused encoder passes (reference: core/extractor.py:49-57,143-150; InstanceNorm2d defaults :28-31).
+ * cer_plane_stats_f32: x [planes, plane_size] (one plane per (image, channel), NCHW) -> stats [planes, 2] =
+ *   (mean, 1/sqrt(biased_var + eps)), accumulated in fp64.
+ * cer_norm_act_f32: out = relu_out( relu_a(norm(x)) + relu_b(norm_r(res)) ) elementwise; x_stats / res / res_stats
+ *   may be NULL (no normalisation / no residual); flags: 1 relu_a, 2 relu_b, 4 relu_out; out may alias x.
+ * Planes whose size is not a multiple of 4 take a scalar path. */
+int cer_plane_stats_f32(const float* x, float* stats, long planes, long plane_size, float eps, void* stream);
+int cer_norm_act_f32(const float* x, const float* x_stats, const float* res, const float* res_stats, float* out,
+                     long planes, long plane_size, int flags, void* stream);
+
 /* NCHW [C,h,w] -> NHWC [h*w,C] with a scale (feature maps: scale = 1/8, core/corr.py:30-31)
  * and NHWC -> NCHW; C % 4 == 0. */
 int cer_nchw_to_nhwc_f32(const float* src, float* dst, int C, long P, float scale, void* stream);

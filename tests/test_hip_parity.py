@@ -262,6 +262,41 @@ def test_update_block_matches_reference_capture(dev, golden, stage, mode):
     assert rel_l1(delta.cpu(), torch.from_numpy(g[f"delta{stage}"])) < 1e-5
 
 
+# ------------------------------------------------------------------------------------ encoders
+@pytest.mark.parametrize("which", ["fnet", "cnet"])
+def test_encoder_fused_passes_match_oracle(dev, which):
+    """MIOpen convolutions + fused stats/normalise/ReLU/residual kernels vs the oracle's torch-CPU encoder."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+    from oracle import cer_oracle as O
+    images, _, _, _ = synthetic_scene(72, 104, 1, seed=8)
+    model = RAFT(test_mode=True)
+    sd = fill_state_dict(model.state_dict(), seed=13)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    x = images[0].float() * (2 / 255.0) - 1
+    with torch.no_grad():
+        got = getattr(model, which)(x.to(dev)).cpu()
+        ref = O.encoder(x, sd, which + ".", "instance" if which == "fnet" else "none")
+    assert got.shape == ref.shape
+    assert rel_l1(got, ref) < 1e-5
+
+
+def test_norm_act_kernels(dev):
+    from cer_mvs_amd import ops
+    x = hashed((3, 5, 12, 20), 131, -3, 5)
+    r = hashed((3, 5, 12, 20), 132, -2, 2)
+    xs, rs = ops.plane_stats(x.to(dev)), ops.plane_stats(r.to(dev))
+    mean, var = x.mean((2, 3)), x.var((2, 3), unbiased=False)
+    assert rel_l1(xs.cpu()[:, 0].view(3, 5), mean) < 1e-6
+    assert rel_l1(xs.cpu()[:, 1].view(3, 5), 1 / torch.sqrt(var + 1e-5)) < 1e-6
+    inorm = lambda t: F.instance_norm(t, eps=1e-5)
+    got = ops.norm_act(x.to(dev), xs, res=r.to(dev), res_stats=rs, relu_a=True, relu_out=True).cpu()
+    assert rel_l1(got, F.relu(F.relu(inorm(x)) + inorm(r))) < 1e-6
+    got = ops.norm_act(x.to(dev), None, res=r.to(dev), relu_a=True, relu_b=True).cpu()
+    assert rel_l1(got, F.relu(x) + F.relu(r)) < 1e-7
+
+
 # ------------------------------------------------------------------------------------ end to end
 def _run_e2e(dev, golden, name, literal=False, gru_precision="f16x3"):
     from cer_mvs_amd import RAFT
