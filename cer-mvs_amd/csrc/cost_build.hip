@@ -29,7 +29,11 @@ __global__ __launch_bounds__(256) void cost_build_kernel(const float* __restrict
                                                          int accumulate) {
     const int lane = threadIdx.x & 63;
     const long P = (long)h1 * w1;
-    const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // XCD-aware block order: workgroup b runs on XCD b % 8 (observed dispatch rule, speed only), so give each XCD a
+    // contiguous band of image rows - its private 4 MiB L2 then sees 1/8 of every source map instead of all of it.
+    const unsigned nblk = gridDim.x, q8 = nblk / 8, r8 = nblk % 8, xcd = blockIdx.x % 8, within = blockIdx.x / 8;
+    const unsigned bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    const long p = (long)bid * 4 + (threadIdx.x >> 6);
     if (p >= P) return;                                    // wave-uniform
     const int sub = lane & 15, cx = (lane >> 4) & 1, cy = lane >> 5;
     const float px = (float)(p % w1), py = (float)(p / w1);
