@@ -237,11 +237,27 @@ def main():
             peak, kname = F16_MFMA_PEAK_TFLOPS / 3, "conv3x3_f16x3_kernel<4,2,1,2,3,4,GATES> (z|r gates, 3x3, K=177, N=128; 3 f16 MFMAs per fp32 product)"
         else:
             peak, kname = FP32_MFMA_PEAK_TFLOPS, "conv3x3_kernel<2,2,4,4,GATES> (z|r gates, 3x3, K=177, N=128; exact fp32 MFMA)"
+        traffic = None                                            # HBM bytes per launch from the committed PMC passes
+        try:
+            with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f)["conv3x3_gates_zr"]["traffic_bytes"] if args.gru_precision == "f16x3" else None
+        except Exception:
+            traffic = None
         roofline = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                    "traffic": None, "avg_launch_us": 1e3 * t_zr / n_zr, "launches": n_zr, "flops_per_launch": flops_zr,
+                    "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2x FETCH correction)", "avg_launch_us": 1e3 * t_zr / n_zr, "launches": n_zr, "flops_per_launch": flops_zr,
                     "peak_note": ("fp32-equivalent ceiling = 2500 TF dense f16 MFMA / 3" if args.gru_precision == "f16x3"
                                   else "fp32 MFMA dense peak"),
                     "frac_of_raw_f16_peak": (3 * achieved / F16_MFMA_PEAK_TFLOPS) if args.gru_precision == "f16x3" else None}
+        hbm = None
+        if "lookup_encode" in rec:
+            n_lk, t_lk = rec["lookup_encode"]
+            D0 = cascade[0][0]
+            rowf = (D0 + D0 // 2 + D0 // 4 + 3) // 4 * 4
+            bytes_lk = 4.0 * P * (rowf + 2 + 64)                  # stage-0 row + origin + disp read, 64 floats written
+            gbs = bytes_lk / (t_lk / n_lk * 1e-3) / 1e9
+            hbm = {"kernel": "lookup_encode_kernel (multi-level lookup + view mean + 1x1 conv)", "bound": "hbm", "achieved": gbs,
+                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "avg_launch_us": 1e3 * t_lk / n_lk,
+                   "bytes_per_launch": bytes_lk, "note": "stage-0 row length used for all launches (stage-1 rows are 80 floats)"}
         result = {
             "metric": "depth-maps/sec (ref+N src views) at DTU 1600x1184; HBM GB/s vs roofline",
             "value": maps / elapsed, "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -253,7 +269,7 @@ def main():
             "config": {"workload": args.workload, "image": f"{W}x{H}", "src_views": V, "cascade": cascade,
                        "gru_iters": sum(c[2] for c in cascade),
                        "parallelism": "single" if world == 1 else (f"view-shard x{world} + all-reduce/stage" if shard else f"replica x{world}")},
-            "roofline": roofline, "kernels": kern,
+            "roofline": roofline, "roofline_hbm_kernel": hbm, "kernels": kern,
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(H, W, V, cascade, {k: v.cpu() for k, v in sd.items()})

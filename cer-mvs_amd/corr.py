@@ -31,12 +31,14 @@ class DirectCorr(torch.autograd.Function):
 
 def fmaps_to_nhwc(fmaps, border=0):
     """[N,C,h,w] -> [N,(h+2b)*(w+2b),C] * (1/8)  (core/corr.py:29-35: permute, /8.0, contiguous, float);
-    ``border`` zero texels on every side (the cost-build kernel wants 2 on the source maps)."""
+    ``border`` zero texels on every side (the cost-build kernel wants 2 on the source maps).  One HIP pass."""
+    from . import _lib as L
     N, C, h, w = fmaps.shape
-    x = fmaps.float() / 8.0
-    if border:
-        x = torch.nn.functional.pad(x, (border, border, border, border))
-    return x.permute(0, 2, 3, 1).reshape(N, (h + 2 * border) * (w + 2 * border), C).contiguous()
+    x = fmaps.float().contiguous()
+    out = torch.empty(N, (h + 2 * border) * (w + 2 * border), C, device=x.device, dtype=torch.float32)
+    L.check(L.load().cer_nchw_to_nhwc_border_f32(L.dev_ptr(x, "fmaps"), L.dev_ptr(out, "out"), N, C, h, w, border, 0.125, L.cur_stream()),
+            "nchw_to_nhwc_border")
+    return out
 
 
 class CorrBlock:

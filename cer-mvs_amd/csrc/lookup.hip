@@ -77,7 +77,10 @@ __global__ __launch_bounds__(256) void lookup_kernel(const float* __restrict__ v
     }
 }
 
-// fused: lookup on the folded volume + 1x1 conv (taps_total -> 64) + bias + ReLU, out [P,64] NHWC
+// fused: lookup on the folded volume + 1x1 conv (taps_total -> 64) + bias + ReLU, out [P,64] NHWC.
+// LDS holds only the 64 staged volume rows (the feature tile overlays them once the windows are read) and the
+// 1x1 weights come through the scalar cache (wave-uniform addresses), so 5 blocks = 20 waves fit a CU and keep
+// enough 16-B loads in flight for an HBM-bound kernel.
 __global__ __launch_bounds__(256) void lookup_encode_kernel(const float* __restrict__ vol, const float* __restrict__ origin,
                                                             const float* __restrict__ disp, const float* __restrict__ wgt,
                                                             const float* __restrict__ bias, float* __restrict__ out, long P, int D, int rs,
@@ -86,8 +89,7 @@ __global__ __launch_bounds__(256) void lookup_encode_kernel(const float* __restr
     const int rsp = rs + 4;
     const int taps = 2 * r + 1, K = L * taps;
     float* rows = lk_smem;                                   // [LK_PIX][rs + 4]
-    float* wsm = rows + LK_PIX * rsp;                        // [K][64]
-    float* feats = wsm + K * 64;                             // [LK_PIX][LK_MAX_TAPS + 1]
+    float* feats = lk_smem;                                  // [LK_PIX][K + 1], overlays `rows` after the second barrier
     const long p0 = (long)blockIdx.x * LK_PIX;
     const int npix = (int)min((long)LK_PIX, P - p0);
     const float* src = vol + p0 * rs;
@@ -96,27 +98,28 @@ __global__ __launch_bounds__(256) void lookup_encode_kernel(const float* __restr
         const int pr = t / n4, q = t - pr * n4;
         *reinterpret_cast<float4*>(&rows[pr * rsp + 4 * q]) = cer_ld4(src + (long)pr * rs + 4 * q);
     }
-    for (int t = threadIdx.x; t < K * 64; t += 256) wsm[t] = wgt[t];
     __syncthreads();
     const int pix = threadIdx.x & 63;
-    const int grp = threadIdx.x >> 6;           // wave id: also the output-channel group (16 channels each)
-    if (pix < npix) {
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id: lookup level, then output-channel group
+    float o[32];
+    const bool active = pix < npix;
+    if (active) {
         const long p = p0 + pix;
         const float c = lk_index(disp[p], origin[p], incre, D);
-        for (int lv = grp; lv < L; lv += 4) {
-            float o[32];
-            lk_window(&rows[pix * rsp], li.off[lv], li.len[lv], c / (float)(1 << lv), r, o);
-            for (int j = 0; j < taps; ++j) feats[pix * (LK_MAX_TAPS + 1) + lv * taps + j] = o[j];
-        }
+        for (int lv = grp; lv < L; lv += 4) lk_window(&rows[pix * rsp], li.off[lv], li.len[lv], c / (float)(1 << lv), r, o);
     }
+    __syncthreads();                                         // every window is in registers: the rows may be overwritten
+    if (active)
+        for (int lv = grp; lv < L; lv += 4)                  // (L <= 4: one level per wave, o[] holds it)
+            for (int j = 0; j < taps; ++j) feats[pix * (K + 1) + lv * taps + j] = o[j];
     __syncthreads();
-    if (pix >= npix) return;
+    if (!active) return;
     float acc[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = bias[grp * 16 + j];
     for (int k = 0; k < K; ++k) {
-        const float f = feats[pix * (LK_MAX_TAPS + 1) + k];
-        const float* wr = &wsm[k * 64 + grp * 16];       // wave-uniform address: LDS broadcast
+        const float f = feats[pix * (K + 1) + k];
+        const float* wr = wgt + k * 64 + grp * 16;           // wave-uniform: scalar loads
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = fmaf(f, wr[j], acc[j]);
     }
@@ -158,13 +161,13 @@ extern "C" int cer_corr_lookup_f32(const float* vol, const float* origin, const 
 extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, const float* disp, const float* w, const float* b, float* out,
                                      long P, int D, int row_stride, double incre, int num_levels, int radius, int Cout, void* stream) {
     if (!vol || !origin || !disp || !w || !b || !out || P <= 0 || D <= 0) return CER_EINVAL;
-    if (Cout != 64) return CER_ESHAPE;
+    if (Cout != 64 || num_levels > 4) return CER_ESHAPE;
     if (!cer_aligned16(vol) || !cer_aligned16(out)) return CER_EALIGN;
     LevelInfo li;
     int rc = level_info(D, row_stride, num_levels, radius, &li);
     if (rc) return rc;
     hipLaunchKernelGGL(lookup_encode_kernel, dim3((unsigned)((P + LK_PIX - 1) / LK_PIX)), dim3(256),
-                       sizeof(float) * (LK_PIX * (row_stride + 4) + num_levels * (2 * radius + 1) * 64 + LK_PIX * (LK_MAX_TAPS + 1)),
+                       sizeof(float) * LK_PIX * (row_stride + 4 > num_levels * (2 * radius + 1) + 1 ? row_stride + 4 : num_levels * (2 * radius + 1) + 1),
                        (hipStream_t)stream, vol, origin, disp, w,
                        b, out, P, D, row_stride, (float)incre, num_levels, radius, li);
     CER_RETURN_IF_LAUNCH_FAILED();

@@ -204,6 +204,9 @@ int cer_norm_act_f32(const float* x, const float* x_stats, const float* res, con
  * and NHWC -> NCHW; C % 4 == 0. */
 int cer_nchw_to_nhwc_f32(const float* src, float* dst, int C, long P, float scale, void* stream);
 int cer_nhwc_to_nchw_f32(const float* src, float* dst, int C, long P, float scale, void* stream);
+/* Batched NCHW [N,C,h,w] -> channels-last [N,(h+2b)*(w+2b),C] * scale with a b-texel zero border (the source-map
+ * layout of cer_cost_build_f32 with b = 2; reference: core/corr.py:29-35 permute, /8.0, contiguous). */
+int cer_nchw_to_nhwc_border_f32(const float* src, float* dst, int N, int C, int h, int w, int border, float scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -69,7 +69,8 @@ def main():
         vol = r(P, 112)
         w0t, b0 = r(33, 64), r(64)
         out = torch.empty(P, 64, device=dev)
-        run(lambda: ops.lookup_encode(vol, disp.clone(), disp + 0.0002 * torch.rand(P, device=dev), w0t, b0, 64, 0.0025 / 64, 3, 5, out=out))
+        org, dd = disp.clone(), disp + 0.0002 * torch.rand(P, device=dev)
+        run(lambda: ops.lookup_encode(vol, org, dd, w0t, b0, 64, 0.0025 / 64, 3, 5, out=out))
     elif args.what in ("build0", "build1"):
         V = 10
         f1 = r(P, 64) * 0.25
