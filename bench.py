@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--mode", default="shard", choices=["shard", "replica"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "amp"])
+    ap.add_argument("--encoder", default="hip", choices=["hip", "miopen"], help="encoder backend: channels-last HIP engine or PyTorch-ROCm (MIOpen)")
     ap.add_argument("--gru-precision", default="f16x3", choices=["f16x3", "fp32"],
                     help="arithmetic of the update block's 3x3 convs: split-f16 MFMA with fp32-equivalent accuracy, or exact fp32 MFMA")
     return ap.parse_args()
@@ -193,7 +194,7 @@ def main():
     H, W, V, cascade = WORKLOADS[args.workload]
     shard = world > 1 and args.mode == "shard"
     model = RAFT(cascade=cascade, test_mode=True, precision=args.precision, view_group=group if shard else None,
-                 gru_precision=args.gru_precision)
+                 gru_precision=args.gru_precision, encoder_backend=args.encoder)
     sd = fill_state_dict(model.state_dict(), seed=5)
     model.load_state_dict(sd)
     model = model.to(dev).eval()

@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CER_MVS_LIB") or os.path.join(_HERE, "csrc", "libcermvs.so")
-ABI_VERSION = 1005
+ABI_VERSION = 1006
 CONV_MAX_SRC = 4
 EPI_LINEAR, EPI_RELU, EPI_GATES, EPI_GRU, EPI_DELTA = 0, 1, 2, 3, 4
 
@@ -46,6 +46,14 @@ _SIGNATURES = {
     "cer_delta_proj_pack": (_I, [_P, _P, _I]),
     "cer_delta_sum_f32": (_I, [_P, _I, _F, _P, _P, _P, _I, _I, _P]),
     "cer_delta_tail_f32": (_I, [_P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
+    "cer_enc_stem_tiles": (_I, [_I, _I]),
+    "cer_enc_stem_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cer_enc_conv_packed_size": (_L, [_I, _I, _I]),
+    "cer_enc_conv_pack": (_I, [_P, _P, _I, _I, _I]),
+    "cer_enc_conv_tiles": (_I, [_I, _I, _I, _I, _I]),
+    "cer_enc_conv_f16x3": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "cer_enc_stats_reduce_f32": (_I, [_P, _P, _I, _I, _I, _L, _F, _P]),
+    "cer_enc_merge_f32": (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _P]),
     "cer_plane_stats_f32": (_I, [_P, _P, _L, _L, _F, _P]),
     "cer_norm_act_f32": (_I, [_P, _P, _P, _P, _P, _L, _L, _I, _P]),
     "cer_nchw_to_nhwc_f32": (_I, [_P, _P, _I, _L, _F, _P]),

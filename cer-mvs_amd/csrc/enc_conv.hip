@@ -1,0 +1,519 @@
+// Encoder convolutions (reference: core/extractor.py:60-155 BasicEncoder "HR") on the same
+// split-f16 MFMA engine as the update block (gru_f16x3.hip), generalised for the encoder's needs:
+//   * batched images (blockIdx.z), channels-last fp32 activations [N, h*w, C];
+//   * 3x3 / 1x1 kernels, stride 1 / 2, 32 or 64 output channels per block;
+//   * instance norm + ReLU of the PRODUCER applied on the fly while the halo tile is staged
+//     (x -> relu((x - mean[n,c]) * rstd[n,c])), so a normalised activation is never written to HBM;
+//   * the epilogue emits per-block partial sums (sum, sum of squares) per output channel for the NEXT
+//     instance norm (deterministic: partials + a tiny fp64 reduce kernel, no atomics);
+//   * final 1x1 convs write straight into the consumers' layouts: feature maps x 1/8 with the 2-texel zero
+//     border of the cost-build kernel; context map split into tanh (net) / relu (inp).
+// Also here: the 7x7 stride-2 stem as a direct fp32 kernel (K = 147 is too ragged for MFMA tiles and it is 6 %
+// of the encoder flops), the residual-merge kernel, and the statistics reduce.
+#include "common.hpp"
+#include <stdlib.h>
+#include <string.h>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define EC_AS 144                      // LDS bytes per halo pixel: 32 hi | 32 lo | 16 pad
+#define EC_EPI_RAW 0                   // out = conv + bias (raw, pre-norm), optional stats partials
+#define EC_EPI_FMAP 1                  // out = (conv + bias) * scale into a (possibly bordered) channels-last map
+#define EC_EPI_CTX 2                   // co < Cout/2: tanh -> out ; else relu -> out2   (core/raft.py:57-60)
+
+struct EncArgs {
+    const float* src;                  // [N, h*w, Cin] channels-last
+    const float* tf;                   // producer statistics [N*Cin][2] (mean, rstd) or NULL
+    int tf_relu;                       // ReLU after the transform (also without statistics)
+    const _Float16* wpk;
+    const float* bias;
+    float* out;
+    float* out2;
+    float* part;                       // stats partials [N][nblk][Cout][2] or NULL
+    int h, w, cin;                     // input geometry
+    int ho, wo, cout;                  // output geometry
+    int tiles_x, nblk;
+    int out_border;                    // EC_EPI_FMAP: zero border of the destination map
+    float out_scale;
+};
+
+__device__ __forceinline__ void ec_split(float v, _Float16& hi, _Float16& lo) {
+    const float x = fminf(fmaxf(v, -65504.0f), 65504.0f);
+    hi = (_Float16)x;
+    lo = (_Float16)((x - (float)hi) * 2048.0f);
+}
+
+template <int NB, int NWAVES>
+__device__ __forceinline__ void ec_issue_B(char* __restrict__ ldsB, const _Float16* __restrict__ slice) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int PIECES = NB / 8;
+#pragma unroll
+    for (int i = 0; i < (PIECES + NWAVES - 1) / NWAVES; ++i) {
+        const int piece = wave + NWAVES * i;
+        if (piece < PIECES)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slice + piece * 512 + lane * 8),
+                                             (__attribute__((address_space(3))) void*)(ldsB + piece * 1024), 16, 0, 0);
+    }
+}
+
+// TH x 32 output pixels per block; WAVES_M x WAVES_N waves each owning WM x WN MFMA tiles of 32 px x 32 ch
+template <int WAVES_M, int WAVES_N, int WM, int WN, int NBUF, int MINW, int TH, int STRIDE, int TAPS, int EPI>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void enc_conv_kernel(const EncArgs a) {
+    static_assert(WAVES_M * WM == TH, "tile config");
+    constexpr int NWAVES = WAVES_M * WAVES_N, NTHR = 64 * NWAVES;
+    constexpr int NB = WAVES_N * WN * 32;
+    constexpr int KS = (TAPS == 9) ? 3 : 1, PAD = (TAPS == 9) ? 1 : 0;
+    constexpr int HH = (TH - 1) * STRIDE + KS, HW = 31 * STRIDE + KS, ROWS = HH * HW;
+    constexpr int A_BYTES = ROWS * EC_AS;
+    constexpr int B_BYTES = NB * 128;
+    constexpr int PIECES = NB / 8;
+    constexpr int DMA_PER_WAVE = (PIECES + NWAVES - 1) / NWAVES;
+    extern __shared__ __attribute__((aligned(16))) char ec_smem[];
+    char* ldsA = ec_smem;
+    char* ldsB = ec_smem + A_BYTES;
+
+    const int img = blockIdx.z;
+    const int tile = blockIdx.x;
+    const int ty0 = (tile / a.tiles_x) * TH, tx0 = (tile % a.tiles_x) * 32;      // output coordinates
+    const int nb0 = blockIdx.y * NB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, kg = lane >> 5;
+    const int NT = a.cout / 32;
+    const int nchunks = a.cin / 32, nsteps = nchunks * TAPS;
+    const float* src = a.src + (long)img * a.h * a.w * a.cin;
+    const float* tf = a.tf ? a.tf + (long)img * a.cin * 2 : nullptr;
+
+    const _Float16* wbase = a.wpk + (long)(nb0 / 32) * 2048;
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i)
+        if (i < nsteps) ec_issue_B<NB, NWAVES>(ldsB + i * B_BYTES, wbase + (long)i * NT * 2048);
+
+    floatx16 accm[WM][WN], accl[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const float b = a.bias ? a.bias[nb0 + (wn * WN + n) * 32 + li] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                accm[m][n][r] = b;
+                accl[m][n][r] = 0.f;
+            }
+        }
+
+    int step = 0;
+    for (int c0 = 0; c0 < a.cin; c0 += 32) {
+        __syncthreads();
+        // ---- stage the halo of this 32-channel chunk: load all, then transform + split + write
+        {
+            constexpr int ITEMS = (ROWS * 4 + NTHR - 1) / NTHR;
+            float4 raw[ITEMS][2];
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const int idx = min((int)threadIdx.x + NTHR * i, ROWS * 4 - 1);
+                const int row = idx >> 2, g = idx & 3;
+                const int hy = row / HW, hx = row - hy * HW;
+                const int gy = min(max(ty0 * STRIDE + hy - PAD, 0), a.h - 1), gx = min(max(tx0 * STRIDE + hx - PAD, 0), a.w - 1);
+                const float* p = src + ((long)gy * a.w + gx) * a.cin + c0 + 8 * g;
+                raw[i][0] = cer_ld4(p);
+                raw[i][1] = cer_ld4(p + 4);
+            }
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const int idx = threadIdx.x + NTHR * i;
+                if (idx < ROWS * 4) {
+                    const int row = idx >> 2, g = idx & 3;
+                    const int hy = row / HW, hx = row - hy * HW;
+                    const int gy = ty0 * STRIDE + hy - PAD, gx = tx0 * STRIDE + hx - PAD;
+                    const bool inside = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+                    float v[8] = {raw[i][0].x, raw[i][0].y, raw[i][0].z, raw[i][0].w, raw[i][1].x, raw[i][1].y, raw[i][1].z, raw[i][1].w};
+                    half8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float x = v[e];
+                        if (tf) {
+                            const int c = c0 + 8 * g + e;
+                            x = (x - tf[2 * c]) * tf[2 * c + 1];
+                        }
+                        if (a.tf_relu) x = fmaxf(x, 0.f);
+                        if (!inside) x = 0.f;             // zero padding of the (normalised) activation
+                        _Float16 h_, l_;
+                        ec_split(x, h_, l_);
+                        hi[e] = h_;
+                        lo[e] = l_;
+                    }
+                    *reinterpret_cast<half8*>(ldsA + row * EC_AS + g * 16) = hi;
+                    *reinterpret_cast<half8*>(ldsA + row * EC_AS + 64 + g * 16) = lo;
+                }
+            }
+        }
+#pragma unroll 1
+        for (int tap = 0; tap < TAPS; ++tap, ++step) {
+            const int younger = min(NBUF - 2, nsteps - 1 - step);
+            if (NBUF >= 3 && younger >= 1) __builtin_amdgcn_s_waitcnt(0x0F70 | DMA_PER_WAVE);
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+            if (step + NBUF - 1 < nsteps)
+                ec_issue_B<NB, NWAVES>(ldsB + ((step + NBUF - 1) % NBUF) * B_BYTES, wbase + (long)(step + NBUF - 1) * NT * 2048);
+            const char* B = ldsB + (step % NBUF) * B_BYTES;
+            const int dy = tap / KS, dx = tap - dy * KS;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                half8 ah[WM], al[WM], bh[WN], bl[WN];
+#pragma unroll
+                for (int m = 0; m < WM; ++m) {
+                    const int row = ((wm * WM + m) * STRIDE + dy) * HW + li * STRIDE + dx;
+                    const char* p = ldsA + row * EC_AS + ks * 32 + kg * 16;
+                    ah[m] = *reinterpret_cast<const half8*>(p);
+                    al[m] = *reinterpret_cast<const half8*>(p + 64);
+                }
+#pragma unroll
+                for (int n = 0; n < WN; ++n) {
+                    const char* p = B + (((wn * WN + n) * 2 + ks) * 2) * 1024 + lane * 16;
+                    bh[n] = *reinterpret_cast<const half8*>(p);
+                    bl[n] = *reinterpret_cast<const half8*>(p + 1024);
+                }
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int n = 0; n < WN; ++n) {
+                        accm[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], accm[m][n], 0, 0, 0);
+                        accl[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], accl[m][n], 0, 0, 0);
+                        accl[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], accl[m][n], 0, 0, 0);
+                    }
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds channel co, pixels x = tx0 + (r&3) + 8*(r>>2) + 4*kg of output row gy
+    float ssum[WN], ssq[WN];
+#pragma unroll
+    for (int n = 0; n < WN; ++n) { ssum[n] = 0.f; ssq[n] = 0.f; }
+    const int wob = a.wo + 2 * a.out_border;
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+        const int gy = ty0 + wm * WM + m;
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const int co = nb0 + (wn * WN + n) * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gx = tx0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                if (gy >= a.ho || gx >= a.wo) continue;
+                const float v = fmaf(accl[m][n][r], 1.0f / 2048.0f, accm[m][n][r]);
+                if (EPI == EC_EPI_RAW) {
+                    a.out[(((long)img * a.ho + gy) * a.wo + gx) * a.cout + co] = v;
+                    ssum[n] += v;
+                    ssq[n] = fmaf(v, v, ssq[n]);
+                } else if (EPI == EC_EPI_FMAP) {
+                    a.out[(((long)img * (a.ho + 2 * a.out_border) + gy + a.out_border) * wob + gx + a.out_border) * a.cout + co] = v * a.out_scale;
+                } else {
+                    const int half = a.cout / 2;
+                    const long pix = ((long)img * a.ho + gy) * a.wo + gx;
+                    if (co < half) a.out[pix * half + co] = tanhf(v);
+                    else a.out2[pix * half + co - half] = fmaxf(v, 0.f);
+                }
+            }
+        }
+    }
+    if (EPI == EC_EPI_RAW && a.part) {
+        // per-block partial statistics for the next instance norm: combine lane halves, then the WAVES_M waves through LDS
+        __syncthreads();                                   // A/B LDS no longer needed
+        float* red = reinterpret_cast<float*>(ec_smem);    // [WAVES_M][NB][2]
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const float s = ssum[n] + __shfl_xor(ssum[n], 32), q = ssq[n] + __shfl_xor(ssq[n], 32);
+            if (kg == 0) {
+                red[(wm * NB + (wn * WN + n) * 32 + li) * 2 + 0] = s;
+                red[(wm * NB + (wn * WN + n) * 32 + li) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < NB) {
+            float s = 0.f, q = 0.f;
+            for (int i = 0; i < WAVES_M; ++i) {
+                s += red[(i * NB + threadIdx.x) * 2 + 0];
+                q += red[(i * NB + threadIdx.x) * 2 + 1];
+            }
+            float* dst = a.part + (((long)img * a.nblk + tile) * a.cout + nb0 + threadIdx.x) * 2;
+            dst[0] = s;
+            dst[1] = q;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// generic weight packing: OIHW [Cout, Cin, k, k] (k = 1 or 3) -> [chunk32][tap][ntile32][k16-step][hi|lo][lane][8]
+extern "C" long cer_enc_conv_packed_size(int Cout, int Cin, int taps) {
+    if (Cout <= 0 || Cin <= 0 || Cout % 32 || Cin % 32 || (taps != 1 && taps != 9)) return CER_ESHAPE;
+    return (long)(Cin / 32) * taps * (Cout / 32) * 2048;
+}
+
+extern "C" int cer_enc_conv_pack(const float* w, void* packed_v, int Cout, int Cin, int taps) {
+    if (!w || !packed_v) return CER_EINVAL;
+    if (Cout % 32 || Cin % 32 || (taps != 1 && taps != 9)) return CER_ESHAPE;
+    _Float16* packed = (_Float16*)packed_v;
+    const int NT = Cout / 32;
+    for (int kc = 0; kc < Cin / 32; ++kc)
+        for (int tap = 0; tap < taps; ++tap)
+            for (int nt = 0; nt < NT; ++nt)
+                for (int ks = 0; ks < 2; ++ks)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = nt * 32 + (lane & 31);
+                            const int ci = kc * 32 + ks * 16 + (lane >> 5) * 8 + e;
+                            float v = w[((long)co * Cin + ci) * taps + tap];
+                            v = v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v);
+                            const _Float16 hi = (_Float16)v;
+                            const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
+                            const long base = ((((long)kc * taps + tap) * NT + nt) * 2 + ks) * 2;
+                            packed[(base + 0) * 512 + lane * 8 + e] = hi;
+                            packed[(base + 1) * 512 + lane * 8 + e] = lo;
+                        }
+    return CER_OK;
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, int NBUF, int MINW, int TH, int STRIDE, int TAPS>
+static int ec_launch(EncArgs a, int nimg, int epi, hipStream_t st) {
+    constexpr int NB = WAVES_N * WN * 32;
+    constexpr int KS = (TAPS == 9) ? 3 : 1;
+    constexpr int HH = (TH - 1) * STRIDE + KS, HW = 31 * STRIDE + KS;
+    size_t smem = (size_t)HH * HW * EC_AS + NBUF * NB * 128;
+    const size_t red = (size_t)WAVES_M * NB * 2 * sizeof(float);
+    if (smem < red) smem = red;
+    a.tiles_x = (a.wo + 31) / 32;
+    const int tiles_y = (a.ho + TH - 1) / TH;
+    a.nblk = a.tiles_x * tiles_y;
+    dim3 grid((unsigned)a.nblk, (unsigned)(a.cout / NB), (unsigned)nimg), block(64 * WAVES_M * WAVES_N);
+    switch (epi) {
+        case EC_EPI_RAW: hipLaunchKernelGGL((enc_conv_kernel<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, TH, STRIDE, TAPS, EC_EPI_RAW>), grid, block, smem, st, a); break;
+        case EC_EPI_FMAP: hipLaunchKernelGGL((enc_conv_kernel<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, TH, STRIDE, TAPS, EC_EPI_FMAP>), grid, block, smem, st, a); break;
+        case EC_EPI_CTX: hipLaunchKernelGGL((enc_conv_kernel<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, TH, STRIDE, TAPS, EC_EPI_CTX>), grid, block, smem, st, a); break;
+        default: return CER_EINVAL;
+    }
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}
+
+// Number of blocks (tiles) per image the kernel will use for an output of ho x wo - the size of the partials buffer.
+extern "C" int cer_enc_conv_tiles(int ho, int wo, int stride, int taps, int Cout) {
+    const int th = (stride == 2) ? 2 : 8;
+    (void)taps; (void)Cout;
+    return ((wo + 31) / 32) * ((ho + th - 1) / th);
+}
+
+extern "C" int cer_enc_conv_f16x3(const float* src, const float* tf_stats, int tf_relu, const void* packed_w, const float* bias, float* out,
+                                  float* out2, float* stats_partial, int N, int h, int w, int Cin, int Cout, int taps, int stride, int epi,
+                                  int out_border, float out_scale, void* stream) {
+    if (!src || !packed_w || !out || N <= 0 || h <= 0 || w <= 0) return CER_EINVAL;
+    if (Cin % 32 || Cout % 32 || (taps != 1 && taps != 9) || (stride != 1 && stride != 2)) return CER_ESHAPE;
+    if (epi == EC_EPI_CTX && !out2) return CER_EINVAL;
+    if (!cer_aligned16(src) || !cer_aligned16(packed_w)) return CER_EALIGN;
+    EncArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src = src;
+    a.tf = tf_stats;
+    a.tf_relu = tf_relu;
+    a.wpk = (const _Float16*)packed_w;
+    a.bias = bias;
+    a.out = out;
+    a.out2 = out2;
+    a.part = stats_partial;
+    a.h = h;
+    a.w = w;
+    a.cin = Cin;
+    a.cout = Cout;
+    const int pad = taps == 9 ? 1 : 0, ks = taps == 9 ? 3 : 1;
+    a.ho = (h + 2 * pad - ks) / stride + 1;
+    a.wo = (w + 2 * pad - ks) / stride + 1;
+    a.out_border = out_border;
+    a.out_scale = out_scale;
+    hipStream_t st = (hipStream_t)stream;
+    if (stride == 1 && taps == 9) {
+        if (Cout % 64 == 0) return ec_launch<8, 1, 1, 2, 3, 4, 8, 1, 9>(a, N, epi, st);       // 8 x 32 px x 64 ch per block
+        return ec_launch<8, 1, 1, 1, 3, 4, 8, 1, 9>(a, N, epi, st);                            // 8 x 32 px x 32 ch
+    }
+    if (stride == 1 && taps == 1) {
+        if (Cout % 64 == 0) return ec_launch<8, 1, 1, 2, 2, 4, 8, 1, 1>(a, N, epi, st);
+        return ec_launch<8, 1, 1, 1, 2, 4, 8, 1, 1>(a, N, epi, st);
+    }
+    if (Cout % 64) return CER_ESHAPE;
+    if (taps == 9) return ec_launch<2, 2, 1, 1, 3, 2, 2, 2, 9>(a, N, epi, st);                  // stride 2: 2 x 32 px x 64 ch
+    return ec_launch<2, 2, 1, 1, 2, 2, 2, 2, 1>(a, N, epi, st);
+}
+
+// ---- statistics reduce: partials [N][nblk][C][2] -> stats [N*C][2] = (mean, rstd), fp64 accumulation ----------
+__global__ __launch_bounds__(256) void enc_stats_reduce_kernel(const float* __restrict__ part, float* __restrict__ stats, int nblk, int C,
+                                                               double count, float eps) {
+    const int n = blockIdx.x / C, c = blockIdx.x % C;
+    double s = 0.0, q = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        const float* p = part + (((long)n * nblk + b) * C + c) * 2;
+        s += p[0];
+        q += p[1];
+    }
+    __shared__ double sh[2][4];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s += __shfl_xor(s, o);
+        q += __shfl_xor(q, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sh[0][threadIdx.x >> 6] = s;
+        sh[1][threadIdx.x >> 6] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double S = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3], Q = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        const double mean = S / count;
+        double var = Q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[2 * blockIdx.x] = (float)mean;
+        stats[2 * blockIdx.x + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+extern "C" int cer_enc_stats_reduce_f32(const float* partial, float* stats, int N, int nblk, int C, long pixels, float eps, void* stream) {
+    if (!partial || !stats || N <= 0 || nblk <= 0 || C <= 0 || pixels <= 0) return CER_EINVAL;
+    hipLaunchKernelGGL(enc_stats_reduce_kernel, dim3((unsigned)(N * C)), dim3(256), 0, (hipStream_t)stream, partial, stats, nblk, C,
+                       (double)pixels, eps);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}
+
+// ---- residual merge, channels-last: out = relu( fa(a) + fb(b) ), f = optional instance norm (+ ReLU) ------------
+// flags: 1 relu on a, 2 relu on b, 4 relu on the sum
+__global__ __launch_bounds__(256) void enc_merge_kernel(const float* __restrict__ xa, const float* __restrict__ sa, const float* __restrict__ xb,
+                                                        const float* __restrict__ sb, float* __restrict__ out, long per_image, int C, int flags,
+                                                        long total4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const long e = i * 4;
+        const int n = (int)(e / per_image), c = (int)(e % C);
+        const float4 va = cer_ld4(xa + e);
+        float a4[4] = {va.x, va.y, va.z, va.w}, b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (xb) {
+            const float4 vb = cer_ld4(xb + e);
+            b4[0] = vb.x; b4[1] = vb.y; b4[2] = vb.z; b4[3] = vb.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float t = a4[k];
+            if (sa) t = (t - sa[2 * (n * C + c + k)]) * sa[2 * (n * C + c + k) + 1];
+            if (flags & 1) t = fmaxf(t, 0.f);
+            if (xb) {
+                float u = b4[k];
+                if (sb) u = (u - sb[2 * (n * C + c + k)]) * sb[2 * (n * C + c + k) + 1];
+                if (flags & 2) u = fmaxf(u, 0.f);
+                t += u;
+            }
+            if (flags & 4) t = fmaxf(t, 0.f);
+            a4[k] = t;
+        }
+        *reinterpret_cast<float4*>(out + e) = make_float4(a4[0], a4[1], a4[2], a4[3]);
+    }
+}
+
+extern "C" int cer_enc_merge_f32(const float* a, const float* a_stats, const float* b, const float* b_stats, float* out, int N, long pixels,
+                                 int C, int flags, void* stream) {
+    if (!a || !out || N <= 0 || pixels <= 0 || C <= 0) return CER_EINVAL;
+    if (C % 4) return CER_ESHAPE;
+    if (!cer_aligned16(a) || !cer_aligned16(out) || (b && !cer_aligned16(b))) return CER_EALIGN;
+    const long total4 = (long)N * pixels * C / 4;
+    long blocks = (total4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(enc_merge_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, a_stats, b, b_stats, out, pixels * C, C,
+                       flags, total4);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}
+
+// ---- stem: 7x7 stride-2 pad-3 convolution 3 -> 32 on the raw image (core/extractor.py:81,145; core/raft.py:40-41) ----
+// NCHW image in 0..255 -> x*(2/255) - 1 on the fly -> channels-last raw output [N, ho*wo, 32] + stats partials.
+// Direct fp32: one thread = one output pixel x 32 channels; weights [147][32] broadcast from LDS.
+#define ST_PIX 256
+__global__ __launch_bounds__(ST_PIX) void enc_stem_kernel(const float* __restrict__ img, const float* __restrict__ wgt, const float* __restrict__ bias,
+                                                          float* __restrict__ out, float* __restrict__ part, int H, int W, int ho, int wo,
+                                                          int nblk, int normalize) {
+    __shared__ __attribute__((aligned(16))) float wsm[147 * 32];
+    __shared__ float red[4][32][2];
+    for (int t = threadIdx.x; t < 147 * 32; t += ST_PIX) wsm[t] = wgt[t];
+    __syncthreads();
+    const int n = blockIdx.y;
+    const long p = (long)blockIdx.x * ST_PIX + threadIdx.x;
+    const long Po = (long)ho * wo;
+    const bool valid = p < Po;
+    const int oy = valid ? (int)(p / wo) : 0, ox = valid ? (int)(p % wo) : 0;
+    float acc[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc[c] = bias[c];
+    const float* im = img + (long)n * 3 * H * W;
+    for (int ci = 0; ci < 3; ++ci)
+        for (int ky = 0; ky < 7; ++ky) {
+            const int iy = oy * 2 + ky - 3;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const int ix = ox * 2 + kx - 3;
+                float x = 0.f;
+                if (ix >= 0 && ix < W) {
+                    x = im[((long)ci * H + iy) * W + ix];
+                    if (normalize) x = x * (2.0f / 255.0f) - 1.0f;
+                }
+                const float4* wr = reinterpret_cast<const float4*>(&wsm[((ci * 7 + ky) * 7 + kx) * 32]);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 w4 = wr[q];
+                    acc[4 * q + 0] = fmaf(x, w4.x, acc[4 * q + 0]);
+                    acc[4 * q + 1] = fmaf(x, w4.y, acc[4 * q + 1]);
+                    acc[4 * q + 2] = fmaf(x, w4.z, acc[4 * q + 2]);
+                    acc[4 * q + 3] = fmaf(x, w4.w, acc[4 * q + 3]);
+                }
+            }
+        }
+    if (valid) {
+        float* o = out + ((long)n * Po + p) * 32;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(o + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
+    if (part) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            float s = valid ? acc[c] : 0.f, q = valid ? acc[c] * acc[c] : 0.f;
+#pragma unroll
+            for (int o2 = 32; o2 >= 1; o2 >>= 1) {
+                s += __shfl_xor(s, o2);
+                q += __shfl_xor(q, o2);
+            }
+            if (lane == 0) {
+                red[wave][c][0] = s;
+                red[wave][c][1] = q;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const int c = threadIdx.x;
+            float* dst = part + (((long)n * nblk + blockIdx.x) * 32 + c) * 2;
+            dst[0] = red[0][c][0] + red[1][c][0] + red[2][c][0] + red[3][c][0];
+            dst[1] = red[0][c][1] + red[1][c][1] + red[2][c][1] + red[3][c][1];
+        }
+    }
+}
+
+extern "C" int cer_enc_stem_tiles(int ho, int wo) { return (int)(((long)ho * wo + ST_PIX - 1) / ST_PIX); }
+
+// wgt: [3*7*7][32] (ci, ky, kx major; output channel minor), device pointer
+extern "C" int cer_enc_stem_f32(const float* images, const float* wgt_k_co, const float* bias, float* out, float* stats_partial, int N, int H,
+                                int W, int normalize, void* stream) {
+    if (!images || !wgt_k_co || !bias || !out || N <= 0 || H <= 0 || W <= 0) return CER_EINVAL;
+    if (N > 65535) return CER_ESHAPE;
+    const int ho = (H + 6 - 7) / 2 + 1, wo = (W + 6 - 7) / 2 + 1;
+    const int nblk = cer_enc_stem_tiles(ho, wo);
+    hipLaunchKernelGGL(enc_stem_kernel, dim3((unsigned)nblk, (unsigned)N), dim3(ST_PIX), 0, (hipStream_t)stream, images, wgt_k_co, bias, out,
+                       stats_partial, H, W, ho, wo, nblk, normalize);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}

@@ -1,0 +1,135 @@
+"""BasicEncoder forward on the HIP encoder engine (csrc/enc_conv.hip) - reference: core/extractor.py:143-155 (type "HR").
+
+Same arithmetic as ``BasicEncoder.forward`` (conv7x7s2 -> norm -> relu -> 2 residual blocks @32 -> 2 residual blocks @64
+(first stride 2 with a 1x1 downsample) -> conv1x1), re-scheduled so that no normalised / activated tensor is ever written:
+each convolution stores its RAW output plus per-block statistics partials, and the consumer applies
+``relu((x - mean) * rstd)`` while it stages its input tile.  Activations are channels-last fp32; convolutions run on
+the split-f16 MFMA path (fp32-equivalent).  Only "instance" and "none" norms (the two the reference uses) are built."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+class _Conv:
+    def __init__(self, conv, device):
+        lib = L.load()
+        w = conv.weight.detach().to("cpu", torch.float32).contiguous()
+        self.cout, self.cin, k, _ = w.shape
+        self.taps = k * k
+        self.stride = conv.stride[0]
+        size = lib.cer_enc_conv_packed_size(self.cout, self.cin, self.taps)
+        if size <= 0:
+            raise RuntimeError(f"encoder conv pack: unsupported {tuple(w.shape)}")
+        packed = torch.empty(size, dtype=torch.float16)
+        L.check(lib.cer_enc_conv_pack(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(packed.data_ptr()), self.cout, self.cin, self.taps),
+                "enc_conv_pack")
+        self.packed = packed.to(device)
+        self.bias = conv.bias.detach().to(device, torch.float32).contiguous()
+
+
+class HipEncoder:
+    """Runs one BasicEncoder ("HR", norm "instance" or "none") on the engine.  Weights are packed at construction."""
+
+    def __init__(self, enc, device):
+        if enc.type != "HR" or enc.norm_fn not in ("instance", "none"):
+            raise NotImplementedError("HipEncoder: only type 'HR' with norm 'instance' or 'none'")
+        self.inorm = enc.norm_fn == "instance"
+        self.device = device
+        w = enc.conv1.weight.detach().to("cpu", torch.float32)
+        self.stem_w = w.permute(1, 2, 3, 0).reshape(147, 32).contiguous().to(device)
+        self.stem_b = enc.conv1.bias.detach().to(device, torch.float32).contiguous()
+        self.blocks = []
+        for layer in (enc.layer1, enc.layer2):
+            for blk in layer:
+                down = _Conv(blk.downsample[0], device) if blk.downsample is not None else None
+                self.blocks.append((_Conv(blk.conv1, device), _Conv(blk.conv2, device), down))
+        self.head = _Conv(enc.conv2, device)
+
+    # ---- kernel faces
+    def _stats(self, part, N, nblk, C, pixels):
+        st = torch.empty(N * C, 2, device=self.device, dtype=torch.float32)
+        L.check(L.load().cer_enc_stats_reduce_f32(L.dev_ptr(part, "part"), L.dev_ptr(st, "stats"), N, nblk, C, pixels, 1e-5, L.cur_stream()),
+                "enc_stats_reduce")
+        return st
+
+    def _conv(self, c, x, N, h, w, tf, relu, epi=0, out=None, out2=None, border=0, scale=1.0, want_stats=True):
+        lib = L.load()
+        pad, ks = (1, 3) if c.taps == 9 else (0, 1)
+        ho, wo = (h + 2 * pad - ks) // c.stride + 1, (w + 2 * pad - ks) // c.stride + 1
+        part = None
+        if epi == 0:
+            out = torch.empty(N, ho * wo, c.cout, device=self.device, dtype=torch.float32)
+            if self.inorm and want_stats:
+                nblk = lib.cer_enc_conv_tiles(ho, wo, c.stride, c.taps, c.cout)
+                part = torch.empty(N, nblk, c.cout, 2, device=self.device, dtype=torch.float32)
+        L.check(lib.cer_enc_conv_f16x3(L.dev_ptr(x, "src"), L.dev_ptr(tf, "tf"), int(relu), L.dev_ptr(c.packed, "w", torch.float16),
+                                       L.dev_ptr(c.bias, "bias"), L.dev_ptr(out, "out"), L.dev_ptr(out2, "out2"), L.dev_ptr(part, "part"),
+                                       N, h, w, c.cin, c.cout, c.taps, c.stride, epi, border, float(scale), L.cur_stream()), "enc_conv")
+        st = self._stats(part, N, part.shape[1], c.cout, ho * wo) if part is not None else None
+        return out, st, ho, wo
+
+    def _merge(self, a, sa, b, sb, N, pixels, C, flags):
+        out = torch.empty(N, pixels, C, device=self.device, dtype=torch.float32)
+        L.check(L.load().cer_enc_merge_f32(L.dev_ptr(a, "a"), L.dev_ptr(sa, "sa"), L.dev_ptr(b, "b"), L.dev_ptr(sb, "sb"), L.dev_ptr(out, "out"),
+                                           N, pixels, C, flags, L.cur_stream()), "enc_merge")
+        return out
+
+    # ---- trunk: images -> last residual activation (channels-last) + geometry
+    def trunk(self, x):
+        """x [N,3,H,W] float32 (already normalised to [-1,1]) -> (a [N, h*w, 64], h, w)."""
+        lib = L.load()
+        N, _, H, W = x.shape
+        x = x.contiguous()
+        ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        raw0 = torch.empty(N, ho * wo, 32, device=self.device, dtype=torch.float32)
+        part = None
+        if self.inorm:
+            part = torch.empty(N, lib.cer_enc_stem_tiles(ho, wo), 32, 2, device=self.device, dtype=torch.float32)
+        L.check(lib.cer_enc_stem_f32(L.dev_ptr(x, "images"), L.dev_ptr(self.stem_w, "w"), L.dev_ptr(self.stem_b, "b"), L.dev_ptr(raw0, "out"),
+                                     L.dev_ptr(part, "part"), N, H, W, 0, L.cur_stream()), "enc_stem")
+        st0 = self._stats(part, N, part.shape[1], 32, ho * wo) if part is not None else None
+        # `cur` = (tensor, stats, relu): the block input is relu(norm(tensor)) when stats/relu are set, else the tensor itself
+        cur, cur_st, cur_relu, h, w, C = raw0, st0, True, ho, wo, 32
+        for c1, c2, down in self.blocks:
+            r1, s1, h1, w1 = self._conv(c1, cur, N, h, w, cur_st, cur_relu)
+            r2, s2, _, _ = self._conv(c2, r1, N, h1, w1, s1, True)
+            if down is not None:
+                rd, sd, _, _ = self._conv(down, cur, N, h, w, cur_st, cur_relu)
+                nxt = self._merge(r2, s2, rd, sd, N, h1 * w1, c2.cout, 1 | 4)                      # relu(norm3(down) + relu(norm(r2)))
+            else:
+                nxt = self._merge(r2, s2, cur, cur_st, N, h1 * w1, c2.cout, 1 | (2 if cur_relu else 0) | 4)
+            cur, cur_st, cur_relu, h, w, C = nxt, None, False, h1, w1, c2.cout
+        return cur, h, w
+
+    def features(self, x, n_ref=1, border=2, scale=0.125, src_out=None):
+        """fnet head: (ref [n_ref*h*w... ] plain, src bordered).  x [N,3,H,W]; the first ``n_ref`` images go to a plain
+        [n_ref, h*w, C] map, the rest to a [N-n_ref, (h+2b)*(w+2b), C] map with a zero border; both scaled."""
+        a, h, w = self.trunk(x)
+        N, C = x.shape[0], self.head.cout
+        ref = torch.empty(n_ref, h * w, C, device=self.device, dtype=torch.float32)
+        self._conv(self.head, a[:n_ref], n_ref, h, w, None, False, epi=1, out=ref, border=0, scale=scale)
+        src = None
+        if N > n_ref:
+            src = src_out if src_out is not None else torch.zeros(N - n_ref, (h + 2 * border) * (w + 2 * border), C, device=self.device,
+                                                                  dtype=torch.float32)
+            self._conv(self.head, a[n_ref:], N - n_ref, h, w, None, False, epi=1, out=src, border=border, scale=scale)
+        return ref, src, h, w
+
+    def context(self, x):
+        """cnet head: x [1,3,H,W] -> (net = tanh(first half) [P,64], inp = relu(second half) [P,64])."""
+        a, h, w = self.trunk(x)
+        half = self.head.cout // 2
+        net = torch.empty(h * w, half, device=self.device, dtype=torch.float32)
+        inp = torch.empty(h * w, half, device=self.device, dtype=torch.float32)
+        self._conv(self.head, a, 1, h, w, None, False, epi=2, out=net, out2=inp)
+        return net, inp, h, w
+
+    def forward_nchw(self, x):
+        """Plain module semantics: [N,3,H,W] -> [N,Cout,h,w] (used by parity tests)."""
+        a, h, w = self.trunk(x)
+        N, C = x.shape[0], self.head.cout
+        out = torch.empty(N, h * w, C, device=self.device, dtype=torch.float32)
+        self._conv(self.head, a, N, h, w, None, False, epi=1, out=out, border=0, scale=1.0)
+        return out.view(N, h, w, C).permute(0, 3, 1, 2).contiguous()

@@ -28,7 +28,7 @@ from .update import UpdateBlock
 
 class RAFT(nn.Module):
     def __init__(self, cascade=[(64, 64, 8), (-1, 320, 8)], encoder_type="HR", dim_fmap=64, dim_net=64, dim_inp=64,
-                 test_mode=False, precision="fp32", view_group=None, gru_precision="f16x3"):
+                 test_mode=False, precision="fp32", view_group=None, gru_precision="f16x3", encoder_backend="hip"):
         super().__init__()
         self.cascade = [tuple(c) for c in cascade]
         self.encoder_type = encoder_type
@@ -40,13 +40,10 @@ class RAFT(nn.Module):
         self.cnet = BasicEncoder(output_dim=dim_net + dim_inp, norm_fn="none", type=encoder_type)
         self.update_block = UpdateBlock(cascade=self.cascade, dim_net=dim_net, dim_inp=dim_inp)
         self.update_block.conv_mode = gru_precision
+        self.encoder_backend = encoder_backend      # "hip": channels-last engine (csrc/enc_conv.hip); "miopen": PyTorch-ROCm convs
+        self._engines = None
+        self._src_buf = {}
         self.last_timings = None
-
-    def load_state_dict(self, state_dict, strict=True, **kw):
-        """Accepts DataParallel-style ``module.``-prefixed checkpoints (reference: inference.py:31-35)."""
-        if state_dict and all(k.startswith("module.") for k in state_dict):
-            state_dict = {k[7:]: v for k, v in state_dict.items()}
-        return super().load_state_dict(state_dict, strict=strict, **kw)
 
     def stages(self):
         """(D, incre, T) per cascade stage (reference: core/raft.py:76-81)."""
@@ -58,12 +55,37 @@ class RAFT(nn.Module):
         return out
 
     # ---------------------------------------------------------------- encoders (PyTorch-ROCm)
+    def _apply(self, fn, *a, **k):
+        self._engines = None            # weights moved / cast: repack on next use
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """Accepts DataParallel-style ``module.``-prefixed checkpoints (reference: inference.py:31-35)."""
+        if state_dict and all(k.startswith("module.") for k in state_dict):
+            state_dict = {k[7:]: v for k, v in state_dict.items()}
+        self._engines = None
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
     def encode(self, images, views):
         """images [1,N,3,H,W] in [-1,1]; ``views`` = source-view indices this rank owns
         -> (net [P,64], inp [P,64], reference features [P,C], source features [len(views),(h+4)*(w+4),C]);
         features are channels-last, scaled by 1/8, source maps with a 2-texel zero border."""
-        amp = self.precision == "amp"
         idx = [0] + list(views)
+        if self.encoder_backend == "hip" and self.precision == "fp32" and self.encoder_type == "HR":
+            from .encoder_hip import HipEncoder
+            dev = images.device
+            if self._engines is None or self._engines[0] != dev:
+                self._engines = (dev, HipEncoder(self.fnet, dev), HipEncoder(self.cnet, dev))
+            _, eng_f, eng_c = self._engines
+            net, inp, h, w = eng_c.context(images[0, :1])
+            key = (len(views), h, w, str(dev))
+            buf = self._src_buf.get(key)
+            if views and buf is None:      # border texels are written once (zeros) and never touched again
+                buf = torch.zeros(len(views), (h + 4) * (w + 4), self.dim_fmap, device=dev, dtype=torch.float32)
+                self._src_buf = {key: buf}
+            ref, src, _, _ = eng_f.features(images[0, idx], n_ref=1, border=2, scale=0.125, src_out=buf if views else None)
+            return net, inp, ref[0], src
+        amp = self.precision == "amp"
         with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
             ctx = self.cnet(images[:, [0]])[0, 0].float()                       # [128,h,w]
             fm = self.fnet(images[0, idx]).float()                             # [n,C,h,w] (instance norm is per image)

@@ -200,6 +200,38 @@ int cer_plane_stats_f32(const float* x, float* stats, long planes, long plane_si
 int cer_norm_act_f32(const float* x, const float* x_stats, const float* res, const float* res_stats, float* out,
                      long planes, long plane_size, int flags, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Encoder engine (reference: core/extractor.py:60-155, BasicEncoder "HR"), channels-last,
+ * batched, on the split-f16 MFMA path (fp32-equivalent accuracy):
+ *
+ * cer_enc_stem_f32      7x7 stride-2 pad-3 conv 3->32 of NCHW images [N,3,H,W] (normalize != 0: x*(2/255)-1 first,
+ *                       core/raft.py:40-41) -> raw channels-last [N, ho*wo, 32]; weights [147][32] (ci,ky,kx major).
+ * cer_enc_conv_f16x3    k x k (taps = 9 or 1), stride 1 or 2, zero pad k/2, Cin,Cout multiples of 32 (stride 2: Cout
+ *                       multiple of 64).  The producer's instance norm + ReLU is applied while staging:
+ *                         x' = tf_relu ? relu(n(x)) : n(x),  n(x) = tf_stats ? (x - mean[n,c]) * rstd[n,c] : x.
+ *                       epi 0 RAW : out [N, ho*wo, Cout] = conv + bias
+ *                       epi 1 FMAP: out [N, (ho+2b)*(wo+2b), Cout] = (conv + bias) * out_scale inside a b-texel border
+ *                                   (border texels are NOT written: zero the buffer once)
+ *                       epi 2 CTX : channels < Cout/2 -> tanh -> out [N, ho*wo, Cout/2]; the rest -> relu -> out2
+ * stats_partial (RAW / stem, may be NULL): per-block (sum, sum of squares) per output channel,
+ *                       [N][tiles][Cout][2] with tiles = cer_enc_conv_tiles(...) / cer_enc_stem_tiles(...);
+ * cer_enc_stats_reduce_f32  partials -> stats [N*C][2] = (mean, 1/sqrt(biased var + eps)) in fp64 (deterministic).
+ * cer_enc_merge_f32     out = relu?( fa(a) + fb(b) ) channels-last, f = optional norm with stats, flags 1 relu a,
+ *                       2 relu b, 4 relu sum  (core/extractor.py:49-57).
+ * Weights: cer_enc_conv_pack (OIHW -> fragment order; size in 2-byte halves from cer_enc_conv_packed_size). */
+int cer_enc_stem_tiles(int ho, int wo);
+int cer_enc_stem_f32(const float* images, const float* wgt_k_co, const float* bias, float* out, float* stats_partial,
+                     int N, int H, int W, int normalize, void* stream);
+long cer_enc_conv_packed_size(int Cout, int Cin, int taps);
+int cer_enc_conv_pack(const float* w_oihw, void* packed, int Cout, int Cin, int taps);
+int cer_enc_conv_tiles(int ho, int wo, int stride, int taps, int Cout);
+int cer_enc_conv_f16x3(const float* src, const float* tf_stats, int tf_relu, const void* packed_w, const float* bias,
+                       float* out, float* out2, float* stats_partial, int N, int h, int w, int Cin, int Cout,
+                       int taps, int stride, int epi, int out_border, float out_scale, void* stream);
+int cer_enc_stats_reduce_f32(const float* partial, float* stats, int N, int nblk, int C, long pixels, float eps, void* stream);
+int cer_enc_merge_f32(const float* a, const float* a_stats, const float* b, const float* b_stats, float* out,
+                      int N, long pixels, int C, int flags, void* stream);
+
 /* NCHW [C,h,w] -> NHWC [h*w,C] with a scale (feature maps: scale = 1/8, core/corr.py:30-31)
  * and NHWC -> NCHW; C % 4 == 0. */
 int cer_nchw_to_nhwc_f32(const float* src, float* dst, int C, long P, float scale, void* stream);

@@ -282,6 +282,27 @@ def test_encoder_fused_passes_match_oracle(dev, which):
     assert rel_l1(got, ref) < 1e-5
 
 
+@pytest.mark.parametrize("size", [(72, 104), (128, 160), (64, 96)])
+@pytest.mark.parametrize("which", ["fnet", "cnet"])
+def test_hip_encoder_engine_matches_oracle(dev, which, size):
+    """The channels-last encoder engine (stem + split-f16 MFMA convs + on-the-fly instance norm) vs the oracle."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.encoder_hip import HipEncoder
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+    from oracle import cer_oracle as O
+    images, _, _, _ = synthetic_scene(size[0], size[1], 2, seed=8)
+    model = RAFT(test_mode=True)
+    sd = fill_state_dict(model.state_dict(), seed=13)
+    model.load_state_dict(sd)
+    x = images[0].float() * (2 / 255.0) - 1
+    eng = HipEncoder(getattr(model, which), dev)
+    with torch.no_grad():
+        got = eng.forward_nchw(x.to(dev)).cpu()
+        ref = O.encoder(x, sd, which + ".", "instance" if which == "fnet" else "none")
+    assert got.shape == ref.shape
+    assert rel_l1(got, ref) < 1e-5
+
+
 def test_norm_act_kernels(dev):
     from cer_mvs_amd import ops
     x = hashed((3, 5, 12, 20), 131, -3, 5)
