@@ -432,15 +432,12 @@ extern "C" int cer_enc_merge_f32(const float* a, const float* a_stats, const flo
 
 // ---- stem: 7x7 stride-2 pad-3 convolution 3 -> 32 on the raw image (core/extractor.py:81,145; core/raft.py:40-41) ----
 // NCHW image in 0..255 -> x*(2/255) - 1 on the fly -> channels-last raw output [N, ho*wo, 32] + stats partials.
-// Direct fp32: one thread = one output pixel x 32 channels; weights [147][32] broadcast from LDS.
+// Direct fp32: one thread = one output pixel x 32 channels; weights [147][32] through the scalar cache.
 #define ST_PIX 256
 __global__ __launch_bounds__(ST_PIX) void enc_stem_kernel(const float* __restrict__ img, const float* __restrict__ wgt, const float* __restrict__ bias,
                                                           float* __restrict__ out, float* __restrict__ part, int H, int W, int ho, int wo,
                                                           int nblk, int normalize) {
-    __shared__ __attribute__((aligned(16))) float wsm[147 * 32];
     __shared__ float red[4][32][2];
-    for (int t = threadIdx.x; t < 147 * 32; t += ST_PIX) wsm[t] = wgt[t];
-    __syncthreads();
     const int n = blockIdx.y;
     const long p = (long)blockIdx.x * ST_PIX + threadIdx.x;
     const long Po = (long)ho * wo;
@@ -462,15 +459,10 @@ __global__ __launch_bounds__(ST_PIX) void enc_stem_kernel(const float* __restric
                     x = im[((long)ci * H + iy) * W + ix];
                     if (normalize) x = x * (2.0f / 255.0f) - 1.0f;
                 }
-                const float4* wr = reinterpret_cast<const float4*>(&wsm[((ci * 7 + ky) * 7 + kx) * 32]);
+                // wave-uniform address: the 32 weights of this tap arrive through the scalar cache (s_load), no LDS traffic
+                const float* wr = wgt + ((ci * 7 + ky) * 7 + kx) * 32;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float4 w4 = wr[q];
-                    acc[4 * q + 0] = fmaf(x, w4.x, acc[4 * q + 0]);
-                    acc[4 * q + 1] = fmaf(x, w4.y, acc[4 * q + 1]);
-                    acc[4 * q + 2] = fmaf(x, w4.z, acc[4 * q + 2]);
-                    acc[4 * q + 3] = fmaf(x, w4.w, acc[4 * q + 3]);
-                }
+                for (int c = 0; c < 32; ++c) acc[c] = fmaf(x, wr[c], acc[c]);
             }
         }
     if (valid) {
