@@ -471,20 +471,26 @@ __global__ __launch_bounds__(ST_PIX) void enc_stem_kernel(const float* __restric
         for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(o + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
     }
     if (part) {
+        // 64 values per lane (32 sums, 32 sums of squares) -> butterfly: 63 exchanges leave the wave total of value l on lane l
+        // (a plain 6-step shuffle reduction per value was 768 ds_bpermute per wave and dominated the kernel)
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        float v[64];
 #pragma unroll
         for (int c = 0; c < 32; ++c) {
-            float s = valid ? acc[c] : 0.f, q = valid ? acc[c] * acc[c] : 0.f;
+            v[c] = valid ? acc[c] : 0.f;
+            v[32 + c] = valid ? acc[c] * acc[c] : 0.f;
+        }
 #pragma unroll
-            for (int o2 = 32; o2 >= 1; o2 >>= 1) {
-                s += __shfl_xor(s, o2);
-                q += __shfl_xor(q, o2);
-            }
-            if (lane == 0) {
-                red[wave][c][0] = s;
-                red[wave][c][1] = q;
+        for (int hb = 32; hb >= 1; hb >>= 1) {
+            const bool up = (lane & hb) != 0;
+#pragma unroll
+            for (int i = 0; i < hb; ++i) {
+                const float send = up ? v[i] : v[i + hb];
+                const float keep = up ? v[i + hb] : v[i];
+                v[i] = keep + __shfl_xor(send, hb);
             }
         }
+        red[wave][lane & 31][lane >> 5] = v[0];           // lane l: l < 32 -> sum of channel l, else sum of squares of channel l-32
         __syncthreads();
         if (threadIdx.x < 32) {
             const int c = threadIdx.x;
