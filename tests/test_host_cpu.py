@@ -45,6 +45,53 @@ def test_argument_errors_without_device():
     assert b"CER_ESHAPE" in lib.cer_error_string(-2)
 
 
+def test_argument_errors_of_the_conv_and_encoder_entry_points():
+    from cer_mvs_amd import _lib
+    lib = _lib.load()
+    null, fake = ctypes.c_void_p(0), ctypes.c_void_p(0x1000)
+    ci = _lib.ConvInputs()
+    ci.nsrc = 1
+    ci.src[0] = 0x1000
+    ci.ch[0] = 48            # not a multiple of 32
+    ci.kind[0] = 0
+    assert lib.cer_conv3x3_f16x3(ctypes.byref(ci), fake, null, null, fake, null, null, null, 8, 8, 64, 1, null) == -2
+    assert lib.cer_conv3x3_f32(ctypes.byref(ci), fake, null, null, fake, null, null, null, 8, 8, 64, 1, null) == -2
+    ci.ch[0] = 64
+    assert lib.cer_conv3x3_f16x3(ctypes.byref(ci), fake, null, null, fake, null, null, null, 8, 8, 64, 2, null) == -1   # GATES needs out2 + aux
+    assert lib.cer_conv3x3_f16x3(ctypes.byref(ci), fake, null, null, fake, null, null, null, 8, 8, 96, 1, null) == -2   # Cout % 64
+    assert lib.cer_conv3x3_f16x3_packed_size(64, 192) == 6 * 9 * 2 * 2048
+    assert lib.cer_conv3x3_f16x3_packed_size(48, 192) == -2
+    assert lib.cer_delta_proj_packed_size(256) == 2 * 8 * 2 * 512 and lib.cer_delta_proj_packed_size(200) == -2
+    assert lib.cer_enc_conv_packed_size(64, 32, 9) == 9 * 2 * 2048 and lib.cer_enc_conv_packed_size(64, 32, 4) == -2
+    assert lib.cer_enc_conv_f16x3(fake, null, 0, fake, null, fake, null, null, 1, 8, 8, 48, 64, 9, 1, 0, 0, 1.0, null) == -2
+    assert lib.cer_enc_conv_f16x3(fake, null, 0, fake, null, fake, null, null, 1, 8, 8, 32, 32, 9, 2, 0, 0, 1.0, null) == -2   # stride 2 needs Cout % 64
+    assert lib.cer_enc_conv_f16x3(null, null, 0, fake, null, fake, null, null, 1, 8, 8, 32, 32, 9, 1, 0, 0, 1.0, null) == -1
+    assert lib.cer_enc_conv_tiles(296, 400, 1, 9, 64) == 13 * 37 and lib.cer_enc_conv_tiles(296, 400, 2, 9, 64) == 13 * 148
+    assert lib.cer_enc_stem_tiles(592, 800) == 1850
+    assert lib.cer_enc_merge_f32(fake, null, null, null, fake, 1, 10, 30, 0, null) == -2                      # C % 4
+    assert lib.cer_delta_sum_f32(null, 2, 0.0, fake, fake, null, 4, 4, null) == -1
+
+
+def test_f16x3_weight_packing_splits_hi_lo():
+    """cer_conv3x3_f16x3_pack (host code): hi = f16(w), lo = f16((w - hi) * 2^11), fragment order
+    [chunk32][tap][ntile32][k16-step][hi|lo][lane][8]; hi + lo/2048 reproduces w to 2^-22."""
+    from cer_mvs_amd import _lib
+    lib = _lib.load()
+    cout, cin = 64, 64
+    w = hashed((cout, cin, 3, 3), 17, -0.3, 0.3)
+    size = lib.cer_conv3x3_f16x3_packed_size(cout, cin)
+    packed = torch.empty(size, dtype=torch.float16)
+    ch, kind = (ctypes.c_int * 1)(cin), (ctypes.c_int * 1)(0)
+    assert lib.cer_conv3x3_f16x3_pack(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(packed.data_ptr()), cout, cin, ch, kind, 1) == 0
+    pk = packed.view(cin // 32, 9, cout // 32, 2, 2, 64, 8).float()
+    for kc, tap, nt, ks, lane, e in [(0, 0, 0, 0, 0, 0), (1, 5, 1, 1, 37, 3), (1, 8, 0, 0, 63, 7), (0, 2, 1, 1, 31, 4)]:
+        co, ci_ = nt * 32 + lane % 32, kc * 32 + ks * 16 + (lane // 32) * 8 + e
+        ref = float(w[co, ci_, tap // 3, tap % 3])
+        hi, lo = float(pk[kc, tap, nt, ks, 0, lane, e]), float(pk[kc, tap, nt, ks, 1, lane, e])
+        assert hi == float(torch.tensor(ref).half())
+        assert abs(hi + lo / 2048.0 - ref) <= abs(ref) * 2.0 ** -21
+
+
 def test_product_path_refuses_cpu_tensors():
     from cer_mvs_amd import RAFT, CorrBlock, alt_cuda_corr
     m = RAFT(test_mode=True)
