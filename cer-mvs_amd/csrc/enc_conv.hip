@@ -106,25 +106,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void enc_conv_kernel(
     int step = 0;
     for (int c0 = 0; c0 < a.cin; c0 += 32) {
         __syncthreads();
-        // ---- stage the halo of this 32-channel chunk: load all, then transform + split + write
+        // ---- stage the halo of this 32-channel chunk: load all, then transform + split + write.
+        // item = (halo pixel, 8-channel group); NTHR % 4 == 0, so a thread keeps the same channel group g for all its items
+        // and its 8 (mean, rstd) pairs are loaded once per chunk.
         {
             constexpr int ITEMS = (ROWS * 4 + NTHR - 1) / NTHR;
+            const int g = threadIdx.x & 3, prow0 = threadIdx.x >> 2;
             float4 raw[ITEMS][2];
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
-                const int idx = min((int)threadIdx.x + NTHR * i, ROWS * 4 - 1);
-                const int row = idx >> 2, g = idx & 3;
+                const int row = min(prow0 + (NTHR / 4) * i, ROWS - 1);
                 const int hy = row / HW, hx = row - hy * HW;
                 const int gy = min(max(ty0 * STRIDE + hy - PAD, 0), a.h - 1), gx = min(max(tx0 * STRIDE + hx - PAD, 0), a.w - 1);
                 const float* p = src + ((long)gy * a.w + gx) * a.cin + c0 + 8 * g;
                 raw[i][0] = cer_ld4(p);
                 raw[i][1] = cer_ld4(p + 4);
             }
+            float mu[8], rs[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                mu[e] = tf ? tf[2 * (c0 + 8 * g + e)] : 0.f;
+                rs[e] = tf ? tf[2 * (c0 + 8 * g + e) + 1] : 1.f;
+            }
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
-                const int idx = threadIdx.x + NTHR * i;
-                if (idx < ROWS * 4) {
-                    const int row = idx >> 2, g = idx & 3;
+                const int row = prow0 + (NTHR / 4) * i;
+                if (row < ROWS) {
                     const int hy = row / HW, hx = row - hy * HW;
                     const int gy = ty0 * STRIDE + hy - PAD, gx = tx0 * STRIDE + hx - PAD;
                     const bool inside = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
@@ -132,11 +139,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void enc_conv_kernel(
                     half8 hi, lo;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        float x = v[e];
-                        if (tf) {
-                            const int c = c0 + 8 * g + e;
-                            x = (x - tf[2 * c]) * tf[2 * c + 1];
-                        }
+                        float x = tf ? (v[e] - mu[e]) * rs[e] : v[e];
                         if (a.tf_relu) x = fmaxf(x, 0.f);
                         if (!inside) x = 0.f;             // zero padding of the (normalised) activation
                         _Float16 h_, l_;
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(ST_PIX) void enc_stem_kernel(const float* __restric
         for (int ky = 0; ky < 7; ++ky) {
             const int iy = oy * 2 + ky - 3;
             if (iy < 0 || iy >= H) continue;
-#pragma unroll
+#pragma unroll 1
             for (int kx = 0; kx < 7; ++kx) {
                 const int ix = ox * 2 + kx - 3;
                 float x = 0.f;
