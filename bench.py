@@ -8,11 +8,11 @@ HBM -> disparity in HBM) at BASELINE.json configs[1]: DTU 1600x1184, 10 source v
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1 (configs[3]): the V source views of ONE reference frame are sharded over the ranks
-(rank g owns views v with (v-1) % N == g); each rank builds its partial view-sum cost volume and the
-level-0 volume is all-reduced (RCCL over xGMI) once per cascade stage; the GRU loop is replicated.
-Total work is fixed as N grows => "scaling": "strong".  `--mode replica` instead runs N independent
-depth maps (one per rank, no collective, weak scaling).
+N > 1 (configs[3]): ONE reference frame is sharded over the ranks (`--mode shard`, default): rank g encodes the
+source views v with (v-1) % N == g and the feature maps are all-gathered (RCCL over xGMI); image rows are sharded for
+the cost volume and the GRU loop with a 7-row halo all-gather of (net, disp) per iteration (cer-mvs_amd/slab.py).
+Total work is fixed as N grows => "scaling": "strong".  `--mode views` is the simpler scheme (views sharded, view-sum
+volume all-reduced once per stage, GRU replicated); `--mode replica` runs N independent depth maps (weak scaling).
 
 Rank 0 prints ONE JSON line (see the README of this file's contract in DESIGN.md §Measurement): besides
 the driver's keys it carries
@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="dtu_1600x1184_v10_it32", choices=sorted(WORKLOADS))
-    ap.add_argument("--mode", default="shard", choices=["shard", "replica"])
+    ap.add_argument("--mode", default="shard", choices=["shard", "views", "replica"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "amp"])
     ap.add_argument("--encoder", default="hip", choices=["hip", "miopen"], help="encoder backend: channels-last HIP engine or PyTorch-ROCm (MIOpen)")
@@ -192,9 +192,9 @@ def main():
     from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
 
     H, W, V, cascade = WORKLOADS[args.workload]
-    shard = world > 1 and args.mode == "shard"
+    shard = world > 1 and args.mode in ("shard", "views")
     model = RAFT(cascade=cascade, test_mode=True, precision=args.precision, view_group=group if shard else None,
-                 gru_precision=args.gru_precision, encoder_backend=args.encoder)
+                 gru_precision=args.gru_precision, encoder_backend=args.encoder, shard="slab" if args.mode == "shard" else "views")
     sd = fill_state_dict(model.state_dict(), seed=5)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
@@ -226,9 +226,11 @@ def main():
     maps = args.steps * (world if (world > 1 and not shard) else 1)
 
     result = None
+    rec = None
+    if rank == 0 or shard:               # a sharded forward is collective: every rank runs the instrumented pass
+        rec = kernel_timing(model, inputs, scale)
     if rank == 0:
         P = (H // 4) * (W // 4)
-        rec = kernel_timing(model, inputs, scale)
         kern = {k: {"launches": n, "avg_us": 1e3 * t / n, "total_ms": t} for k, (n, t) in sorted(rec.items())}
         n_zr, t_zr = rec["conv3x3_gates_zr"]
         flops_zr = 2.0 * 9 * (64 + 49 + 64) * 128 * P            # algorithmic (unpadded K = net|disp49|corr), DESIGN.md
@@ -269,7 +271,9 @@ def main():
                         if args.gru_precision == "f16x3" else ""), "data": "synthetic",
             "config": {"workload": args.workload, "image": f"{W}x{H}", "src_views": V, "cascade": cascade,
                        "gru_iters": sum(c[2] for c in cascade),
-                       "parallelism": "single" if world == 1 else (f"view-shard x{world} + all-reduce/stage" if shard else f"replica x{world}")},
+                       "parallelism": "single" if world == 1 else (
+                           (f"row-slab x{world}: feature all-gather + 7-row halo all-gather per GRU iteration" if args.mode == "shard"
+                            else f"view-shard x{world} + all-reduce/stage") if shard else f"replica x{world}")},
             "roofline": roofline, "roofline_hbm_kernel": hbm, "kernels": kern,
         }
         if world == 1 and not args.no_cpu_baseline:

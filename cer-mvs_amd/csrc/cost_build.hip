@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void cost_build_kernel(const float* __restrict
                                                          const float* __restrict__ Pij, const float* __restrict__ disp_in,
                                                          float* __restrict__ vol, float* __restrict__ origin_out, int V, int h1, int w1,
                                                          int h2, int w2, int C, int D, int rs, float incre, float lim, int shift,
-                                                         int accumulate) {
+                                                         int accumulate, int y0) {
     const int lane = threadIdx.x & 63;
     const long P = (long)h1 * w1;
     // XCD-aware block order: workgroup b runs on XCD b % 8 (observed dispatch rule, speed only), so give each XCD a
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void cost_build_kernel(const float* __restrict
     const long p = (long)bid * 4 + (threadIdx.x >> 6);
     if (p >= P) return;                                    // wave-uniform
     const int sub = lane & 15, cx = (lane >> 4) & 1, cy = lane >> 5;
-    const float px = (float)(p % w1), py = (float)(p / w1);
+    const float px = (float)(p % w1), py = (float)(p / w1 + y0);     // y0: first image row of a row slab (multi-GPU)
     float origin = disp_in[p];
     if (shift && origin < lim) origin = lim;
     if (origin_out && lane == 0 && blockIdx.y == 0) origin_out[p] = origin;
@@ -135,24 +135,24 @@ __global__ __launch_bounds__(256) void cost_build_kernel(const float* __restrict
 
 template <int NQ>
 static int launch_build(const float* f1, const float* f2, const float* Pij, const float* disp_in, float* vol, float* origin_out, int V,
-                        int h1, int w1, int h2, int w2, int C, int D, int rs, double incre_d, int shift, int mode, hipStream_t st) {
+                        int h1, int w1, int h2, int w2, int C, int D, int rs, double incre_d, int shift, int mode, int y0, hipStream_t st) {
     const long P = (long)h1 * w1;
     const float lim = (float)((D / 2) * incre_d);
     const float incre = (float)incre_d;
     const unsigned gx = (unsigned)((P + 3) / 4);
     if (mode == 0)
         hipLaunchKernelGGL((cost_build_kernel<NQ, false>), dim3(gx, (unsigned)V), dim3(256), 0, st, f1, f2, Pij, disp_in, vol, origin_out, V,
-                           h1, w1, h2, w2, C, D, rs, incre, lim, shift, 0);
+                           h1, w1, h2, w2, C, D, rs, incre, lim, shift, 0, y0);
     else
         hipLaunchKernelGGL((cost_build_kernel<NQ, true>), dim3(gx, 1), dim3(256), 0, st, f1, f2, Pij, disp_in, vol, origin_out, V, h1, w1, h2,
-                           w2, C, D, rs, incre, lim, shift, mode == 2 ? 1 : 0);
+                           w2, C, D, rs, incre, lim, shift, mode == 2 ? 1 : 0, y0);
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }
 
 extern "C" int cer_cost_build_f32(const float* fmap1, const float* fmap2, const float* Pij, const float* disp_in, float* vol,
                                   float* origin_out, int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride, double incre,
-                                  int shift, int mode, void* stream) {
+                                  int shift, int mode, int y0, void* stream) {
     if (!fmap1 || !fmap2 || !Pij || !disp_in || !vol) return CER_EINVAL;
     if (V <= 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || C <= 0 || D <= 0 || row_stride < D || mode < 0 || mode > 2) return CER_EINVAL;
     if (C % 64 != 0 || C > 256 || V > 65535) return CER_ESHAPE;
@@ -160,10 +160,10 @@ extern "C" int cer_cost_build_f32(const float* fmap1, const float* fmap2, const 
     if (!cer_aligned16(fmap1) || !cer_aligned16(fmap2)) return CER_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     switch (C / 64) {
-        case 1: return launch_build<1>(fmap1, fmap2, Pij, disp_in, vol, origin_out, V, h1, w1, h2, w2, C, D, row_stride, incre, shift, mode, st);
-        case 2: return launch_build<2>(fmap1, fmap2, Pij, disp_in, vol, origin_out, V, h1, w1, h2, w2, C, D, row_stride, incre, shift, mode, st);
-        case 3: return launch_build<3>(fmap1, fmap2, Pij, disp_in, vol, origin_out, V, h1, w1, h2, w2, C, D, row_stride, incre, shift, mode, st);
-        default: return launch_build<4>(fmap1, fmap2, Pij, disp_in, vol, origin_out, V, h1, w1, h2, w2, C, D, row_stride, incre, shift, mode, st);
+        case 1: return launch_build<1>(fmap1, fmap2, Pij, disp_in, vol, origin_out, V, h1, w1, h2, w2, C, D, row_stride, incre, shift, mode, y0, st);
+        case 2: return launch_build<2>(fmap1, fmap2, Pij, disp_in, vol, origin_out, V, h1, w1, h2, w2, C, D, row_stride, incre, shift, mode, y0, st);
+        case 3: return launch_build<3>(fmap1, fmap2, Pij, disp_in, vol, origin_out, V, h1, w1, h2, w2, C, D, row_stride, incre, shift, mode, y0, st);
+        default: return launch_build<4>(fmap1, fmap2, Pij, disp_in, vol, origin_out, V, h1, w1, h2, w2, C, D, row_stride, incre, shift, mode, y0, st);
     }
 }
 

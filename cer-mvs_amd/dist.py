@@ -12,6 +12,11 @@ def group_info(group):
     return dist.get_world_size(group), dist.get_rank(group)
 
 
+def local_views_for(num_views, G, g):
+    """1-based source-view indices owned by rank g of G: v with (v-1) % G == g."""
+    return [v for v in range(1, num_views + 1) if (v - 1) % G == g]
+
+
 def local_views(num_views, group):
     """1-based source-view indices owned by this rank: v with (v-1) % G == g (cfg4: V=10 on G=2/4/8 ->
     5 / 3,3,2,2 / 2,2,1,1,1,1,1,1 views per rank).  May be empty when G > V."""

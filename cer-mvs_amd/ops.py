@@ -44,12 +44,14 @@ def alt_corr_backward(fmap1, fmap2, coords, corr_grad, radius):
     return g1, g2, gc
 
 
-def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, fold, vol=None, accumulate=False):
-    """fmap1 [P,C], fmap2 [V,(h1+4)*(w1+4),C] (NHWC, pre-scaled, 2-texel zero border), Pij [V,4,4], disp_in [P].
+def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, fold, vol=None, accumulate=False, src_hw=None, y0=0):
+    """fmap1 [P,C], fmap2 [V,(h2+4)*(w2+4),C] (NHWC, pre-scaled, 2-texel zero border), Pij [V,4,4], disp_in [P].
+    (h1, w1): reference grid of this call, first image row ``y0`` (row slabs); ``src_hw``: source-map size (default h1, w1).
     Returns (vol [V,P,rs] or [P,rs], origin [P]).  Level 0 only; call ``pyramid`` next."""
     V, P2, C = fmap2.shape
     P = h1 * w1
-    if P2 != (h1 + 4) * (w1 + 4):
+    h2, w2 = src_hw if src_hw is not None else (h1, w1)
+    if P2 != (h2 + 4) * (w2 + 4):
         raise RuntimeError("cost_build: fmap2 must carry a 2-texel zero border ([V,(h+4)*(w+4),C])")
     _, _, rs = row_layout(D, num_levels)
     if vol is None:
@@ -59,7 +61,7 @@ def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, 
     mode = (2 if accumulate else 1) if fold else 0
     L.check(L.load().cer_cost_build_f32(L.dev_ptr(fmap1, "fmap1"), L.dev_ptr(fmap2, "fmap2"), L.dev_ptr(Pij, "Pij"),
                                         L.dev_ptr(disp_in, "disp_in"), L.dev_ptr(vol, "vol"), L.dev_ptr(origin, "origin"),
-                                        V, h1, w1, h1, w1, C, D, rs, float(incre), int(bool(shift)), mode, L.cur_stream()),
+                                        V, h1, w1, h2, w2, C, D, rs, float(incre), int(bool(shift)), mode, int(y0), L.cur_stream()),
             "cost_build")
     return vol, origin
 

@@ -12,9 +12,11 @@ reference that a caller can observe, all deliberate (SURVEY.md §8(a) "quirks"):
     encoders only.  ``gru_precision`` picks the arithmetic of the update block's 3x3 convolutions:
     "f16x3" (default: split-f16 MFMA with two fp32 accumulators, fp32-equivalent accuracy, 5.3x the
     fp32-MFMA rate) or "fp32" (exact v_mfma_f32_16x16x4_f32).
-Multi-GPU: ``view_group`` = a torch.distributed process group over which source views are sharded
-(rank g owns views v with v % G == g); the level-0 view-sum volume is all-reduced once per stage
-(RCCL over xGMI) and everything after it is replicated."""
+Multi-GPU: ``view_group`` = a torch.distributed process group (one rank per GPU, RCCL over xGMI).  ``shard="slab"``
+(default): source views are sharded for the encoders (all-gather of the feature maps), image rows are sharded for the cost
+volume and the GRU loop with a 7-row halo exchange per iteration (slab.py) - strong scaling of one depth map;
+``shard="views"``: views sharded, view-sum volume all-reduced once per stage, GRU replicated (the simpler fallback, also
+used when a slab would be thinner than the halo)."""
 import torch
 import torch.nn as nn
 
@@ -28,7 +30,7 @@ from .update import UpdateBlock
 
 class RAFT(nn.Module):
     def __init__(self, cascade=[(64, 64, 8), (-1, 320, 8)], encoder_type="HR", dim_fmap=64, dim_net=64, dim_inp=64,
-                 test_mode=False, precision="fp32", view_group=None, gru_precision="f16x3", encoder_backend="hip"):
+                 test_mode=False, precision="fp32", view_group=None, gru_precision="f16x3", encoder_backend="hip", shard="slab"):
         super().__init__()
         self.cascade = [tuple(c) for c in cascade]
         self.encoder_type = encoder_type
@@ -36,6 +38,7 @@ class RAFT(nn.Module):
         self.test_mode = test_mode
         self.precision = precision
         self.view_group = view_group
+        self.shard = shard
         self.fnet = BasicEncoder(output_dim=dim_fmap, norm_fn="instance", type=encoder_type)
         self.cnet = BasicEncoder(output_dim=dim_net + dim_inp, norm_fn="none", type=encoder_type)
         self.update_block = UpdateBlock(cascade=self.cascade, dim_net=dim_net, dim_inp=dim_inp)
@@ -103,16 +106,22 @@ class RAFT(nn.Module):
         if "mean" not in self.update_block.aggregation or len(self.update_block.aggregation) != 1:
             return self._forward_literal(images, poses, intrinsics, scale, do_report)
         dev = images.device
-        poses = poses.clone().float()
-        if scale is not None:
-            s = float(torch.as_tensor(scale).reshape(-1)[0])
-            poses[..., :3, 3] *= s
-        factor = 8 if self.encoder_type == "LR" else 4
-        intrinsics = intrinsics.clone().float()
-        intrinsics[:, :, :2] /= factor
+        if scale is None:
+            raise AssertionError("scale is required in test mode (reference: core/raft.py:107)")
         batch, num, ch, ht, wd = images.shape
         if batch != 1:
             raise RuntimeError("RAFT.forward: batch must be 1 in test mode")
+        if self.view_group is not None and self.shard == "slab":
+            from . import slab
+            ex = slab.DistExchange(self.view_group)
+            if ex.G > 1 and slab.can_shard(ht // (8 if self.encoder_type == "LR" else 4), ex.G):
+                return slab.sharded_forward(self, images, poses, intrinsics, scale, ex)
+        poses = poses.clone().float()
+        s = float(torch.as_tensor(scale).reshape(-1)[0])
+        poses[..., :3, 3] *= s
+        factor = 8 if self.encoder_type == "LR" else 4
+        intrinsics = intrinsics.clone().float()
+        intrinsics[:, :, :2] /= factor
         images = images.float() * (2 / 255.0) - 1
         h, w = ht // factor, wd // factor
         P = h * w
@@ -141,10 +150,7 @@ class RAFT(nn.Module):
                 report()
             for _ in range(T):
                 ub.step(vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws)
-        out = disp.view(1, 1, h, w)
-        if scale is None:
-            raise AssertionError("scale is required in test mode (reference: core/raft.py:107)")
-        return out * s
+        return disp.view(1, 1, h, w) * s
 
     def _forward_literal(self, images, poses, intrinsics, scale, do_report):
         """Reference control flow call for call (CorrBlock per stage, per-view lookup, UpdateBlock.forward):

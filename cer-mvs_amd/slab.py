@@ -1,0 +1,169 @@
+"""Spatially sharded depth inference across the GPUs of one node.
+
+Rank g of G
+  * encodes the reference view, the context map and ITS source views (views v with (v-1) % G == g) and all-gathers the
+    source feature maps (the exchange step of the cost volume - RCCL all-gather over xGMI);
+  * owns a slab of image rows: builds the view-summed cost volume for its rows (all V views - no all-reduce needed) and runs
+    the GRU loop on the slab extended by HALO rows on each interior side;
+  * after every iteration all-gathers the HALO owned rows next to each slab border of (net, disp) and refreshes its halo.
+HALO = 7 is the receptive-field growth of one update-block iteration (corr_encoder 3x3: 1 row; z|r: 7x7 unfold + 3x3 = 4;
+q: 5; delta head two 3x3: 7): rows closer than 7 to an interior slab edge are computed from zero padding instead of the
+neighbour's data, are never used, and are overwritten by the next refresh.  Results equal the single-GPU forward.
+
+The collective layer is injectable: ``DistExchange`` (torch.distributed, one rank per process) or ``LocalExchange`` (G
+simulated ranks in one process - used to validate the slab logic on a single GPU and on CPU)."""
+import torch
+
+HALO = 7
+
+
+def slab_bounds(h, G, g, halo=HALO):
+    """Owned rows [r0, r1) and extended rows [e0, e1) of rank g (balanced split, remainder to the first ranks)."""
+    base, rem = divmod(h, G)
+    r0 = g * base + min(g, rem)
+    r1 = r0 + base + (1 if g < rem else 0)
+    return r0, r1, max(r0 - halo, 0), min(r1 + halo, h)
+
+
+def can_shard(h, G, halo=HALO):
+    """Every rank must own at least ``halo`` rows (its border strip is what the neighbour's halo is refreshed from)."""
+    return h // G >= halo
+
+
+class LocalExchange:
+    """G simulated ranks in one process: all_gather(list of G tensors) -> each rank sees the whole list."""
+
+    def __init__(self, G):
+        self.G = G
+        self.ranks = list(range(G))
+
+    def all_gather(self, tensors):
+        assert len(tensors) == self.G
+        return [list(tensors) for _ in range(self.G)]
+
+
+class DistExchange:
+    """One rank per process on a torch.distributed group (backend nccl = RCCL over xGMI on the GPU box, gloo in CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.group = group
+        self.G = dist.get_world_size(group)
+        self.ranks = [dist.get_rank(group)]
+
+    def all_gather(self, tensors):
+        import torch.distributed as dist
+        t = tensors[0].contiguous()
+        out = [torch.empty_like(t) for _ in range(self.G)]
+        dist.all_gather(out, t, group=self.group)
+        return [out]
+
+
+def border_strips(x, w, r0, r1, e0, halo=HALO):
+    """x [rows_ext*w, C] -> [2, halo*w, C]: the first and last ``halo`` OWNED rows (what the neighbours need)."""
+    top = x[(r0 - e0) * w:(r0 - e0 + halo) * w]
+    bot = x[(r1 - halo - e0) * w:(r1 - e0) * w]
+    return torch.stack([top, bot], 0)
+
+
+def refresh_halo(x, strips, w, g, G, r0, r1, e0, e1, halo=HALO):
+    """Fill the halo rows of x [rows_ext*w, C] from the neighbours' strips (list indexed by rank, each [2, halo*w, C])."""
+    if g > 0 and r0 > e0:          # rows [e0, r0) = the last `halo` owned rows of rank g-1
+        x[:(r0 - e0) * w] = strips[g - 1][1][(halo - (r0 - e0)) * w:]
+    if g < G - 1 and e1 > r1:      # rows [r1, e1) = the first `halo` owned rows of rank g+1
+        x[(r1 - e0) * w:] = strips[g + 1][0][:(e1 - r1) * w]
+    return x
+
+
+def sharded_forward(model, images, poses, intrinsics, scale, ex):
+    """Test-mode RAFT.forward sharded over ``ex.G`` ranks; ``ex.ranks`` are the ranks simulated by this process.
+    Returns the full-resolution disparity [1,1,h,w] * scale (identical on every rank)."""
+    from . import ops
+    from .dist import local_views_for
+    from .projective import pij_matrices
+    dev = images.device
+    G = ex.G
+    s = float(torch.as_tensor(scale).reshape(-1)[0])
+    poses = poses.clone().float()
+    poses[..., :3, 3] *= s
+    factor = 8 if model.encoder_type == "LR" else 4
+    intr = intrinsics.clone().float()
+    intr[:, :, :2] /= factor
+    _, num, _, ht, wd = images.shape
+    images = images.float() * (2 / 255.0) - 1
+    h, w = ht // factor, wd // factor
+    V = num - 1
+    ub = model.update_block
+    C = model.dim_fmap
+    vmax = (V + G - 1) // G
+    Pb = (h + 4) * (w + 4)
+
+    # ---- encoders: every rank the reference + context, each rank its own source views; all-gather the source maps
+    st = {}
+    send = []
+    for g in ex.ranks:
+        views = local_views_for(V, G, g)
+        net_l, inp_l, f1, f2 = model.encode(images, views)
+        st[g] = dict(net=net_l, inp=inp_l, f1=f1)
+        pad = torch.zeros(vmax, Pb, C, device=dev, dtype=torch.float32)
+        if views:
+            pad[:len(views)] = f2
+        send.append(pad)
+    gathered = ex.all_gather(send)
+    for i, g in enumerate(ex.ranks):
+        f2_all = torch.empty(V, Pb, C, device=dev, dtype=torch.float32)
+        for r in range(G):
+            vr = local_views_for(V, G, r)
+            for j, v in enumerate(vr):
+                f2_all[v - 1] = gathered[i][r][j]
+        st[g]["f2"] = f2_all
+    Pij = pij_matrices(poses[0], intr[0], [0] * V, list(range(1, V + 1))).to(dev)
+
+    # ---- slabs
+    for g in ex.ranks:
+        r0, r1, e0, e1 = slab_bounds(h, G, g)
+        d = st[g]
+        d.update(r0=r0, r1=r1, e0=e0, e1=e1, hs=e1 - e0)
+        d["net"] = d["net"][e0 * w:e1 * w].clone()
+        d["inp"] = d["inp"][e0 * w:e1 * w].contiguous()
+        d["f1s"] = d["f1"][e0 * w:e1 * w].contiguous()
+        d["disp"] = torch.zeros((e1 - e0) * w, device=dev, dtype=torch.float32)
+        d["hoist"] = ub.hoist(d["inp"], e1 - e0, w)
+        d["ws"] = ub.workspace((e1 - e0) * w, dev)
+
+    for stage, (D, incre, T) in enumerate(model.stages()):
+        for g in ex.ranks:
+            d = st[g]
+            vol, origin = ops.cost_build(d["f1s"], d["f2"], Pij, d["disp"], D, incre, stage == 0, d["hs"], w, ub.num_levels,
+                                         fold=True, src_hw=(h, w), y0=d["e0"])
+            ops.pyramid(vol, D, ub.num_levels, scale=1.0 / V)
+            d["vol"], d["origin"] = vol, origin
+        for _ in range(T):
+            send = []
+            for g in ex.ranks:
+                d = st[g]
+                ub.step(d["vol"], d["origin"], d["net"], d["disp"], d["hoist"], stage, d["hs"], w, D, incre, d["ws"])
+                # only the 2 x HALO border rows travel: [2, HALO*w, 64 + 1] per rank
+                send.append(torch.cat([border_strips(d["net"], w, d["r0"], d["r1"], d["e0"]),
+                                       border_strips(d["disp"][:, None], w, d["r0"], d["r1"], d["e0"])], 2))
+            gathered = ex.all_gather(send)
+            for i, g in enumerate(ex.ranks):
+                d = st[g]
+                refresh_halo(d["net"], [t[..., :64] for t in gathered[i]], w, g, G, d["r0"], d["r1"], d["e0"], d["e1"])
+                refresh_halo(d["disp"], [t[..., 64] for t in gathered[i]], w, g, G, d["r0"], d["r1"], d["e0"], d["e1"])
+
+    # ---- gather the owned rows of every rank
+    rows_max = (h + G - 1) // G
+    send = []
+    for g in ex.ranks:
+        d = st[g]
+        own = torch.zeros(rows_max * w, device=dev, dtype=torch.float32)
+        n = (d["r1"] - d["r0"]) * w
+        own[:n] = d["disp"][(d["r0"] - d["e0"]) * w:(d["r1"] - d["e0"]) * w]
+        send.append(own)
+    gathered = ex.all_gather(send)
+    out = torch.empty(h * w, device=dev, dtype=torch.float32)
+    for r in range(G):
+        r0, r1, _, _ = slab_bounds(h, G, r)
+        out[r0 * w:r1 * w] = gathered[0][r][:(r1 - r0) * w]
+    return out.view(1, 1, h, w) * s

@@ -87,3 +87,83 @@ def test_partition_covers_every_view_once():
                 seen += [v for v in range(1, V + 1) if (v - 1) % G == g]
             assert sorted(seen) == list(range(1, V + 1))
     assert cdist.local_views(10, None) == list(range(1, 11))
+
+
+# ---------------------------------------------------------------------------------------------- row-slab sharding
+def _fake_step(x, rows, w):
+    """Stand-in for one update-block iteration: a vertical 15-tap filter + nonlinearity = receptive field of exactly 7 rows,
+    zero padded at the edges of whatever tensor it is given (as the conv kernels do on a slab)."""
+    import torch.nn.functional as F
+    img = x.view(rows, w, -1).permute(2, 0, 1)[None]
+    k = torch.linspace(0.2, 1.0, 15).view(1, 1, 15, 1).repeat(img.shape[1], 1, 1, 1)
+    y = torch.tanh(F.conv2d(img, k, padding=(7, 0), groups=img.shape[1]) * 0.3 + 0.1 * img)
+    return y[0].permute(1, 2, 0).reshape(rows * w, -1).contiguous()
+
+
+def _slab_worker(rank, world, port, ret):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    from cer_mvs_amd import slab
+    from test_oracle_golden import hashed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    h, w, C = 23, 6, 5
+    full = hashed((h * w, C), 77)
+    ex = slab.DistExchange(dist.group.WORLD)
+    r0, r1, e0, e1 = slab.slab_bounds(h, world, rank)
+    x = full[e0 * w:e1 * w].clone()
+    ref = full.clone()
+    for _ in range(3):
+        x = _fake_step(x, e1 - e0, w)
+        ref = _fake_step(ref, h, w)
+        strips = ex.all_gather([slab.border_strips(x, w, r0, r1, e0)])[0]
+        slab.refresh_halo(x, strips, w, rank, world, r0, r1, e0, e1)
+    own = x[(r0 - e0) * w:(r1 - e0) * w]
+    ret[rank] = (float((own - ref[r0 * w:r1 * w]).abs().max()), float((x - ref[e0 * w:e1 * w]).abs().max()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_slabs_with_halo_exchange_reproduce_the_full_image():
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_slab_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret[r][0] < 1e-6 and ret[r][1] < 1e-6, dict(ret)
+
+
+def test_slab_bounds_cover_the_image():
+    from cer_mvs_amd import slab
+    for h in (16, 37, 120, 296, 384, 540):
+        for G in (1, 2, 3, 4, 8):
+            rows = []
+            for g in range(G):
+                r0, r1, e0, e1 = slab.slab_bounds(h, G, g)
+                assert 0 <= e0 <= r0 < r1 <= e1 <= h and r0 - e0 <= slab.HALO and e1 - r1 <= slab.HALO
+                rows += list(range(r0, r1))
+            assert rows == list(range(h))
+    assert slab.can_shard(296, 8) and not slab.can_shard(40, 8)
+
+
+def test_local_exchange_simulation_matches_full_image():
+    """The same bookkeeping with G simulated ranks in one process (what the GPU test of the real kernels uses)."""
+    from cer_mvs_amd import slab
+    from test_oracle_golden import hashed
+    h, w, C, G = 40, 5, 3, 4
+    full = hashed((h * w, C), 78)
+    ex = slab.LocalExchange(G)
+    b = [slab.slab_bounds(h, G, g) for g in range(G)]
+    xs = [full[e0 * w:e1 * w].clone() for (_, _, e0, e1) in b]
+    ref = full.clone()
+    for _ in range(4):
+        xs = [_fake_step(x, e1 - e0, w) for x, (_, _, e0, e1) in zip(xs, b)]
+        ref = _fake_step(ref, h, w)
+        got = ex.all_gather([slab.border_strips(x, w, r0, r1, e0) for x, (r0, r1, e0, e1) in zip(xs, b)])
+        for g in range(G):
+            slab.refresh_halo(xs[g], got[g], w, g, G, *b[g])
+    for g, (r0, r1, e0, e1) in enumerate(b):
+        assert float((xs[g] - ref[e0 * w:e1 * w]).abs().max()) < 1e-6
