@@ -37,6 +37,7 @@ WORKLOADS = {
     "dtu_1600x1184_v10_it32": (1184, 1600, 10, [(64, 64, 16), (-1, 320, 16)]),
     "dtu_640x480_v2_it4": (480, 640, 2, [(64, 64, 2), (-1, 320, 2)]),
     "blended_2048x1536_v7_it16": (1536, 2048, 7, [(64, 64, 8), (-1, 320, 8)]),
+    "tnt_3840x2160_v15_it16": (2160, 3840, 15, [(64, 64, 8), (-1, 320, 8)]),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 F16_MFMA_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak

@@ -165,13 +165,20 @@ def disp_features(disp, k=7):
     return u - disp
 
 
-def update_block(sd, net, inp, disp, corr_frames, stage, prefix="update_block."):
+def update_block(sd, net, inp, disp, corr_frames, stage, prefix="update_block.", aggregation=("mean",)):
     """UpdateBlock.forward + ConvGRU.forward, defaults aggregation=["mean"], shared corr_encoder/gru,
     per-stage delta (core/update.py:87-120, 17-25).  net, inp [1,64,h,w]; disp [1,1,h,w];
     corr_frames [V,33,h,w] -> (net [1,64,h,w], delta [1,1,h,w])."""
     g = lambda n: sd[prefix + n]
     d = 100 * disp_features(disp)
-    corr = corr_frames.mean(0, keepdim=True)
+    parts = []                                    # core/update.py:101-110: mean / max / std over views, stacked per channel
+    if "mean" in aggregation:
+        parts.append(corr_frames.mean(0))
+    if "max" in aggregation:
+        parts.append(corr_frames.max(0).values)
+    if "std" in aggregation:
+        parts.append(corr_frames.std(0))
+    corr = torch.stack(parts, 1).reshape(1, -1, *corr_frames.shape[-2:])
     corr = F.relu(F.conv2d(corr, g("corr_encoder.0.weight"), g("corr_encoder.0.bias")))
     corr = F.relu(F.conv2d(corr, g("corr_encoder.2.weight"), g("corr_encoder.2.bias"), padding=1))
     x = torch.cat([inp, d, corr], 1)

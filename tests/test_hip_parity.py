@@ -318,6 +318,63 @@ def test_norm_act_kernels(dev):
     assert rel_l1(got, F.relu(x) + F.relu(r)) < 1e-7
 
 
+def test_update_block_other_aggregations(dev):
+    """aggregation = ["mean", "max", "std"] (core/update.py:101-110): the literal UpdateBlock API against the oracle."""
+    from cer_mvs_amd.update import UpdateBlock
+    from oracle import cer_oracle as O
+    h1, w1, V = 12, 20, 4
+    agg = ["mean", "max", "std"]
+    torch.manual_seed(3)
+    ub = UpdateBlock(cascade=[(64, 64, 1), (-1, 320, 1)], dim_net=64, dim_inp=64, aggregation=agg)
+    sd = {"update_block." + k: v.detach().clone() for k, v in ub.state_dict().items()}
+    net = torch.tanh(hashed((1, 1, 64, h1, w1), 141, -2, 2))
+    inp = torch.relu(hashed((1, 1, 64, h1, w1), 142, -1, 2))
+    disp = hashed((1, 1, h1, w1), 143, 0.0, 0.0025)
+    corr = hashed((1, V, 33, h1, w1), 144, -1.5, 3.0)
+    ub = ub.to(dev)
+    with torch.no_grad():
+        n2, delta = ub(net.to(dev), inp.to(dev), disp.to(dev), corr.to(dev), 1)
+        rn, rd = O.update_block(sd, net[0], inp[0], disp, corr[0], 1, aggregation=agg)
+    assert rel_l1(n2.cpu()[0], rn) < 1e-5 and rel_l1(delta.cpu(), rd) < 1e-5
+
+
+def test_inference_driver_writes_reference_format(dev, tmp_path):
+    """The caller-side counterpart of inference.py:41-66 end to end: loader tuple -> model -> depth -> PFM file."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd import inference as I
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+    images, poses, intr, scale = synthetic_scene(64, 96, 2, seed=5)
+    model = RAFT(cascade=[(64, 64, 1), (-1, 320, 1)], test_mode=True)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=2))
+    model = model.to(dev)
+    loader = [(images, poses, intr, [["rect_001"]], scale)]
+    files = I.inference(loader, None, tmp_path, rescale=1, model=model, num_frames=3)
+    assert files == [str(tmp_path / "depths" / "rect_001_scale1_nf3.pfm")]
+    raw = open(files[0], "rb").read()
+    assert raw.startswith(b"Pf\n24 16\n-1.000000\n")
+    depth = np.frombuffer(raw[len(b"Pf\n24 16\n-1.000000\n"):], dtype="<f4").reshape(16, 24)[::-1]
+    with torch.no_grad():
+        disp = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale).cpu().numpy()[0, 0]
+    assert np.array_equal(depth, I.disp_to_depth(disp))
+    # rescale + crop path (utils/data_utils.py:58-78) keeps running and changes the output size accordingly
+    files = I.inference(loader, None, tmp_path, rescale=2, crop=(64, 128), model=model, num_frames=3)
+    assert open(files[0], "rb").read().startswith(b"Pf\n32 16\n")
+
+
+def test_large_configs_run(dev):
+    """BASELINE.json configs[4] size (2048x1536, 7 views) with a short cascade: finite output of the right shape, bitwise repeatable."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+    images, poses, intr, scale = synthetic_scene(1536, 2048, 7, seed=1)
+    model = RAFT(cascade=[(64, 64, 1), (-1, 320, 1)], test_mode=True)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=5))
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        a = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale)
+        b = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale)
+    assert a.shape == (1, 1, 384, 512) and torch.isfinite(a).all() and torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------------ end to end
 def _run_e2e(dev, golden, name, literal=False, gru_precision="f16x3"):
     from cer_mvs_amd import RAFT
