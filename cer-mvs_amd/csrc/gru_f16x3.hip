@@ -215,6 +215,58 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
         }
     }
 
+    // MFMA operands of one k16-step: A hi/lo for the wave's WM pixel tiles, B hi/lo for its WN channel tiles
+    struct Frag {
+        half8 ah[WM], al[WM], bh[WN], bl[WN];
+    };
+    auto load_frags = [&](Frag& f, const char* B, int dy, int dx, int ks) {
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+            const int row = (wm * WM + m + dy) * HX_HW + li + dx;
+            const char* p = ldsA + row * HX_AS + ks * 32 + kg * 16;
+            f.ah[m] = *reinterpret_cast<const half8*>(p);
+            f.al[m] = *reinterpret_cast<const half8*>(p + 64);
+        }
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const char* p = B + (((wn * WN + n) * 2 + ks) * 2) * 1024 + lane * 16;
+            f.bh[n] = *reinterpret_cast<const half8*>(p);
+            f.bl[n] = *reinterpret_cast<const half8*>(p + 1024);
+        }
+    };
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n) {
+                if (HX_ABL & 1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("" ::"v"(f.ah[m]), "v"(f.al[m]), "v"(f.bh[n]), "v"(f.bl[n]));
+#endif
+                } else {
+                    accm[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[m], f.bh[n], accm[m][n], 0, 0, 0);
+                    accl[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[m], f.bl[n], accl[m][n], 0, 0, 0);
+                    accl[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[m], f.bh[n], accl[m][n], 0, 0, 0);
+                }
+            }
+    };
+    // (64-channel blocks only: with 128 channels per block the extra live fragment set does not fit 128 VGPRs.)
+    constexpr bool SKEW = (WM * WN == 1);
+    // The MFMA stream is skewed by half a tap against the LDS reads: the second k16-step of tap t-1 (already in registers)
+    // is multiplied right after barrier(t) while the first operands of tap t travel from LDS, so the matrix pipe has work
+    // during the post-barrier LDS latency.  `pend` starts as zeros (a harmless first multiply) and is drained at the end.
+    Frag pend;
+    if constexpr (SKEW)
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { pend.ah[m][e] = (_Float16)0; pend.al[m][e] = (_Float16)0; }
+    if constexpr (SKEW)
+#pragma unroll
+    for (int n = 0; n < WN; ++n)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { pend.bh[n][e] = (_Float16)0; pend.bl[n][e] = (_Float16)0; }
+
     int step = 0;                                          // chunk * 9 + tap; ring slot = step % NBUF
     for (int s = 0; s < a.nsrc; ++s) {
         for (int c0 = 0; c0 < a.chpad[s]; c0 += HX_KC) {
@@ -236,40 +288,51 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
                     hx_issue_B<NB, NWAVES>(ldsB + ((step + NBUF - 1) % NBUF) * B_BYTES, wbase + (long)(step + NBUF - 1) * NT * 2048);
                 const char* B = ldsB + (step % NBUF) * B_BYTES;
                 const int dy = tap / 3, dx = tap - dy * 3;
+                if constexpr (SKEW) {
+                    Frag cur;
+                    load_frags(cur, B, dy, dx, 0);
+                    mma(pend);                             // previous tap, second k16-step: covers the LDS latency of `cur`
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_frags(pend, B, dy, dx, 1);
+                    mma(cur);                              // covers the LDS latency of the new `pend`
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    half8 ah[WM], al[WM], bh[WN], bl[WN];
+                    for (int ks = 0; ks < 2; ++ks) {
+                        half8 ah[WM], al[WM], bh[WN], bl[WN];
 #pragma unroll
-                    for (int m = 0; m < WM; ++m) {
-                        const int row = (wm * WM + m + dy) * HX_HW + li + dx;
-                        const char* p = ldsA + row * HX_AS + ks * 32 + kg * 16;
-                        ah[m] = *reinterpret_cast<const half8*>(p);
-                        al[m] = *reinterpret_cast<const half8*>(p + 64);
-                    }
-#pragma unroll
-                    for (int n = 0; n < WN; ++n) {
-                        const char* p = B + (((wn * WN + n) * 2 + ks) * 2) * 1024 + lane * 16;
-                        bh[n] = *reinterpret_cast<const half8*>(p);
-                        bl[n] = *reinterpret_cast<const half8*>(p + 1024);
-                    }
-#pragma unroll
-                    for (int m = 0; m < WM; ++m)
+                        for (int m = 0; m < WM; ++m) {
+                            const int row = (wm * WM + m + dy) * HX_HW + li + dx;
+                            const char* p = ldsA + row * HX_AS + ks * 32 + kg * 16;
+                            ah[m] = *reinterpret_cast<const half8*>(p);
+                            al[m] = *reinterpret_cast<const half8*>(p + 64);
+                        }
 #pragma unroll
                         for (int n = 0; n < WN; ++n) {
-                            if (HX_ABL & 1) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                                asm volatile("" ::"v"(ah[m]), "v"(al[m]), "v"(bh[n]), "v"(bl[n]));
-#endif
-                            } else {
-                                accm[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], accm[m][n], 0, 0, 0);
-                                accl[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], accl[m][n], 0, 0, 0);
-                                accl[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], accl[m][n], 0, 0, 0);
-                            }
+                            const char* p = B + (((wn * WN + n) * 2 + ks) * 2) * 1024 + lane * 16;
+                            bh[n] = *reinterpret_cast<const half8*>(p);
+                            bl[n] = *reinterpret_cast<const half8*>(p + 1024);
                         }
+#pragma unroll
+                        for (int m = 0; m < WM; ++m)
+#pragma unroll
+                            for (int n = 0; n < WN; ++n) {
+                                if (HX_ABL & 1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                                    asm volatile("" ::"v"(ah[m]), "v"(al[m]), "v"(bh[n]), "v"(bl[n]));
+#endif
+                                } else {
+                                    accm[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], accm[m][n], 0, 0, 0);
+                                    accl[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], accl[m][n], 0, 0, 0);
+                                    accl[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], accl[m][n], 0, 0, 0);
+                                }
+                            }
+                    }
                 }
             }
         }
     }
+    if constexpr (SKEW) mma(pend);
 
     // ---- epilogue: lane holds channel co, pixels x = tx0 + (r&3) + 8*(r>>2) + 4*kg of row gy
     const int half = a.cout / 2;
