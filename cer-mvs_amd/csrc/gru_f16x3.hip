@@ -48,6 +48,7 @@ struct ConvArgsX {
     int kind[CER_CONV_MAX_SRC];
     int nsrc;
     const _Float16* wpk;
+    const _Float16* wpk_c;                 // collapsed-disparity packing for interior tiles (or null)
     const float* bias;
     const float* init;
     float* out;
@@ -145,6 +146,27 @@ __device__ __forceinline__ void hx_stage_disp(char* __restrict__ ldsA, const flo
     }
 }
 
+// collapsed disparity chunk (interior tiles only): channel s = (sy, sx) of the 9x9 window holds 100 * (disp[p + s - 4] - disp[p]).
+// The 3x3 conv over the 49 unfold features is linear in the disparity, so for a pixel whose 3x3 neighbours are all inside
+// the image it equals ONE 81-tap filter on the (zero-padded) disparity around p; the weights are pre-summed on the host
+// (cer_conv3x3_f16x3_pack_collapsed).  Only the centre tap reads this chunk, so only the tile's own 128 pixels are staged.
+template <int NTHR>
+__device__ __forceinline__ void hx_stage_disp9(char* __restrict__ ldsA, const float* __restrict__ ldsD, int c0) {
+    for (int idx = threadIdx.x; idx < HX_TH * HX_TW * 4; idx += NTHR) {
+        const int px = idx >> 2, g = idx & 3;
+        const int hy = 1 + px / HX_TW, hx = 1 + px % HX_TW;
+        const float ctr = ldsD[(hy + 3) * HX_DT_W + hx + 3];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + 8 * g + e;
+            const int sy = c / 9, sx = c - sy * 9;
+            v[e] = (c < 81) ? 100.0f * (ldsD[(hy - 1 + sy) * HX_DT_W + hx - 1 + sx] - ctr) : 0.f;
+        }
+        hx_write8(ldsA, hy * HX_HW + hx, g, v);
+    }
+}
+
 // DMA the block's weight slice of one (chunk, tap) step into an LDS ring slot: NB/8 pieces of 1 KiB
 template <int NB, int NWAVES>
 __device__ __forceinline__ void hx_issue_B(char* __restrict__ ldsB, const _Float16* __restrict__ slice) {
@@ -179,9 +201,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
     const int NT = a.cout / 32;
 
     // ---- pipeline prologue: the weight DMA ring runs NBUF-1 steps ahead of the multiply, across chunk boundaries
+    // tiles whose pixels all have their 3x3 neighbourhood inside the image take the collapsed disparity chunks
+    const bool coll = a.wpk_c && ty0 >= 1 && ty0 + HX_TH <= a.h - 1 && tx0 >= 1 && tx0 + HX_TW <= a.w - 1;
     int nsteps = 0;
-    for (int s = 0; s < a.nsrc; ++s) nsteps += (a.chpad[s] / HX_KC) * 9;
-    const _Float16* wbase = a.wpk + (long)(nb0 / 32) * 2048;      // + step * NT * 2048, step = chunk * 9 + tap
+    for (int s = 0; s < a.nsrc; ++s) nsteps += (coll && a.kind[s] == 1) ? 3 : (a.chpad[s] / HX_KC) * 9;
+    const _Float16* wbase = (coll ? a.wpk_c : a.wpk) + (long)(nb0 / 32) * 2048;      // + step * NT * 2048
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i)
         if (i < nsteps && !(HX_ABL & 16)) hx_issue_B<NB, NWAVES>(ldsB + i * B_BYTES, wbase + (long)i * NT * 2048);
@@ -269,14 +293,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
 
     int step = 0;                                          // chunk * 9 + tap; ring slot = step % NBUF
     for (int s = 0; s < a.nsrc; ++s) {
-        for (int c0 = 0; c0 < a.chpad[s]; c0 += HX_KC) {
+        const bool c9 = coll && a.kind[s] == 1;
+        const int chunk_end = c9 ? 96 : a.chpad[s], ntaps = c9 ? 1 : 9;
+        for (int c0 = 0; c0 < chunk_end; c0 += HX_KC) {
             __syncthreads();                               // every wave has finished reading A (previous chunk, tap 8); ldsD visible
             if (!(HX_ABL & 4)) {
                 if (a.kind[s] == 0) hx_stage_tensor<NTHR>(ldsA, a, s, c0, ty0, tx0);
+                else if (c9) hx_stage_disp9<NTHR>(ldsA, ldsD, c0);
                 else hx_stage_disp<NTHR>(ldsA, ldsD, a, c0, ty0, tx0);
             }
 #pragma unroll 1
-            for (int tap = 0; tap < 9; ++tap, ++step) {
+            for (int t = 0; t < ntaps; ++t, ++step) {
+                const int tap = c9 ? 4 : t;
                 // B[step] was DMA'd NBUF-1 steps ago.  VMEM ops retire in order, so leaving the DMAs of the NBUF-2 younger
                 // steps in flight still guarantees B[step].  (Builtin waits: hipcc's own scoreboard must see them.)
                 const int younger = min(NBUF - 2, nsteps - 1 - step);
@@ -478,6 +506,87 @@ extern "C" int cer_conv3x3_f16x3_pack(const float* w, void* packed_v, int Cout, 
     return CER_OK;
 }
 
+// Collapsed packing: same step order as above, except that a kind-1 (disparity) source contributes 3 single-tap steps
+// holding the 81-tap filter  W9[co][s] = sum_{t + u = s} w[co][u][t]  -  [|s - 4| <= 1] * sum_u w[co][u][t = s - 3]
+// (t over the 3x3 conv taps, u over the 7x7 unfold offsets, s over the 9x9 window; the second term is the centre
+// subtraction of core/update.py:84).  Valid for pixels whose 3x3 neighbourhood lies inside the image.
+extern "C" long cer_conv3x3_f16x3_collapsed_size(int Cout, const int* ch, const int* kind, int nsrc) {
+    if (!ch || !kind || nsrc <= 0 || nsrc > CER_CONV_MAX_SRC || Cout <= 0 || Cout % 32) return CER_ESHAPE;
+    long steps = 0;
+    for (int s = 0; s < nsrc; ++s) steps += kind[s] == 1 ? 3 : (hx_padded_channels(ch[s], kind[s]) / 32) * 9;
+    return steps * (Cout / 32) * 2048;
+}
+
+static void hx_pack_step(_Float16* packed, long step, int NT, int nt, const float* col /* [32 k][32 co] */) {
+    for (int ks = 0; ks < 2; ++ks)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e) {
+                float v = col[(ks * 16 + (lane >> 5) * 8 + e) * 32 + (lane & 31)];
+                v = v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v);
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
+                const long base = ((step * NT + nt) * 2 + ks) * 2;
+                packed[(base + 0) * 512 + lane * 8 + e] = hi;
+                packed[(base + 1) * 512 + lane * 8 + e] = lo;
+            }
+}
+
+extern "C" int cer_conv3x3_f16x3_pack_collapsed(const float* w, void* packed_v, int Cout, int Cin, const int* ch, const int* kind, int nsrc) {
+    if (!w || !packed_v || !ch || !kind || nsrc <= 0 || nsrc > CER_CONV_MAX_SRC) return CER_EINVAL;
+    if (Cout % 32) return CER_ESHAPE;
+    int real = 0;
+    for (int s = 0; s < nsrc; ++s) {
+        if (kind[s] == 1 && ch[s] != 49) return CER_ESHAPE;
+        real += ch[s];
+    }
+    if (real != Cin) return CER_ESHAPE;
+    _Float16* packed = (_Float16*)packed_v;
+    const int NT = Cout / 32;
+    float col[32 * 32];
+    long step = 0;
+    int c = 0;
+    for (int s = 0; s < nsrc; ++s) {
+        if (kind[s] == 1) {
+            for (int kc = 0; kc < 3; ++kc, ++step)
+                for (int nt = 0; nt < NT; ++nt) {
+                    for (int k = 0; k < 32; ++k)
+                        for (int j = 0; j < 32; ++j) {
+                            const int sidx = kc * 32 + k, co = nt * 32 + j;
+                            double acc = 0.0;
+                            if (sidx < 81) {
+                                const int sy = sidx / 9, sx = sidx % 9;
+                                for (int ty = 0; ty < 3; ++ty)
+                                    for (int tx = 0; tx < 3; ++tx) {
+                                        const int uy = sy - ty, ux = sx - tx;
+                                        if (uy >= 0 && uy < 7 && ux >= 0 && ux < 7) acc += (double)w[((long)co * Cin + c + uy * 7 + ux) * 9 + ty * 3 + tx];
+                                    }
+                                if (sy >= 3 && sy <= 5 && sx >= 3 && sx <= 5) {
+                                    const int t = (sy - 3) * 3 + (sx - 3);
+                                    for (int u = 0; u < 49; ++u) acc -= (double)w[((long)co * Cin + c + u) * 9 + t];
+                                }
+                            }
+                            col[k * 32 + j] = (float)acc;
+                        }
+                    hx_pack_step(packed, step, NT, nt, col);
+                }
+        } else {
+            const int pc = hx_padded_channels(ch[s], kind[s]);
+            for (int kc = 0; kc < pc / 32; ++kc)
+                for (int tap = 0; tap < 9; ++tap, ++step)
+                    for (int nt = 0; nt < NT; ++nt) {
+                        for (int k = 0; k < 32; ++k)
+                            for (int j = 0; j < 32; ++j) {
+                                const int ci = kc * 32 + k;
+                                col[k * 32 + j] = ci < ch[s] ? w[((long)(nt * 32 + j) * Cin + c + ci) * 9 + tap] : 0.f;
+                            }
+                        hx_pack_step(packed, step, NT, nt, col);
+                    }
+        }
+        c += ch[s];
+    }
+    return CER_OK;
+}
+
 template <int WAVES_M, int WAVES_N, int WM, int WN, int NBUF, int MINW>
 static int hx_launch(const ConvArgsX& a, int epi, int nby, hipStream_t st) {
     constexpr int NB = WAVES_N * WN * 32;
@@ -502,8 +611,8 @@ static int hx_launch(const ConvArgsX& a, int epi, int nby, hipStream_t st) {
     return CER_OK;
 }
 
-extern "C" int cer_conv3x3_f16x3(const cer_conv_inputs* in, const void* packed_w, const float* bias, const float* init, float* out,
-                                 float* out2, const float* aux, const float* aux2, int h, int w, int Cout, int epi, void* stream) {
+extern "C" int cer_conv3x3_f16x3(const cer_conv_inputs* in, const void* packed_w, const void* packed_collapsed, const float* bias,
+                                 const float* init, float* out, float* out2, const float* aux, const float* aux2, int h, int w, int Cout, int epi, void* stream) {
     if (!in || !packed_w || !out || h <= 0 || w <= 0 || Cout <= 0) return CER_EINVAL;
     if (in->nsrc <= 0 || in->nsrc > CER_CONV_MAX_SRC) return CER_EINVAL;
     if (epi == CER_EPI_GATES && (!out2 || !aux)) return CER_EINVAL;
@@ -523,8 +632,9 @@ extern "C" int cer_conv3x3_f16x3(const cer_conv_inputs* in, const void* packed_w
         a.kind[s] = in->kind[s];
         a.chpad[s] = hx_padded_channels(in->ch[s], in->kind[s]);
     }
-    if (!cer_aligned16(packed_w)) return CER_EALIGN;
+    if (!cer_aligned16(packed_w) || !cer_aligned16(packed_collapsed)) return CER_EALIGN;
     a.wpk = (const _Float16*)packed_w;
+    a.wpk_c = (const _Float16*)packed_collapsed;
     a.bias = bias;
     a.init = init;
     a.out = out;

@@ -135,11 +135,23 @@ class PackedConv3x3:
         L.check(lib.cer_conv3x3_f16x3_pack(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(packed_x.data_ptr()), Cout, Cin, ch, kind, n),
                 "conv3x3_f16x3_pack")
         self.packed_x = packed_x.to(device)
+        self.packed_c = None                 # collapsed-disparity packing (interior tiles), only with a kind-1 source
+        if any(k == 1 for _, k in sources):
+            size_c = lib.cer_conv3x3_f16x3_collapsed_size(Cout, ch, kind, n)
+            if size_c <= 0:
+                raise RuntimeError(f"conv3x3 collapsed pack: unsupported shape Cout={Cout}")
+            packed_c = torch.empty(size_c, dtype=torch.float16)
+            L.check(lib.cer_conv3x3_f16x3_pack_collapsed(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(packed_c.data_ptr()), Cout, Cin,
+                                                         ch, kind, n), "conv3x3_f16x3_pack_collapsed")
+            self.packed_c = packed_c.to(device)
         self.bias = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
         self.cout = Cout
 
 
 CONV_MODE = "f16x3"      # default arithmetic of ops.conv3x3: "f16x3" (split-f16 MFMA, fp32-equivalent) or "fp32" (exact fp32 MFMA)
+
+
+COLLAPSE_DISP = True     # interior tiles of a conv with a disparity source use the 81-tap collapsed form (cer_mvs.h)
 
 
 def conv3x3(pc, srcs, h, w, epi, out=None, out2=None, aux=None, aux2=None, init=None, use_bias=True, mode=None):
@@ -165,16 +177,17 @@ def conv3x3(pc, srcs, h, w, epi, out=None, out2=None, aux=None, aux2=None, init=
     if epi == L.EPI_GATES and out2 is None:
         out2 = torch.empty(P, oc, device=dev, dtype=torch.float32)
     bias = pc.bias if (use_bias and init is None) else None
+    aux_p = L.dev_ptr(aux, "aux", torch.float16) if epi == L.EPI_DELTA else L.dev_ptr(aux, "aux")
+    tail = (L.dev_ptr(bias, "bias"), L.dev_ptr(init, "init"), L.dev_ptr(out, "out"), L.dev_ptr(out2, "out2"), aux_p,
+            L.dev_ptr(aux2, "aux2"), h, w, pc.cout, epi, L.cur_stream())
     if mode == "f16x3":
-        fn, wts = L.load().cer_conv3x3_f16x3, L.dev_ptr(pc.packed_x, "packed_w", torch.float16)
+        coll = L.dev_ptr(pc.packed_c, "packed_collapsed", torch.float16) if (COLLAPSE_DISP and pc.packed_c is not None) else None
+        rc = L.load().cer_conv3x3_f16x3(ctypes.byref(ci), L.dev_ptr(pc.packed_x, "packed_w", torch.float16), coll, *tail)
     elif mode == "fp32":
-        fn, wts = L.load().cer_conv3x3_f32, L.dev_ptr(pc.packed, "packed_w")
+        rc = L.load().cer_conv3x3_f32(ctypes.byref(ci), L.dev_ptr(pc.packed, "packed_w"), *tail)
     else:
         raise ValueError(f"conv3x3: unknown mode {mode!r}")
-    aux_p = L.dev_ptr(aux, "aux", torch.float16) if epi == L.EPI_DELTA else L.dev_ptr(aux, "aux")
-    L.check(fn(ctypes.byref(ci), wts, L.dev_ptr(bias, "bias"), L.dev_ptr(init, "init"),
-               L.dev_ptr(out, "out"), L.dev_ptr(out2, "out2"), aux_p, L.dev_ptr(aux2, "aux2"),
-               h, w, pc.cout, epi, L.cur_stream()), f"conv3x3[{mode}]")
+    L.check(rc, f"conv3x3[{mode}]")
     return (out, out2) if epi == L.EPI_GATES else out
 
 

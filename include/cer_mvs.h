@@ -168,7 +168,16 @@ int cer_conv3x3_f32(const cer_conv_inputs* in, const float* packed_w, const floa
 long cer_conv3x3_f16x3_packed_size(int Cout, int Kpad);
 int cer_conv3x3_f16x3_pack(const float* w_oihw, void* packed, int Cout, int Cin,
                            const int* ch, const int* kind, int nsrc);
-int cer_conv3x3_f16x3(const cer_conv_inputs* in, const void* packed_w, const float* bias, const float* init,
+/* `packed_collapsed` (may be NULL): a second packing of the same weights in which a kind-1 source is ONE 81-tap
+ * filter on the raw disparity (the 3x3 conv over the 49 unfold features of core/update.py:80-85,97 is linear in
+ * the disparity: W9[s] = sum_{t+u=s} w[u][t] minus the centre terms).  Tiles whose pixels all have their 3x3
+ * neighbourhood inside the image use it (3 MFMA steps instead of 18 for that source); border tiles keep the
+ * literal form.  Built by cer_conv3x3_f16x3_pack_collapsed, size (halves) from cer_conv3x3_f16x3_collapsed_size. */
+long cer_conv3x3_f16x3_collapsed_size(int Cout, const int* ch, const int* kind, int nsrc);
+int cer_conv3x3_f16x3_pack_collapsed(const float* w_oihw, void* packed, int Cout, int Cin,
+                                     const int* ch, const int* kind, int nsrc);
+int cer_conv3x3_f16x3(const cer_conv_inputs* in, const void* packed_w, const void* packed_collapsed,
+                      const float* bias, const float* init,
                       float* out, float* out2, const float* aux, const float* aux2,
                       int h, int w, int Cout, int epi, void* stream);
 

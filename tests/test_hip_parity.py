@@ -241,6 +241,37 @@ def test_conv3x3_disp_encoder_source(dev):
         assert rel_l1(out.cpu(), ref) < 2e-6, mode
 
 
+@pytest.mark.parametrize("h,w,cout", [(20, 140, 128), (13, 101, 64), (24, 96, 64)])
+def test_conv3x3_collapsed_disparity_tiles(dev, h, w, cout):
+    """Interior tiles evaluate the disparity source as one 81-tap filter on the raw disparity (cer_mvs.h,
+    cer_conv3x3_f16x3_pack_collapsed); border tiles keep the literal 49-feature form.  Both must match the literal
+    convolution, including where the 9x9 window leaves the image (unfold zero padding, core/update.py:80-83)."""
+    from cer_mvs_amd import _lib as L, ops
+    from oracle import cer_oracle as O
+    disp = hashed((1, 1, h, w), 211, 0.0005, 0.0025)
+    a = hashed((1, 32, h, w), 212)
+    feat = 100 * O.disp_features(disp)
+    wt = hashed((cout, 32 + 49, 3, 3), 213, -0.1, 0.1)
+    ref = F.conv2d(torch.cat([a, feat], 1).double(), wt.double(), None, padding=1)[0].permute(1, 2, 0).reshape(h * w, cout)
+    pc = ops.PackedConv3x3(wt, None, [(32, 0), (49, 1)], dev)
+    assert pc.packed_c is not None
+    al = a[0].permute(1, 2, 0).reshape(h * w, 32).contiguous().to(dev)
+    outs = {}
+    for flag in (True, False):
+        ops.COLLAPSE_DISP = flag
+        try:
+            outs[flag] = ops.conv3x3(pc, [al, disp.reshape(-1).to(dev)], h, w, L.EPI_LINEAR, mode="f16x3").cpu().double()
+        finally:
+            ops.COLLAPSE_DISP = True
+        assert rel_l1(outs[flag], ref) < 2e-6, flag
+    ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    interior = ((ys // 4 >= 1) & (ys // 4 * 4 + 4 <= h - 1) & (xs // 32 >= 1) & (xs // 32 * 32 + 32 <= w - 1)).reshape(-1)
+    assert interior.any() and not interior.all()
+    assert torch.equal(outs[True][~interior], outs[False][~interior])        # border tiles run the literal form
+    assert not torch.equal(outs[True][interior], outs[False][interior])      # interior tiles really took the other path
+    assert (outs[True] - ref).abs().max() < 5e-6 * ref.abs().max()
+
+
 @pytest.mark.parametrize("mode", ["fp32", "f16x3"])
 @pytest.mark.parametrize("stage", [0, 1])
 def test_update_block_matches_reference_capture(dev, golden, stage, mode):

@@ -8,6 +8,7 @@ import re
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import REPO, rel_l1
 from test_oracle_golden import blank_state_dict, hashed
@@ -54,11 +55,11 @@ def test_argument_errors_of_the_conv_and_encoder_entry_points():
     ci.src[0] = 0x1000
     ci.ch[0] = 48            # not a multiple of 32
     ci.kind[0] = 0
-    assert lib.cer_conv3x3_f16x3(ctypes.byref(ci), fake, null, null, fake, null, null, null, 8, 8, 64, 1, null) == -2
+    assert lib.cer_conv3x3_f16x3(ctypes.byref(ci), fake, null, null, null, fake, null, null, null, 8, 8, 64, 1, null) == -2
     assert lib.cer_conv3x3_f32(ctypes.byref(ci), fake, null, null, fake, null, null, null, 8, 8, 64, 1, null) == -2
     ci.ch[0] = 64
-    assert lib.cer_conv3x3_f16x3(ctypes.byref(ci), fake, null, null, fake, null, null, null, 8, 8, 64, 2, null) == -1   # GATES needs out2 + aux
-    assert lib.cer_conv3x3_f16x3(ctypes.byref(ci), fake, null, null, fake, null, null, null, 8, 8, 96, 1, null) == -2   # Cout % 64
+    assert lib.cer_conv3x3_f16x3(ctypes.byref(ci), fake, null, null, null, fake, null, null, null, 8, 8, 64, 2, null) == -1   # GATES needs out2 + aux
+    assert lib.cer_conv3x3_f16x3(ctypes.byref(ci), fake, null, null, null, fake, null, null, null, 8, 8, 96, 1, null) == -2   # Cout % 64
     assert lib.cer_conv3x3_f16x3_packed_size(64, 192) == 6 * 9 * 2 * 2048
     assert lib.cer_conv3x3_f16x3_packed_size(48, 192) == -2
     assert lib.cer_delta_proj_packed_size(256) == 2 * 8 * 2 * 512 and lib.cer_delta_proj_packed_size(200) == -2
@@ -90,6 +91,39 @@ def test_f16x3_weight_packing_splits_hi_lo():
         hi, lo = float(pk[kc, tap, nt, ks, 0, lane, e]), float(pk[kc, tap, nt, ks, 1, lane, e])
         assert hi == float(torch.tensor(ref).half())
         assert abs(hi + lo / 2048.0 - ref) <= abs(ref) * 2.0 ** -21
+
+
+def test_collapsed_disparity_weights_equal_the_literal_conv():
+    """cer_conv3x3_f16x3_pack_collapsed (host code): for a pixel whose 3x3 neighbours are inside the image,
+    conv3x3(100*(unfold7x7(d) - d)) == sum_s W9[s] * 100*(dz[p+s-4] - d[p]) with the pre-summed 81-tap filter."""
+    from cer_mvs_amd import _lib
+    from oracle import cer_oracle as O
+    lib = _lib.load()
+    cout, cin = 32, 49
+    w = hashed((cout, cin, 3, 3), 23, -0.2, 0.2)
+    ch, kind = (ctypes.c_int * 1)(cin), (ctypes.c_int * 1)(1)
+    size = lib.cer_conv3x3_f16x3_collapsed_size(cout, ch, kind, 1)
+    assert size == 3 * 1 * 2048
+    packed = torch.empty(size, dtype=torch.float16)
+    assert lib.cer_conv3x3_f16x3_pack_collapsed(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(packed.data_ptr()), cout, cin, ch, kind, 1) == 0
+    pk = packed.view(3, 1, 2, 2, 64, 8).double()                       # [step][ntile][k16][hi|lo][lane][8]
+    w9 = torch.zeros(cout, 96, dtype=torch.float64)
+    for kc in range(3):
+        for ks in range(2):
+            for lane in range(64):
+                for e in range(8):
+                    k = kc * 32 + ks * 16 + (lane // 32) * 8 + e
+                    w9[lane % 32, k] = pk[kc, 0, ks, 0, lane, e] + pk[kc, 0, ks, 1, lane, e] / 2048.0
+    assert torch.all(w9[:, 81:] == 0)
+    h, wd = 9, 11
+    d = hashed((1, 1, h, wd), 24, 0.0005, 0.0025)
+    lit = F.conv2d(100 * O.disp_features(d).double(), w.double(), None, padding=1)[0]          # [cout, h, w]
+    dz = F.pad(d[0, 0].double(), (4, 4, 4, 4))
+    for (y, x) in [(1, 1), (4, 5), (h - 2, wd - 2), (1, wd - 2), (3, 1)]:
+        win = 100 * (dz[y:y + 9, x:x + 9] - d[0, 0, y, x].double()).reshape(81)
+        got = w9[:, :81] @ win
+        assert torch.allclose(got, lit[:, y, x], rtol=0, atol=2e-6 * float(lit.abs().max())), (y, x)
+    assert lib.cer_conv3x3_f16x3_collapsed_size(48, ch, kind, 1) == -2
 
 
 def test_product_path_refuses_cpu_tensors():
