@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--workload", default="dtu_1600x1184_v10_it32", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="shard", choices=["shard", "views", "replica"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N>1: nccl (= RCCL over xGMI, the product path) or gloo (validation "
+                         "of the multi-rank code path on a box with fewer GPUs than ranks: ranks share devices)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "amp"])
     ap.add_argument("--encoder", default="hip", choices=["hip", "miopen"], help="encoder backend: channels-last HIP engine or PyTorch-ROCm (MIOpen)")
     ap.add_argument("--gru-precision", default="f16x3", choices=["f16x3", "fp32"],
@@ -180,13 +183,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and args.backend == "nccl":
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({ndev} visible); RCCL needs one GPU per rank")
+    local_dev = local_rank % ndev
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
         group = dist.group.WORLD
 
     from cer_mvs_amd import RAFT
@@ -274,7 +284,8 @@ def main():
                        "gru_iters": sum(c[2] for c in cascade),
                        "parallelism": "single" if world == 1 else (
                            (f"row-slab x{world}: feature all-gather + 7-row halo all-gather per GRU iteration" if args.mode == "shard"
-                            else f"view-shard x{world} + all-reduce/stage") if shard else f"replica x{world}")},
+                            else f"view-shard x{world} + all-reduce/stage") if shard else f"replica x{world}"),
+                       **({"backend": "gloo (validation run, ranks may share a GPU)"} if (world > 1 and args.backend == "gloo") else {})},
             "roofline": roofline, "roofline_hbm_kernel": hbm, "kernels": kern,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,68 @@
+"""Two real processes (torch.distributed, gloo, both on cuda:0) run the product's sharded RAFT.forward - every rank with the
+HIP kernels on device tensors, the exchange through torch.distributed - and must reproduce the reference captures like the
+single-process path.  (The GPU test boxes have one GPU; RCCL refuses two ranks on one device, so the transport here is gloo.
+The collectives the product issues - all_gather / all_reduce on device tensors - are the same calls RCCL serves on a node.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import REPO, rel_l1
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, shard, name, out_path):
+    import sys
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    g = np.load(os.path.join(REPO, "tests", "golden", name + ".npz"))
+    H, W, V = int(g["H"]), int(g["W"]), int(g["V"])
+    cascade = [tuple(int(x) for x in c) for c in g["cascade"]]
+    images, poses, intr, scale = synthetic_scene(H, W, V, seed=int(g["scene_seed"]))
+    model = RAFT(cascade=cascade, test_mode=True, view_group=dist.group.WORLD, shard=shard)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(g["weight_seed"])))
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        out = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale)
+    torch.cuda.synchronize()
+    np.save(f"{out_path}.{rank}.npy", out.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shard,name", [("slab", "e2e_cfg1"), ("views", "e2e_cfg1"), ("slab", "e2e_tiny")])
+def test_two_process_sharded_forward(dev, golden, tmp_path, shard, name):
+    world = 2
+    out_path = str(tmp_path / "disp")
+    mp.spawn(_worker, args=(world, _free_port(), shard, name, out_path), nprocs=world, join=True)
+    ref = torch.from_numpy(golden(name)["disp"])
+    outs = [torch.from_numpy(np.load(f"{out_path}.{r}.npy")) for r in range(world)]
+    assert torch.equal(outs[0], outs[1])                       # every rank returns the full disparity map
+    assert outs[0].shape == ref.shape
+    assert rel_l1(outs[0], ref) < TOL
