@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CER_MVS_LIB") or os.path.join(_HERE, "csrc", "libcermvs.so")
-ABI_VERSION = 1008
+ABI_VERSION = 1009
 CONV_MAX_SRC = 4
 EPI_LINEAR, EPI_RELU, EPI_GATES, EPI_GRU, EPI_DELTA = 0, 1, 2, 3, 4
 
@@ -23,6 +23,13 @@ _D = _c.c_double
 
 class ConvInputs(ctypes.Structure):
     _fields_ = [("src", _P * CONV_MAX_SRC), ("ch", _I * CONV_MAX_SRC), ("kind", _I * CONV_MAX_SRC), ("nsrc", _I)]
+
+
+COPY_MAX_SEG = 4
+
+
+class CopySegments(ctypes.Structure):
+    _fields_ = [("src", _P * COPY_MAX_SEG), ("dst", _P * COPY_MAX_SEG), ("n", _L * COPY_MAX_SEG)]
 
 
 _SIGNATURES = {
@@ -61,6 +68,7 @@ _SIGNATURES = {
     "cer_nchw_to_nhwc_f32": (_I, [_P, _P, _I, _L, _F, _P]),
     "cer_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _L, _F, _P]),
     "cer_nchw_to_nhwc_border_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "cer_copy_segments_f32": (_I, [_c.POINTER(CopySegments), _P]),
 }
 
 _lib = None

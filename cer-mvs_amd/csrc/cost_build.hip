@@ -286,3 +286,46 @@ extern "C" int cer_nchw_to_nhwc_border_f32(const float* src, float* dst, int N, 
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }
+
+// ---- multi-segment copy (row-slab halo pack / refresh): blockIdx.y = segment, grid-stride over the segment
+struct CopySegs {
+    const float* src[CER_COPY_MAX_SEG];
+    float* dst[CER_COPY_MAX_SEG];
+    long n[CER_COPY_MAX_SEG];
+};
+
+__global__ __launch_bounds__(256) void copy_segments_kernel(const CopySegs a) {
+    const int s = blockIdx.y;
+    const float* __restrict__ src = a.src[s];
+    float* __restrict__ dst = a.dst[s];
+    const long n = a.n[s];
+    const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    const long stride = (long)gridDim.x * 256;
+    if (vec) {
+        const long n4 = n >> 2;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+            reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+        for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    }
+}
+
+extern "C" int cer_copy_segments_f32(const cer_copy_segments* seg, void* stream) {
+    if (!seg) return CER_EINVAL;
+    CopySegs a;
+    long nmax = 0;
+    for (int i = 0; i < CER_COPY_MAX_SEG; ++i) {
+        if (seg->n[i] < 0 || (seg->n[i] > 0 && (!seg->src[i] || !seg->dst[i]))) return CER_EINVAL;
+        a.src[i] = seg->src[i];
+        a.dst[i] = seg->dst[i];
+        a.n[i] = seg->n[i];
+        nmax = seg->n[i] > nmax ? seg->n[i] : nmax;
+    }
+    if (nmax == 0) return CER_OK;
+    const long blocks = (nmax / 4 + 255) / 256;
+    dim3 grid((unsigned)(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks)), CER_COPY_MAX_SEG);
+    hipLaunchKernelGGL(copy_segments_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}

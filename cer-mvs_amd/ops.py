@@ -261,3 +261,20 @@ def norm_act(x, x_stats=None, res=None, res_stats=None, relu_a=False, relu_b=Fal
     L.check(L.load().cer_norm_act_f32(L.dev_ptr(x, "x"), L.dev_ptr(x_stats, "x_stats"), L.dev_ptr(res, "res"), L.dev_ptr(res_stats, "res_stats"),
                                       L.dev_ptr(out, "out"), N * C, H * W, flags, L.cur_stream()), "norm_act")
     return out
+
+
+def copy_segments(pairs):
+    """One launch copying up to 4 contiguous fp32 ranges: pairs = [(src, dst), ...] with equal numel per pair
+    (the row-slab halo pack / refresh, slab.py)."""
+    if len(pairs) > L.COPY_MAX_SEG:
+        raise ValueError(f"copy_segments: at most {L.COPY_MAX_SEG} segments")
+    seg = L.CopySegments()
+    for i, (src, dst) in enumerate(pairs):
+        if src.numel() != dst.numel() or not src.is_contiguous() or not dst.is_contiguous():
+            raise ValueError("copy_segments: each pair must be contiguous with equal numel")
+        L.dev_ptr(src, f"src{i}")
+        L.dev_ptr(dst, f"dst{i}")
+        seg.src[i] = src.data_ptr()
+        seg.dst[i] = dst.data_ptr()
+        seg.n[i] = src.numel()
+    L.check(L.load().cer_copy_segments_f32(ctypes.byref(seg), L.cur_stream()), "copy_segments")

@@ -41,6 +41,12 @@ class LocalExchange:
         assert len(tensors) == self.G
         return [list(tensors) for _ in range(self.G)]
 
+    def all_gather_flat(self, tensors):
+        """list of G equal-sized tensors -> per simulated rank the stacked [G, ...] tensor."""
+        assert len(tensors) == self.G
+        allt = torch.stack(list(tensors), 0)
+        return [allt for _ in range(self.G)]
+
 
 class DistExchange:
     """One rank per process on a torch.distributed group (backend nccl = RCCL over xGMI on the GPU box, gloo in CPU tests)."""
@@ -58,6 +64,20 @@ class DistExchange:
         dist.all_gather(out, t, group=self.group)
         return [out]
 
+    def all_gather_flat(self, tensors):
+        """One collective into one preallocated [G, ...] buffer (no per-rank output tensors, no copies after it)."""
+        import torch.distributed as dist
+        t = tensors[0]
+        key = (tuple(t.shape), t.device, t.dtype)
+        if getattr(self, "_flat_key", None) != key:
+            self._flat_key, self._flat = key, torch.empty((self.G,) + tuple(t.shape), device=t.device, dtype=t.dtype)
+        out = self._flat
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(out, t, group=self.group)
+        else:
+            dist.all_gather(list(out.unbind(0)), t, group=self.group)
+        return [out]
+
 
 def border_strips(x, w, r0, r1, e0, halo=HALO):
     """x [rows_ext*w, C] -> [2, halo*w, C]: the first and last ``halo`` OWNED rows (what the neighbours need)."""
@@ -73,6 +93,36 @@ def refresh_halo(x, strips, w, g, G, r0, r1, e0, e1, halo=HALO):
     if g < G - 1 and e1 > r1:      # rows [r1, e1) = the first `halo` owned rows of rank g+1
         x[(r1 - e0) * w:] = strips[g + 1][0][:(e1 - r1) * w]
     return x
+
+
+def _device_copy(pairs):
+    from . import ops
+    ops.copy_segments(pairs)
+
+
+def pack_strips(net, disp, buf, w, r0, r1, e0, halo=HALO, copy=_device_copy):
+    """The first / last ``halo`` OWNED rows of net [rows_ext*w, C] and disp [rows_ext*w] -> buf (flat:
+    net top | net bottom | disp top | disp bottom).  All four ranges are contiguous: one cer_copy_segments_f32 launch."""
+    C = net.shape[1]
+    n, t0, b0 = halo * w, (r0 - e0) * w, (r1 - halo - e0) * w
+    copy([(net[t0:t0 + n], buf[:n * C]), (net[b0:b0 + n], buf[n * C:2 * n * C]),
+          (disp[t0:t0 + n], buf[2 * n * C:2 * n * C + n]), (disp[b0:b0 + n], buf[2 * n * C + n:])])
+
+
+def unpack_halo(net, disp, allbuf, w, g, G, r0, r1, e0, e1, halo=HALO, copy=_device_copy):
+    """Refresh the halo rows of (net, disp) from the gathered strips allbuf [G, 2*halo*w*(C+1)] (layout of pack_strips),
+    one launch; same row bookkeeping as refresh_halo."""
+    C = net.shape[1]
+    n = halo * w
+    pairs = []
+    if g > 0 and r0 > e0:          # rows [e0, r0) = the last (r0-e0) rows of rank g-1's bottom strip
+        k, src = (r0 - e0) * w, allbuf[g - 1]
+        pairs += [(src[n * C + (n - k) * C:2 * n * C], net[:k]), (src[2 * n * C + n + (n - k):], disp[:k])]
+    if g < G - 1 and e1 > r1:      # rows [r1, e1) = the first (e1-r1) rows of rank g+1's top strip
+        k, src, o = (e1 - r1) * w, allbuf[g + 1], (r1 - e0) * w
+        pairs += [(src[:k * C], net[o:o + k]), (src[2 * n * C:2 * n * C + k], disp[o:o + k])]
+    if pairs:
+        copy(pairs)
 
 
 def sharded_forward(model, images, poses, intrinsics, scale, ex):
@@ -130,6 +180,7 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
         d["disp"] = torch.zeros((e1 - e0) * w, device=dev, dtype=torch.float32)
         d["hoist"] = ub.hoist(d["inp"], e1 - e0, w)
         d["ws"] = ub.workspace((e1 - e0) * w, dev)
+        d["strips"] = torch.empty(2 * HALO * w * (d["net"].shape[1] + 1), device=dev, dtype=torch.float32)
 
     for stage, (D, incre, T) in enumerate(model.stages()):
         for g in ex.ranks:
@@ -143,14 +194,13 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
             for g in ex.ranks:
                 d = st[g]
                 ub.step(d["vol"], d["origin"], d["net"], d["disp"], d["hoist"], stage, d["hs"], w, D, incre, d["ws"])
-                # only the 2 x HALO border rows travel: [2, HALO*w, 64 + 1] per rank
-                send.append(torch.cat([border_strips(d["net"], w, d["r0"], d["r1"], d["e0"]),
-                                       border_strips(d["disp"][:, None], w, d["r0"], d["r1"], d["e0"])], 2))
-            gathered = ex.all_gather(send)
+                # only the 2 x HALO border rows of (net, disp) travel: one pack launch, one collective, one refresh launch
+                pack_strips(d["net"], d["disp"], d["strips"], w, d["r0"], d["r1"], d["e0"])
+                send.append(d["strips"])
+            gathered = ex.all_gather_flat(send)
             for i, g in enumerate(ex.ranks):
                 d = st[g]
-                refresh_halo(d["net"], [t[..., :64] for t in gathered[i]], w, g, G, d["r0"], d["r1"], d["e0"], d["e1"])
-                refresh_halo(d["disp"], [t[..., 64] for t in gathered[i]], w, g, G, d["r0"], d["r1"], d["e0"], d["e1"])
+                unpack_halo(d["net"], d["disp"], gathered[i], w, g, G, d["r0"], d["r1"], d["e0"], d["e1"])
 
     # ---- gather the owned rows of every rank
     rows_max = (h + G - 1) // G

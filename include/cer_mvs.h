@@ -251,6 +251,17 @@ int cer_nhwc_to_nchw_f32(const float* src, float* dst, int C, long P, float scal
  * layout of cer_cost_build_f32 with b = 2; reference: core/corr.py:29-35 permute, /8.0, contiguous). */
 int cer_nchw_to_nhwc_border_f32(const float* src, float* dst, int N, int C, int h, int w, int border, float scale, void* stream);
 
+/* Multi-GPU row-slab exchange (cer-mvs_amd/slab.py): up to CER_COPY_MAX_SEG contiguous fp32 ranges copied by ONE launch -
+ * the pack of a rank's (net, disp) border strips into its send buffer, and the refresh of its halo rows from the gathered
+ * strips.  n[i] floats from src[i] to dst[i]; n[i] == 0 skips a segment.  Device pointers; ranges must not overlap. */
+#define CER_COPY_MAX_SEG 4
+typedef struct cer_copy_segments {
+    const float* src[CER_COPY_MAX_SEG];
+    float* dst[CER_COPY_MAX_SEG];
+    long n[CER_COPY_MAX_SEG];
+} cer_copy_segments;
+int cer_copy_segments_f32(const cer_copy_segments* seg, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,13 @@ def _fake_step(x, rows, w):
     return y[0].permute(1, 2, 0).reshape(rows * w, -1).contiguous()
 
 
+def _torch_copy(pairs):
+    """CPU stand-in for ops.copy_segments (cer_copy_segments_f32): same (src, dst) contiguous-range contract."""
+    for src, dst in pairs:
+        assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
+        dst.view(-1).copy_(src.reshape(-1))
+
+
 def _slab_worker(rank, world, port, ret):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -117,13 +124,26 @@ def _slab_worker(rank, world, port, ret):
     r0, r1, e0, e1 = slab.slab_bounds(h, world, rank)
     x = full[e0 * w:e1 * w].clone()
     ref = full.clone()
+    fulld = hashed((h * w,), 79)
+    xd, refd = fulld[e0 * w:e1 * w].clone(), fulld.clone()
+    buf = torch.empty(2 * slab.HALO * w * (C + 1))
     for _ in range(3):
         x = _fake_step(x, e1 - e0, w)
         ref = _fake_step(ref, h, w)
-        strips = ex.all_gather([slab.border_strips(x, w, r0, r1, e0)])[0]
-        slab.refresh_halo(x, strips, w, rank, world, r0, r1, e0, e1)
+        xd = _fake_step(xd[:, None], e1 - e0, w)[:, 0].contiguous()
+        refd = _fake_step(refd[:, None], h, w)[:, 0].contiguous()
+        # the product's per-iteration exchange: pack -> one flat all-gather -> refresh (slab.sharded_forward)
+        slab.pack_strips(x, xd, buf, w, r0, r1, e0, copy=_torch_copy)
+        allbuf = ex.all_gather_flat([buf])[0]
+        slab.unpack_halo(x, xd, allbuf, w, rank, world, r0, r1, e0, e1, copy=_torch_copy)
+        # and the list form (features / final gather use it)
+        y = x.clone()
+        strips = ex.all_gather([slab.border_strips(y, w, r0, r1, e0)])[0]
+        slab.refresh_halo(y, strips, w, rank, world, r0, r1, e0, e1)
+        assert torch.equal(x, y)
     own = x[(r0 - e0) * w:(r1 - e0) * w]
-    ret[rank] = (float((own - ref[r0 * w:r1 * w]).abs().max()), float((x - ref[e0 * w:e1 * w]).abs().max()))
+    ret[rank] = (float((own - ref[r0 * w:r1 * w]).abs().max()),
+                 max(float((x - ref[e0 * w:e1 * w]).abs().max()), float((xd - refd[e0 * w:e1 * w]).abs().max())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -163,7 +183,17 @@ def test_local_exchange_simulation_matches_full_image():
         xs = [_fake_step(x, e1 - e0, w) for x, (_, _, e0, e1) in zip(xs, b)]
         ref = _fake_step(ref, h, w)
         got = ex.all_gather([slab.border_strips(x, w, r0, r1, e0) for x, (r0, r1, e0, e1) in zip(xs, b)])
+        ys = [x.clone() for x in xs]
         for g in range(G):
             slab.refresh_halo(xs[g], got[g], w, g, G, *b[g])
+        # flat pack / gather / refresh path on the same data (disp = channel 0 as a separate tensor)
+        ds = [y[:, 0].contiguous() for y in ys]
+        bufs = [torch.empty(2 * slab.HALO * w * (C + 1)) for _ in range(G)]
+        for g, (r0, r1, e0, e1) in enumerate(b):
+            slab.pack_strips(ys[g], ds[g], bufs[g], w, r0, r1, e0, copy=_torch_copy)
+        flat = ex.all_gather_flat(bufs)
+        for g in range(G):
+            slab.unpack_halo(ys[g], ds[g], flat[g], w, g, G, *b[g], copy=_torch_copy)
+            assert torch.equal(ys[g], xs[g]) and torch.equal(ds[g], xs[g][:, 0])
     for g, (r0, r1, e0, e1) in enumerate(b):
         assert float((xs[g] - ref[e0 * w:e1 * w]).abs().max()) < 1e-6

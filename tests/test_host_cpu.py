@@ -71,6 +71,12 @@ def test_argument_errors_of_the_conv_and_encoder_entry_points():
     assert lib.cer_enc_stem_tiles(592, 800) == 1850
     assert lib.cer_enc_merge_f32(fake, null, null, null, fake, 1, 10, 30, 0, null) == -2                      # C % 4
     assert lib.cer_delta_sum_f32(null, 2, 0.0, fake, fake, null, 4, 4, null) == -1
+    from cer_mvs_amd._lib import CopySegments
+    seg = CopySegments()
+    assert lib.cer_copy_segments_f32(None, null) == -1
+    assert lib.cer_copy_segments_f32(ctypes.byref(seg), null) == 0          # all segments empty: nothing launched
+    seg.n[1] = 16                                                          # non-empty segment without pointers
+    assert lib.cer_copy_segments_f32(ctypes.byref(seg), null) == -1
 
 
 def test_f16x3_weight_packing_splits_hi_lo():
