@@ -65,10 +65,12 @@ def parse():
 def kernel_timing(model, inputs, scale):
     """One extra, instrumented forward: HIP events (on the launch stream = torch's current stream) around every
     kernel class of the inner loop.  Returns {name: (launches, total_ms)}."""
-    from cer_mvs_amd import ops
+    from cer_mvs_amd import ops, update
     records = {}
     pending = []
     originals = {}
+    plans = update.USE_PLANS
+    update.USE_PLANS = False             # every iteration through the (wrapped) ops, so that each launch gets its events
 
     def wrap(name, fn, label=None):
         def inner(*a, **k):
@@ -94,6 +96,7 @@ def kernel_timing(model, inputs, scale):
             model(*inputs, scale=scale)
         torch.cuda.synchronize()
     finally:
+        update.USE_PLANS = plans
         for name, fn in originals.items():
             setattr(ops, name, fn)
     for key, e0, e1 in pending:

@@ -130,9 +130,11 @@ class RAFT(nn.Module):
         # ---- view sharding: this rank encodes and builds the partial view-sum over its own source views only
         V = num - 1
         views = cdist.local_views(V, self.view_group)
+        # (uploaded BEFORE the encoders are enqueued: a pageable H2D copy is stream-ordered and would block the host
+        # until everything enqueued so far has finished)
+        Pij = pij_matrices(poses[0], intrinsics[0], [0] * len(views), views).to(dev) if views else None
         net_l, inp_l, f1, f2 = self.encode(images, views)
         del images
-        Pij = pij_matrices(poses[0], intrinsics[0], [0] * len(views), views).to(dev) if views else None
 
         disp = torch.zeros(P, device=dev, dtype=torch.float32)
         hoisted = ub.hoist(inp_l, h, w)
@@ -148,8 +150,7 @@ class RAFT(nn.Module):
             ops.pyramid(vol, D, ub.num_levels, scale=1.0 / V)
             if do_report and stage > 0:
                 report()
-            for _ in range(T):
-                ub.step(vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws)
+            ub.run(T, vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws)
         return disp.view(1, 1, h, w) * s
 
     def _forward_literal(self, images, poses, intrinsics, scale, do_report):

@@ -44,8 +44,12 @@ class LocalExchange:
     def all_gather_flat(self, tensors):
         """list of G equal-sized tensors -> per simulated rank the stacked [G, ...] tensor."""
         assert len(tensors) == self.G
-        allt = torch.stack(list(tensors), 0)
-        return [allt for _ in range(self.G)]
+        t = tensors[0]
+        key = (tuple(t.shape), t.device, t.dtype)
+        if getattr(self, "_flat_key", None) != key:      # persistent, like DistExchange: recorded launches point into it
+            self._flat_key, self._flat = key, torch.empty((self.G,) + tuple(t.shape), device=t.device, dtype=t.dtype)
+        torch.stack(list(tensors), 0, out=self._flat)
+        return [self._flat for _ in range(self.G)]
 
 
 class DistExchange:
@@ -128,7 +132,7 @@ def unpack_halo(net, disp, allbuf, w, g, G, r0, r1, e0, e1, halo=HALO, copy=_dev
 def sharded_forward(model, images, poses, intrinsics, scale, ex):
     """Test-mode RAFT.forward sharded over ``ex.G`` ranks; ``ex.ranks`` are the ranks simulated by this process.
     Returns the full-resolution disparity [1,1,h,w] * scale (identical on every rank)."""
-    from . import ops
+    from . import _lib as L, ops, update
     from .dist import local_views_for
     from .projective import pij_matrices
     dev = images.device
@@ -147,6 +151,9 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
     C = model.dim_fmap
     vmax = (V + G - 1) // G
     Pb = (h + 4) * (w + 4)
+
+    # (uploaded before anything is enqueued: a pageable H2D copy blocks the host until the stream has drained)
+    Pij = pij_matrices(poses[0], intr[0], [0] * V, list(range(1, V + 1))).to(dev)
 
     # ---- encoders: every rank the reference + context, each rank its own source views; all-gather the source maps
     st = {}
@@ -167,7 +174,6 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
             for j, v in enumerate(vr):
                 f2_all[v - 1] = gathered[i][r][j]
         st[g]["f2"] = f2_all
-    Pij = pij_matrices(poses[0], intr[0], [0] * V, list(range(1, V + 1))).to(dev)
 
     # ---- slabs
     for g in ex.ranks:
@@ -189,18 +195,30 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
                                          fold=True, src_hw=(h, w), y0=d["e0"])
             ops.pyramid(vol, D, ub.num_levels, scale=1.0 / V)
             d["vol"], d["origin"] = vol, origin
-        for _ in range(T):
+        ub.packed(stage, dev)                  # host-side weight packing stays out of the recorded plans
+        for it in range(T):
+            record = it == 0 or not update.USE_PLANS
             send = []
             for g in ex.ranks:
                 d = st[g]
-                ub.step(d["vol"], d["origin"], d["net"], d["disp"], d["hoist"], stage, d["hs"], w, D, incre, d["ws"])
-                # only the 2 x HALO border rows of (net, disp) travel: one pack launch, one collective, one refresh launch
-                pack_strips(d["net"], d["disp"], d["strips"], w, d["r0"], d["r1"], d["e0"])
+                if record:
+                    # iteration + pack of the 2 x HALO border rows of (net, disp): recorded once per stage, then replayed
+                    d["plan_step"] = L.LaunchPlan(keep=(d["vol"], d["origin"]))
+                    with L.recording(d["plan_step"]):
+                        ub.step(d["vol"], d["origin"], d["net"], d["disp"], d["hoist"], stage, d["hs"], w, D, incre, d["ws"])
+                        pack_strips(d["net"], d["disp"], d["strips"], w, d["r0"], d["r1"], d["e0"])
+                else:
+                    d["plan_step"].replay()
                 send.append(d["strips"])
-            gathered = ex.all_gather_flat(send)
+            gathered = ex.all_gather_flat(send)   # one collective per iteration
             for i, g in enumerate(ex.ranks):
                 d = st[g]
-                unpack_halo(d["net"], d["disp"], gathered[i], w, g, G, d["r0"], d["r1"], d["e0"], d["e1"])
+                if record:
+                    d["plan_halo"] = L.LaunchPlan(keep=(gathered[i],))
+                    with L.recording(d["plan_halo"]):
+                        unpack_halo(d["net"], d["disp"], gathered[i], w, g, G, d["r0"], d["r1"], d["e0"], d["e1"])
+                else:
+                    d["plan_halo"].replay()
 
     # ---- gather the owned rows of every rank
     rows_max = (h + G - 1) // G

@@ -18,6 +18,9 @@ from . import _lib as L
 from . import ops
 
 
+USE_PLANS = True         # replay recorded launches for GRU iterations 2..T (False: every iteration through the checked wrappers)
+
+
 class ConvGRU(nn.Module):
     """Parameter container + literal forward (reference: core/update.py:9-25)."""
 
@@ -174,6 +177,24 @@ class UpdateBlock(nn.Module):
         else:
             ops.conv3x3(p["d1"], [net_l], h, w, L.EPI_RELU, mode=self.conv_mode, out=ws["hid"])
             ops.delta_tail(ws["hid"], p["d2w"], p["d2b"], disp, h, w, disp_out=disp, want_delta=False)
+
+    def run(self, iters, vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws, after=None):
+        """``iters`` GRU iterations on fixed buffers: the first executes through the checked wrappers while its raw launches
+        are recorded (``_lib.LaunchPlan``), the rest replay them.  ``after(i)``: called after every iteration (the slab
+        exchange of the sharded forward)."""
+        plan = None
+        self.packed(stage, net_l.device)        # weight packing (host work) must not end up in the recorded plan
+        for i in range(iters):
+            if not USE_PLANS:
+                self.step(vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws)
+            elif plan is None:
+                plan = L.LaunchPlan(keep=(vol, origin, net_l, disp, hoisted, ws))
+                with L.recording(plan):
+                    self.step(vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws)
+            else:
+                plan.replay()
+            if after is not None:
+                after(i)
 
     @staticmethod
     def workspace(P, device):
