@@ -41,6 +41,18 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define HX_EPI_DELTA 4                 // conv + ReLU + projection onto the 9 taps of the 256->1 delta conv (cer_mvs.h: CER_EPI_DELTA)
 #define HX_HS 272                      // LDS bytes per pixel row of the hidden tile (128 f16 + 16 pad: conflict-free b128 reads)
 
+// HX_TRACE (debug builds only, tools/trace_conv.py): per (block, wave, step) cycle stamps written to `aux2`, which the traced
+// epilogue (GATES) does not use: [0] loop top, [1] after the barrier, [2] after the first k16-step, [3] end of the step; slot
+// 63 of each wave holds (kernel entry, main loop start, main loop end, kernel end) and slot 62 the HW_ID register.
+#ifndef HX_TRACE
+#define HX_TRACE 0
+#endif
+#if HX_TRACE
+#define HX_STAMP(k) do { if (HX_TRACE) trace_v[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define HX_STAMP(k) do { } while (0)
+#endif
+
 struct ConvArgsX {
     const float* src[CER_CONV_MAX_SRC];
     int ch[CER_CONV_MAX_SRC];
@@ -200,6 +212,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
     const int li = lane & 31, kg = lane >> 5;
     const int NT = a.cout / 32;
 
+#if HX_TRACE
+    unsigned long long trace_v[4];
+    unsigned long long* trace_base = (unsigned long long*)a.aux2 + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * NWAVES + wave) * 64 * 4;
+    const unsigned long long trace_t0 = __builtin_readcyclecounter();
+#endif
     // ---- pipeline prologue: the weight DMA ring runs NBUF-1 steps ahead of the multiply, across chunk boundaries
     // tiles whose pixels all have their 3x3 neighbourhood inside the image take the collapsed disparity chunks
     const bool coll = a.wpk_c && ty0 >= 1 && ty0 + HX_TH <= a.h - 1 && tx0 >= 1 && tx0 + HX_TW <= a.w - 1;
@@ -275,7 +292,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
             }
     };
     // (64-channel blocks only: with 128 channels per block the extra live fragment set does not fit 128 VGPRs.)
-    constexpr bool SKEW = (WM * WN == 1);
+    constexpr bool SKEW = (WM * WN == 1) || (MINW <= 2);   // needs a second fragment set in registers
     // The MFMA stream is skewed by half a tap against the LDS reads: the second k16-step of tap t-1 (already in registers)
     // is multiplied right after barrier(t) while the first operands of tap t travel from LDS, so the matrix pipe has work
     // during the post-barrier LDS latency.  `pend` starts as zeros (a harmless first multiply) and is drained at the end.
@@ -291,6 +308,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
 #pragma unroll
         for (int e = 0; e < 8; ++e) { pend.bh[n][e] = (_Float16)0; pend.bl[n][e] = (_Float16)0; }
 
+#if HX_TRACE
+    const unsigned long long trace_t1 = __builtin_readcyclecounter();
+#endif
     int step = 0;                                          // chunk * 9 + tap; ring slot = step % NBUF
     for (int s = 0; s < a.nsrc; ++s) {
         const bool c9 = coll && a.kind[s] == 1;
@@ -307,11 +327,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
                 const int tap = c9 ? 4 : t;
                 // B[step] was DMA'd NBUF-1 steps ago.  VMEM ops retire in order, so leaving the DMAs of the NBUF-2 younger
                 // steps in flight still guarantees B[step].  (Builtin waits: hipcc's own scoreboard must see them.)
+                HX_STAMP(0);
                 const int younger = min(NBUF - 2, nsteps - 1 - step);
                 if (NBUF >= 3 && younger >= 1) __builtin_amdgcn_s_waitcnt(0x0F70 | DMA_PER_WAVE);
                 else __builtin_amdgcn_s_waitcnt(0x0F70);
                 __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): this wave's LDS writes (A tile) are done
                 if (!(HX_ABL & 2)) __builtin_amdgcn_s_barrier();   // all shares of B[step] + A visible; slot of B[step-1] free
+                HX_STAMP(1);
                 if (step + NBUF - 1 < nsteps && !(HX_ABL & 16))
                     hx_issue_B<NB, NWAVES>(ldsB + ((step + NBUF - 1) % NBUF) * B_BYTES, wbase + (long)(step + NBUF - 1) * NT * 2048);
                 const char* B = ldsB + (step % NBUF) * B_BYTES;
@@ -355,12 +377,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
                                     accl[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], accl[m][n], 0, 0, 0);
                                 }
                             }
+                        if (ks == 0) HX_STAMP(2);
                     }
                 }
+#if HX_TRACE
+                trace_v[3] = __builtin_readcyclecounter();
+                if (lane == 0 && step < 62)
+                    for (int k = 0; k < 4; ++k) trace_base[step * 4 + k] = trace_v[k];
+#endif
             }
         }
     }
     if constexpr (SKEW) mma(pend);
+#if HX_TRACE
+    const unsigned long long trace_t2 = __builtin_readcyclecounter();
+#endif
 
     // ---- epilogue: lane holds channel co, pixels x = tx0 + (r&3) + 8*(r>>2) + 4*kg of row gy
     const int half = a.cout / 2;
@@ -455,6 +486,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
             }
         }
     }
+#if HX_TRACE
+    if (EPI == CER_EPI_GATES && lane == 0) {
+        trace_base[63 * 4 + 0] = trace_t0;
+        trace_base[63 * 4 + 1] = trace_t1;
+        trace_base[63 * 4 + 2] = trace_t2;
+        trace_base[63 * 4 + 3] = __builtin_readcyclecounter();
+        trace_base[62 * 4 + 0] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
+        trace_base[62 * 4 + 1] = (unsigned long long)nsteps;
+        trace_base[62 * 4 + 2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------- host side
@@ -648,6 +690,13 @@ extern "C" int cer_conv3x3_f16x3(const cer_conv_inputs* in, const void* packed_w
     hipStream_t st = (hipStream_t)stream;
     // 128 output channels per block: 8 waves (4 x 2) of 32 px x 64 ch, 3-slot weight ring, 2 blocks (16 waves) per CU;
     //  64 output channels per block: 8 waves (4 x 2) of 32 px x 32 ch, 3-slot ring, 2 blocks (16 waves) per CU.
+#if defined(HX_CFG) && HX_CFG == 1      // experiment: 4-wave blocks, 64 px x 64 ch per wave, 256 registers, 2 blocks/CU
+    if (Cout % 128 == 0 && epi != HX_EPI_DELTA) return hx_launch<2, 2, 2, 2, 3, 2>(a, epi, Cout / 128, st);
+#elif defined(HX_CFG) && HX_CFG == 2    // experiment: 4-wave blocks, 128 px x 32 ch per wave
+    if (Cout % 128 == 0 && epi != HX_EPI_DELTA) return hx_launch<1, 4, 4, 1, 3, 2>(a, epi, Cout / 128, st);
+#elif defined(HX_CFG) && HX_CFG == 3    // experiment: 4-wave blocks, 32 px x 128 ch per wave
+    if (Cout % 128 == 0 && epi != HX_EPI_DELTA) return hx_launch<4, 1, 1, 4, 3, 2>(a, epi, Cout / 128, st);
+#endif
     if (Cout % 128 == 0) return hx_launch<4, 2, 1, 2, 3, 4>(a, epi, Cout / 128, st);
     return hx_launch<4, 2, 1, 1, 3, 4>(a, epi, Cout / 64, st);
 }
