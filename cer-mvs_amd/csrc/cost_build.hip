@@ -21,7 +21,9 @@
 //     wave writes its pixel's row with one coalesced 256-B store.
 #include "common.hpp"
 
-template <int NQ, bool SUM>
+// NACC: accumulator registers per lane (hypotheses per 64-block that can be live): 48 for D <= 48 (stage 1: D = 44) keeps the
+// kernel under 128 VGPRs = 4 waves per SIMD instead of 3; the walk is latency-bound, so the extra wave is throughput.
+template <int NQ, bool SUM, int NACC>
 __global__ __launch_bounds__(256) void cost_build_kernel(const float* __restrict__ fmap1, const float* __restrict__ fmap2,
                                                          const float* __restrict__ Pij, const float* __restrict__ disp_in,
                                                          float* __restrict__ vol, float* __restrict__ origin_out, int V, int h1, int w1,
@@ -50,15 +52,16 @@ __global__ __launch_bounds__(256) void cost_build_kernel(const float* __restrict
     const int wp = w2 + 4;
     const long P2C = (long)(h2 + 4) * wp * C;
     const int loff = (cy * wp + cx) * C + 4 * sub;         // this lane's corner + channel quad
-    // bilinear weight of this lane's corner: wy = cy ? dw : 1 - dw (as one exact fma), same for x
-    const float sy = cy ? 1.0f : -1.0f, by = cy ? 0.0f : 1.0f, sx = cx ? 1.0f : -1.0f, bx = cx ? 0.0f : 1.0f;
+    __shared__ __attribute__((aligned(16))) float wl_all[4][4 * 64];     // per wave: [corner][hypothesis] bilinear weights
+    float* wl = wl_all[threadIdx.x >> 6];
+    const int corner = cy * 2 + cx;
     const int v_lo = SUM ? 0 : (int)blockIdx.y, v_hi = SUM ? V : (int)blockIdx.y + 1;
     float* orow = SUM ? vol + p * rs : vol + ((long)blockIdx.y * P + p) * rs;
 
     for (int kb = 0; kb < D; kb += 64) {
-        float acc[64];
+        float acc[NACC];
 #pragma unroll
-        for (int j = 0; j < 64; ++j) acc[j] = 0.f;
+        for (int j = 0; j < NACC; ++j) acc[j] = 0.f;
         const int nk = min(64, D - kb);
         for (int v = v_lo; v < v_hi; ++v) {
             const float* m = Pij + v * 16;
@@ -76,22 +79,34 @@ __global__ __launch_bounds__(256) void cost_build_kernel(const float* __restrict
             const float du = ok ? u - fu : 0.f, dw = ok ? w - fw : 0.f;
             const int iu = ok ? min(max((int)fu, -2), w2) : -2, iw = ok ? min(max((int)fw, -2), h2) : -2;
             const int off = ((iw + 2) * wp + (iu + 2)) * C;    // element offset of the cell's top-left texel
+            // bilinear corner weights of hypothesis `lane`, transposed through LDS: afterwards every lane reads the weights of
+            // ITS corner for 8 consecutive samples with two 16-B loads (broadcast within the 16-lane row), so that a sample
+            // costs one v_readlane (cell offset) + one fma instead of rebuilding its weight on every lane.
+            {
+                const float wy1 = dw, wy0 = 1.0f - dw, wx1 = du, wx0 = 1.0f - du;
+                __builtin_amdgcn_s_waitcnt(0xC07F);        // the previous view's weight reads of this wave are done
+                wl[0 * 64 + lane] = wy0 * wx0;
+                wl[1 * 64 + lane] = wy0 * wx1;
+                wl[2 * 64 + lane] = wy1 * wx0;
+                wl[3 * 64 + lane] = wy1 * wx1;
+                __builtin_amdgcn_s_waitcnt(0xC07F);        // wave-local exchange: LDS ops of a wave complete in order
+            }
             int coff = -1;                                 // cell of the previous sample (offsets are >= 0)
             float sdot = 0.f;
             // samples are walked in groups of 8: first all (needed) texel loads of the group are issued,
             // then consumed - 8 loads in flight per wave instead of one dependent load per sample
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
+            for (int g = 0; g < NACC / 8; ++g) {
                 if (g * 8 < nk) {                          // wave-uniform
                     int soff[8];
-                    float sdu[8], sdw[8];
                     bool need[8];
                     float4 t[8][NQ];
+                    const float4 wa = *reinterpret_cast<const float4*>(wl + corner * 64 + g * 8);
+                    const float4 wb = *reinterpret_cast<const float4*>(wl + corner * 64 + g * 8 + 4);
+                    const float wgt[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         soff[i] = __builtin_amdgcn_readlane(off, g * 8 + i);
-                        sdu[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(du), g * 8 + i));
-                        sdw[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dw), g * 8 + i));
                         need[i] = soff[i] != (i ? soff[i - 1] : coff);      // scalar: new texel cell?
                     }
                     coff = soff[7];
@@ -109,8 +124,7 @@ __global__ __launch_bounds__(256) void cost_build_kernel(const float* __restrict
 #pragma unroll
                             for (int q = 0; q < NQ; ++q) sdot = cer_dot4(f1q[q], t[i][q], sdot);
                         }
-                        const float wy = fmaf(sy, sdw[i], by), wx = fmaf(sx, sdu[i], bx);
-                        acc[g * 8 + i] = fmaf(sdot * wy, wx, acc[g * 8 + i]);
+                        acc[g * 8 + i] = fmaf(sdot, wgt[i], acc[g * 8 + i]);
                     }
                 }
             }
@@ -121,8 +135,10 @@ __global__ __launch_bounds__(256) void cost_build_kernel(const float* __restrict
             const bool up = (lane & hb) != 0;
 #pragma unroll
             for (int i = 0; i < hb; ++i) {
-                const float send = up ? acc[i] : acc[i + hb];
-                const float keep = up ? acc[i + hb] : acc[i];
+                if (i >= NACC) continue;                   // (compile time) hypotheses beyond NACC do not exist
+                const float hi = (i + hb < NACC) ? acc[i + hb] : 0.f;
+                const float send = up ? acc[i] : hi;
+                const float keep = up ? hi : acc[i];
                 acc[i] = keep + __shfl_xor(send, hb);
             }
         }
@@ -141,11 +157,14 @@ static int launch_build(const float* f1, const float* f2, const float* Pij, cons
     const float incre = (float)incre_d;
     const unsigned gx = (unsigned)((P + 3) / 4);
     if (mode == 0)
-        hipLaunchKernelGGL((cost_build_kernel<NQ, false>), dim3(gx, (unsigned)V), dim3(256), 0, st, f1, f2, Pij, disp_in, vol, origin_out, V,
+        hipLaunchKernelGGL((cost_build_kernel<NQ, false, 64>), dim3(gx, (unsigned)V), dim3(256), 0, st, f1, f2, Pij, disp_in, vol, origin_out, V,
                            h1, w1, h2, w2, C, D, rs, incre, lim, shift, 0, y0);
+    else if (D <= 48)
+        hipLaunchKernelGGL((cost_build_kernel<NQ, true, 48>), dim3(gx, 1), dim3(256), 0, st, f1, f2, Pij, disp_in, vol, origin_out, V, h1, w1,
+                           h2, w2, C, D, rs, incre, lim, shift, mode == 2 ? 1 : 0, y0);
     else
-        hipLaunchKernelGGL((cost_build_kernel<NQ, true>), dim3(gx, 1), dim3(256), 0, st, f1, f2, Pij, disp_in, vol, origin_out, V, h1, w1, h2,
-                           w2, C, D, rs, incre, lim, shift, mode == 2 ? 1 : 0, y0);
+        hipLaunchKernelGGL((cost_build_kernel<NQ, true, 64>), dim3(gx, 1), dim3(256), 0, st, f1, f2, Pij, disp_in, vol, origin_out, V, h1, w1,
+                           h2, w2, C, D, rs, incre, lim, shift, mode == 2 ? 1 : 0, y0);
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }
