@@ -62,9 +62,12 @@ class CorrBlock:
         f2 = fmaps_to_nhwc(fmaps[0, jj_l], border=2)
         Pij = pij_matrices(poses[0], intrinsics[0], ii_l, jj_l).to(fmaps.device)
         disp_in = disps_input.reshape(-1).float().contiguous()
-        vol, origin = ops.cost_build(f1, f2, Pij, disp_in, nIncre, incre, shift, h1, w1, num_levels, fold=fold_views)
         total_views = self.num_views if view_weight is None else view_weight
-        ops.pyramid(vol, nIncre, num_levels, scale=(1.0 / total_views) if fold_views else 1.0)
+        fuse = fold_views and nIncre <= 64          # view-mean fold: scale + pooled levels written by the build's epilogue
+        vol, origin = ops.cost_build(f1, f2, Pij, disp_in, nIncre, incre, shift, h1, w1, num_levels, fold=fold_views,
+                                     pyramid_scale=(1.0 / total_views) if fuse else None)
+        if not fuse:
+            ops.pyramid(vol, nIncre, num_levels, scale=(1.0 / total_views) if fold_views else 1.0)
         self.volume = vol                                           # [V,P,rs] or [P,rs]
         self.origin = origin                                        # [P]
         self.disps_origin = origin.view(1, 1, 1, h1, w1)

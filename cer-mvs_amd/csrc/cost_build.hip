@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void cost_build_kernel(const float* __restrict
                                                          const float* __restrict__ Pij, const float* __restrict__ disp_in,
                                                          float* __restrict__ vol, float* __restrict__ origin_out, int V, int h1, int w1,
                                                          int h2, int w2, int C, int D, int rs, float incre, float lim, int shift,
-                                                         int accumulate, int y0) {
+                                                         int accumulate, int y0, int levels, float scale) {
     const int lane = threadIdx.x & 63;
     const long P = (long)h1 * w1;
     // XCD-aware block order: workgroup b runs on XCD b % 8 (observed dispatch rule, speed only), so give each XCD a
@@ -142,7 +142,21 @@ __global__ __launch_bounds__(256) void cost_build_kernel(const float* __restrict
                 acc[i] = keep + __shfl_xor(send, hb);
             }
         }
-        if (lane < nk) {
+        if (levels > 1) {
+            // fused pyramid (host guarantees SUM, !accumulate, D <= 64): level 0 = view sum * scale, then avg-pool pairs
+            // (core/corr.py:94-97) with one exchange per level: element j of level l lives on lane j << l
+            float cur = acc[0] * scale;
+            if (lane < nk) orow[lane] = cur;
+            int off = 0, n = D;
+            for (int l = 1; l < levels; ++l) {
+                const int m = n / 2;
+                const float other = __shfl_xor(cur, 1 << (l - 1));
+                cur = (cur + other) * 0.5f;
+                off += n;
+                if ((lane & ((1 << l) - 1)) == 0 && (lane >> l) < m) orow[off + (lane >> l)] = cur;
+                n = m;
+            }
+        } else if (lane < nk) {
             float* o = orow + kb + lane;
             *o = accumulate ? (*o + acc[0]) : acc[0];
         }
@@ -151,38 +165,45 @@ __global__ __launch_bounds__(256) void cost_build_kernel(const float* __restrict
 
 template <int NQ>
 static int launch_build(const float* f1, const float* f2, const float* Pij, const float* disp_in, float* vol, float* origin_out, int V,
-                        int h1, int w1, int h2, int w2, int C, int D, int rs, double incre_d, int shift, int mode, int y0, hipStream_t st) {
+                        int h1, int w1, int h2, int w2, int C, int D, int rs, double incre_d, int shift, int mode, int y0, int levels, float scale,
+                        hipStream_t st) {
     const long P = (long)h1 * w1;
     const float lim = (float)((D / 2) * incre_d);
     const float incre = (float)incre_d;
     const unsigned gx = (unsigned)((P + 3) / 4);
     if (mode == 0)
         hipLaunchKernelGGL((cost_build_kernel<NQ, false, 64>), dim3(gx, (unsigned)V), dim3(256), 0, st, f1, f2, Pij, disp_in, vol, origin_out, V,
-                           h1, w1, h2, w2, C, D, rs, incre, lim, shift, 0, y0);
+                           h1, w1, h2, w2, C, D, rs, incre, lim, shift, 0, y0, 0, 1.0f);
     else if (D <= 48)
         hipLaunchKernelGGL((cost_build_kernel<NQ, true, 48>), dim3(gx, 1), dim3(256), 0, st, f1, f2, Pij, disp_in, vol, origin_out, V, h1, w1,
-                           h2, w2, C, D, rs, incre, lim, shift, mode == 2 ? 1 : 0, y0);
+                           h2, w2, C, D, rs, incre, lim, shift, mode == 2 ? 1 : 0, y0, levels, scale);
     else
         hipLaunchKernelGGL((cost_build_kernel<NQ, true, 64>), dim3(gx, 1), dim3(256), 0, st, f1, f2, Pij, disp_in, vol, origin_out, V, h1, w1,
-                           h2, w2, C, D, rs, incre, lim, shift, mode == 2 ? 1 : 0, y0);
+                           h2, w2, C, D, rs, incre, lim, shift, mode == 2 ? 1 : 0, y0, levels, scale);
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }
 
 extern "C" int cer_cost_build_f32(const float* fmap1, const float* fmap2, const float* Pij, const float* disp_in, float* vol,
                                   float* origin_out, int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride, double incre,
-                                  int shift, int mode, int y0, void* stream) {
+                                  int shift, int mode, int y0, int fuse_levels, float fuse_scale, void* stream) {
     if (!fmap1 || !fmap2 || !Pij || !disp_in || !vol) return CER_EINVAL;
+    if (fuse_levels > 1) {                                 // fused pyramid: view-sum fold of a single 64-hypothesis block only
+        if (mode != 1 || D > 64) return CER_EINVAL;
+        int need = 0, n = D;
+        for (int l = 0; l < fuse_levels; ++l) { need += n; n /= 2; }
+        if (row_stride < need || fuse_levels > 6) return CER_ESHAPE;
+    }
     if (V <= 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || C <= 0 || D <= 0 || row_stride < D || mode < 0 || mode > 2) return CER_EINVAL;
     if (C % 64 != 0 || C > 256 || V > 65535) return CER_ESHAPE;
     if ((long)(h2 + 4) * (w2 + 4) * C >= (1L << 31)) return CER_ESHAPE;
     if (!cer_aligned16(fmap1) || !cer_aligned16(fmap2)) return CER_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     switch (C / 64) {
-        case 1: return launch_build<1>(fmap1, fmap2, Pij, disp_in, vol, origin_out, V, h1, w1, h2, w2, C, D, row_stride, incre, shift, mode, y0, st);
-        case 2: return launch_build<2>(fmap1, fmap2, Pij, disp_in, vol, origin_out, V, h1, w1, h2, w2, C, D, row_stride, incre, shift, mode, y0, st);
-        case 3: return launch_build<3>(fmap1, fmap2, Pij, disp_in, vol, origin_out, V, h1, w1, h2, w2, C, D, row_stride, incre, shift, mode, y0, st);
-        default: return launch_build<4>(fmap1, fmap2, Pij, disp_in, vol, origin_out, V, h1, w1, h2, w2, C, D, row_stride, incre, shift, mode, y0, st);
+        case 1: return launch_build<1>(fmap1, fmap2, Pij, disp_in, vol, origin_out, V, h1, w1, h2, w2, C, D, row_stride, incre, shift, mode, y0, fuse_levels, fuse_scale, st);
+        case 2: return launch_build<2>(fmap1, fmap2, Pij, disp_in, vol, origin_out, V, h1, w1, h2, w2, C, D, row_stride, incre, shift, mode, y0, fuse_levels, fuse_scale, st);
+        case 3: return launch_build<3>(fmap1, fmap2, Pij, disp_in, vol, origin_out, V, h1, w1, h2, w2, C, D, row_stride, incre, shift, mode, y0, fuse_levels, fuse_scale, st);
+        default: return launch_build<4>(fmap1, fmap2, Pij, disp_in, vol, origin_out, V, h1, w1, h2, w2, C, D, row_stride, incre, shift, mode, y0, fuse_levels, fuse_scale, st);
     }
 }
 

@@ -44,10 +44,12 @@ def alt_corr_backward(fmap1, fmap2, coords, corr_grad, radius):
     return g1, g2, gc
 
 
-def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, fold, vol=None, accumulate=False, src_hw=None, y0=0):
+def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, fold, vol=None, accumulate=False, src_hw=None, y0=0,
+               pyramid_scale=None):
     """fmap1 [P,C], fmap2 [V,(h2+4)*(w2+4),C] (NHWC, pre-scaled, 2-texel zero border), Pij [V,4,4], disp_in [P].
     (h1, w1): reference grid of this call, first image row ``y0`` (row slabs); ``src_hw``: source-map size (default h1, w1).
-    Returns (vol [V,P,rs] or [P,rs], origin [P]).  Level 0 only; call ``pyramid`` next."""
+    Returns (vol [V,P,rs] or [P,rs], origin [P]).  Level 0 only; call ``pyramid`` next - unless ``pyramid_scale`` is given
+    (fold, no accumulate, D <= 64): then the kernel's epilogue scales level 0 and writes the pooled levels itself."""
     V, P2, C = fmap2.shape
     P = h1 * w1
     h2, w2 = src_hw if src_hw is not None else (h1, w1)
@@ -59,9 +61,13 @@ def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, 
         vol = torch.zeros(shape, device=fmap1.device, dtype=torch.float32)
     origin = torch.empty(P, device=fmap1.device, dtype=torch.float32)
     mode = (2 if accumulate else 1) if fold else 0
+    fuse = pyramid_scale is not None
+    if fuse and (mode != 1 or D > 64):
+        raise ValueError("cost_build: the fused pyramid needs fold=True, accumulate=False and D <= 64")
     L.check(L.load().cer_cost_build_f32(L.dev_ptr(fmap1, "fmap1"), L.dev_ptr(fmap2, "fmap2"), L.dev_ptr(Pij, "Pij"),
                                         L.dev_ptr(disp_in, "disp_in"), L.dev_ptr(vol, "vol"), L.dev_ptr(origin, "origin"),
-                                        V, h1, w1, h2, w2, C, D, rs, float(incre), int(bool(shift)), mode, int(y0), L.cur_stream()),
+                                        V, h1, w1, h2, w2, C, D, rs, float(incre), int(bool(shift)), mode, int(y0),
+                                        num_levels if fuse else 0, float(pyramid_scale) if fuse else 1.0, L.cur_stream()),
             "cost_build")
     return vol, origin
 

@@ -140,14 +140,17 @@ class RAFT(nn.Module):
         hoisted = ub.hoist(inp_l, h, w)
         ws = ub.workspace(P, dev)
         for stage, (D, incre, T) in enumerate(self.stages()):
+            single = self.view_group is None   # no cross-rank sum between the build and the pooling: fuse them
             if views:
-                vol, origin = ops.cost_build(f1, f2, Pij, disp, D, incre, stage == 0, h, w, ub.num_levels, fold=True)
+                vol, origin = ops.cost_build(f1, f2, Pij, disp, D, incre, stage == 0, h, w, ub.num_levels, fold=True,
+                                             pyramid_scale=(1.0 / V) if (single and D <= 64) else None)
             else:                      # more ranks than views: contribute zeros
                 _, _, rs = ops.row_layout(D, ub.num_levels)
                 vol = torch.zeros(P, rs, device=dev)
                 origin = cdist.stage_origin(disp, D, incre, stage == 0)
-            cdist.reduce_volume(vol, self.view_group)
-            ops.pyramid(vol, D, ub.num_levels, scale=1.0 / V)
+            if not (single and views and D <= 64):
+                cdist.reduce_volume(vol, self.view_group)
+                ops.pyramid(vol, D, ub.num_levels, scale=1.0 / V)
             if do_report and stage > 0:
                 report()
             ub.run(T, vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws)

@@ -192,8 +192,9 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
         for g in ex.ranks:
             d = st[g]
             vol, origin = ops.cost_build(d["f1s"], d["f2"], Pij, d["disp"], D, incre, stage == 0, d["hs"], w, ub.num_levels,
-                                         fold=True, src_hw=(h, w), y0=d["e0"])
-            ops.pyramid(vol, D, ub.num_levels, scale=1.0 / V)
+                                         fold=True, src_hw=(h, w), y0=d["e0"], pyramid_scale=(1.0 / V) if D <= 64 else None)
+            if D > 64:
+                ops.pyramid(vol, D, ub.num_levels, scale=1.0 / V)
             d["vol"], d["origin"] = vol, origin
         ub.packed(stage, dev)                  # host-side weight packing stays out of the recorded plans
         for it in range(T):

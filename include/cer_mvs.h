@@ -74,13 +74,16 @@ int cer_alt_corr_backward_f32(const float* fmap1, const float* fmap2, const floa
  *   mode 2: as mode 1 but adds into the existing vol (accumulate across calls)
  * (h1, w1) is the reference-pixel grid this call covers and y0 the image row of its first row: a multi-GPU rank that owns
  * a row slab passes its slab height and first row (fmap1 / disp_in / vol then hold only those rows); y0 = 0 otherwise.
+ * fuse_levels > 1 (mode 1, D <= 64 only): the epilogue also scales level 0 by fuse_scale (1/V: the view mean) and writes
+ * the avg-pooled levels 1..fuse_levels-1 behind it - what cer_pyramid_f32(vol, ..., fuse_levels, fuse_scale) would do in a
+ * second pass (core/corr.py:94-97); 0 or 1 = level 0 only, unscaled.
  * origin_out [P] may be NULL.  C % 64 == 0.  `incre` is the reference's Python float (core/raft.py:81): the kernel
  * uses (float)incre for the hypothesis spacing and (float)((D/2)*incre) for the shift limit, as torch does.
  */
 int cer_cost_build_f32(const float* fmap1, const float* fmap2, const float* Pij, const float* disp_in,
                        float* vol, float* origin_out,
                        int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride,
-                       double incre, int shift, int mode, int y0, void* stream);
+                       double incre, int shift, int mode, int y0, int fuse_levels, float fuse_scale, void* stream);
 
 /* Correlation pyramid (reference: core/corr.py:94-97, F.avg_pool2d([1,2]) x (L-1)), in place on
  * rows laid out [level0 (D) | level1 (D/2) | level2 (D/4) | ... | pad]: first level0 *= scale

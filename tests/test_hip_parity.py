@@ -241,6 +241,30 @@ def test_conv3x3_disp_encoder_source(dev):
         assert rel_l1(out.cpu(), ref) < 2e-6, mode
 
 
+@pytest.mark.parametrize("D", [64, 44, 20])
+def test_cost_build_fused_pyramid_equals_two_pass(dev, D):
+    """cer_cost_build_f32 with fuse_levels: level 0 * 1/V and the avg-pooled levels written by the build's epilogue are
+    bit-identical to cer_cost_build_f32 + cer_pyramid_f32 (core/corr.py:94-97)."""
+    from cer_mvs_amd import ops
+    from cer_mvs_amd.corr import fmaps_to_nhwc
+    h1, w1, V, C = 11, 17, 3, 64
+    fm = hashed((1, V + 1, C, h1, w1), 301, -2, 2).to(dev)
+    f1 = fmaps_to_nhwc(fm[0, 0:1])[0]
+    f2 = fmaps_to_nhwc(fm[0, 1:], border=2)
+    Pij = torch.eye(4).repeat(V, 1, 1)
+    for v in range(V):
+        Pij[v, 0, 3] = 900.0 * (v + 1)
+        Pij[v, 1, 3] = -300.0 * v
+    d0 = hashed((h1 * w1,), 302, 0.0005, 0.002).to(dev)
+    incre = 0.0025 / 64
+    a, oa = ops.cost_build(f1, f2, Pij.to(dev), d0, D, incre, False, h1, w1, 3, fold=True)
+    ops.pyramid(a, D, 3, scale=1.0 / V)
+    b, ob = ops.cost_build(f1, f2, Pij.to(dev), d0, D, incre, False, h1, w1, 3, fold=True, pyramid_scale=1.0 / V)
+    n = D + D // 2 + D // 4
+    assert torch.equal(a[:, :n], b[:, :n]) and torch.equal(oa, ob)
+    assert a[:, :D].abs().sum() > 0
+
+
 @pytest.mark.parametrize("h,w,cout", [(20, 140, 128), (13, 101, 64), (24, 96, 64)])
 def test_conv3x3_collapsed_disparity_tiles(dev, h, w, cout):
     """Interior tiles evaluate the disparity source as one 81-tap filter on the raw disparity (cer_mvs.h,

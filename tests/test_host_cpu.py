@@ -36,7 +36,7 @@ def test_argument_errors_without_device():
     lib = _lib.load()
     null = ctypes.c_void_p(0)
     assert lib.cer_alt_corr_forward_f32(null, null, null, null, 1, 1, 4, 4, 4, 4, 64, 0, null) == -1
-    assert lib.cer_cost_build_f32(null, null, null, null, null, null, 1, 4, 4, 4, 4, 64, 64, 112, ctypes.c_double(0.1), 1, 1, 0, null) == -1
+    assert lib.cer_cost_build_f32(null, null, null, null, null, null, 1, 4, 4, 4, 4, 64, 64, 112, ctypes.c_double(0.1), 1, 1, 0, 0, 1.0, null) == -1
     assert lib.cer_pyramid_f32(null, 10, 64, 112, 3, 1.0, null) == -1
     fake = ctypes.c_void_p(0x1000)
     assert lib.cer_alt_corr_forward_f32(fake, fake, fake, fake, 1, 1, 4, 4, 4, 4, 60, 0, null) == -2      # C % 64
