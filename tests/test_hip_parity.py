@@ -358,6 +358,31 @@ def test_hip_encoder_engine_matches_oracle(dev, which, size):
     assert rel_l1(got, ref) < 1e-5
 
 
+def test_encoder_engine_batch_invariance_at_tnt_size(dev):
+    """BASELINE.json configs[2] size (3840x2160, 16 images per fnet launch): layer-1 activations are 16 x 1080 x 1920 x 32
+    floats = 4.2 GB, i.e. element offsets beyond 2^31 bytes.  Instance norm is per image, so the batched launch must
+    reproduce, bit for bit, what the LAST image gives alone (an offset overflow would corrupt exactly the late images)."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.encoder_hip import HipEncoder
+    from cer_mvs_amd.synthetic import fill_state_dict
+    model = RAFT(test_mode=True)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=13))
+    eng = HipEncoder(model.fnet, dev)
+    N, H, W = 16, 2160, 3840
+    g = torch.Generator(device="cpu").manual_seed(7)
+    small = torch.rand(N, 3, H // 8, W // 8, generator=g) * 2 - 1
+    x = torch.nn.functional.interpolate(small, size=(H, W), mode="bilinear", align_corners=False).to(dev)
+    x += 0.05 * torch.sin(torch.arange(W, device=dev) * 0.37)[None, None, None, :]
+    with torch.no_grad():
+        ref_all, src_all, h, w = eng.features(x, n_ref=1)
+        _, src_last, _, _ = eng.features(x[[0, N - 1]], n_ref=1)
+        _, src_mid, _, _ = eng.features(x[[0, 9]], n_ref=1)
+    assert (h, w) == (H // 4, W // 4) and torch.isfinite(src_all).all()
+    assert torch.equal(src_all[N - 2], src_last[0])
+    assert torch.equal(src_all[8], src_mid[0])
+    assert src_all[N - 2].abs().sum() > 0
+
+
 def test_norm_act_kernels(dev):
     from cer_mvs_amd import ops
     x = hashed((3, 5, 12, 20), 131, -3, 5)
