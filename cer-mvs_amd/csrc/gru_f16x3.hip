@@ -30,7 +30,9 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-#define HX_TH 4
+#ifndef HX_TH
+#define HX_TH 4                        // tile rows (8: experiment, one 8-wave block of 256 px per CU)
+#endif
 #define HX_TW 32
 #define HX_HH (HX_TH + 2)
 #define HX_HW (HX_TW + 2)
@@ -690,15 +692,21 @@ extern "C" int cer_conv3x3_f16x3(const cer_conv_inputs* in, const void* packed_w
     hipStream_t st = (hipStream_t)stream;
     // 128 output channels per block: 8 waves (4 x 2) of 32 px x 64 ch, 3-slot weight ring, 2 blocks (16 waves) per CU;
     //  64 output channels per block: 8 waves (4 x 2) of 32 px x 32 ch, 3-slot ring, 2 blocks (16 waves) per CU.
-#if defined(HX_CFG) && HX_CFG == 1      // experiment: 4-wave blocks, 64 px x 64 ch per wave, 256 registers, 2 blocks/CU
+#if HX_TH == 8                          // experiment: 8 x 32 pixel tile, 8 waves of 64 px x (64 | 32) ch, 256 registers, 1 block/CU
+    if (epi == HX_EPI_DELTA) return CER_ESHAPE;
+    if (Cout % 128 == 0) return hx_launch<4, 2, 2, 2, 3, 2>(a, epi, Cout / 128, st);
+    return hx_launch<4, 2, 2, 1, 3, 2>(a, epi, Cout / 64, st);
+#elif defined(HX_CFG) && HX_CFG == 1      // experiment: 4-wave blocks, 64 px x 64 ch per wave, 256 registers, 2 blocks/CU
     if (Cout % 128 == 0 && epi != HX_EPI_DELTA) return hx_launch<2, 2, 2, 2, 3, 2>(a, epi, Cout / 128, st);
 #elif defined(HX_CFG) && HX_CFG == 2    // experiment: 4-wave blocks, 128 px x 32 ch per wave
     if (Cout % 128 == 0 && epi != HX_EPI_DELTA) return hx_launch<1, 4, 4, 1, 3, 2>(a, epi, Cout / 128, st);
 #elif defined(HX_CFG) && HX_CFG == 3    // experiment: 4-wave blocks, 32 px x 128 ch per wave
     if (Cout % 128 == 0 && epi != HX_EPI_DELTA) return hx_launch<4, 1, 1, 4, 3, 2>(a, epi, Cout / 128, st);
 #endif
+#if HX_TH == 4
     if (Cout % 128 == 0) return hx_launch<4, 2, 1, 2, 3, 4>(a, epi, Cout / 128, st);
     return hx_launch<4, 2, 1, 1, 3, 4>(a, epi, Cout / 64, st);
+#endif
 }
 
 // ---- delta head tail for the fused path ------------------------------------------------------------------
