@@ -127,6 +127,43 @@ def synthetic_scene(H, W, V, seed=0, depth=600.0, ring_deg=4.0, focal_factor=1.8
             torch.tensor([1.0], dtype=torch.float64))
 
 
+def synthetic_depth_maps(H, W, V, seed=0, depth=600.0, ring_deg=4.0, focal_factor=1.8, noise=2e-3, outliers=0.08):
+    """Per-view depth maps [V+1,H,W] (float32) of the ``synthetic_scene`` plane as an MVS network would deliver them: the
+    analytic ray/plane depth of every view times (1 + smooth value noise of relative amplitude ``noise``), with a fraction
+    ``outliers`` of 8x8 blocks pushed 3-12 % off - so that the geometric-consistency masks of the fusion step are neither
+    empty nor full.  Same cameras as ``synthetic_scene`` (call it for images / poses / intrinsics)."""
+    fx = focal_factor * W
+    K = np.array([[fx, 0.0, W / 2.0], [0.0, fx, H / 2.0], [0.0, 0.0, 1.0]])
+    Kinv = np.linalg.inv(K)
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    centre = np.array([0.0, 0.0, depth])
+    out = np.zeros((V + 1, H, W), dtype=np.float32)
+    for v in range(V + 1):
+        if v == 0:
+            R, t = np.eye(3), np.zeros(3)
+        else:
+            k = (v + 1) // 2
+            yaw = math.radians(ring_deg * k) * (1.0 if v % 2 else -1.0)
+            pitch = math.radians(0.6 * ring_deg * ((v % 3) - 1))
+            cy, sy, cp, sp = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch)
+            Ry = np.array([[cy, 0.0, sy], [0.0, 1.0, 0.0], [-sy, 0.0, cy]])
+            Rx = np.array([[1.0, 0.0, 0.0], [0.0, cp, -sp], [0.0, sp, cp]])
+            R = Rx @ Ry
+            t = centre - R @ centre
+        rays = Kinv @ np.stack([xs.ravel(), ys.ravel(), np.ones(H * W)])
+        Rt = R.T
+        lam = ((depth + (Rt @ t)[2]) / (Rt @ rays)[2]).reshape(H, W)
+        smooth = plane_texture(xs * 3.0, ys * 3.0, 0, seed + 100 + v) / 255.0 - 0.5          # value noise in [-0.5, 0.5]
+        d = lam * (1.0 + 2.0 * noise * smooth)
+        bx, by = (xs // 8).astype(np.int64), (ys // 8).astype(np.int64)
+        hsh = _lattice(bx, by, seed * 97 + 7 + 1000 * v)                                     # block hashes in [0, 1)
+        amp = 0.03 + 0.09 * _lattice(bx, by, seed * 97 + 9 + 1000 * v)
+        sign = np.where(_lattice(bx, by, seed * 97 + 11 + 1000 * v) < 0.5, -1.0, 1.0)
+        d = np.where(hsh < outliers, d * (1.0 + sign * amp), d)
+        out[v] = d.astype(np.float32)
+    return torch.from_numpy(out)
+
+
 def fill_state_dict(state_dict, seed=0, gain=1.0):
     """Overwrite every tensor of a RAFT ``state_dict`` with closed-form values.
 
