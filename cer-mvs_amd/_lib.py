@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CER_MVS_LIB") or os.path.join(_HERE, "csrc", "libcermvs.so")
-ABI_VERSION = 1010
+ABI_VERSION = 1011
 CONV_MAX_SRC = 4
 EPI_LINEAR, EPI_RELU, EPI_GATES, EPI_GRU, EPI_DELTA = 0, 1, 2, 3, 4
 
@@ -69,6 +69,7 @@ _SIGNATURES = {
     "cer_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _L, _F, _P]),
     "cer_nchw_to_nhwc_border_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "cer_copy_segments_f32": (_I, [_c.POINTER(CopySegments), _P]),
+    "cer_geo_consistency_f32": (_I, [_P, _P, _P, _I, _I, _I, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

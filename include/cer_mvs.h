@@ -254,6 +254,22 @@ int cer_nhwc_to_nchw_f32(const float* src, float* dst, int C, long P, float scal
  * layout of cer_cost_build_f32 with b = 2; reference: core/corr.py:29-35 permute, /8.0, contiguous). */
 int cer_nchw_to_nhwc_border_f32(const float* src, float* dst, int N, int C, int h, int w, int border, float scale, void* stream);
 
+/* ---- after the path: geometric-consistency filtering of the depth maps ------------------------
+ * One reference depth map against S <= 10 source views, fused (reference: fusion.py:39-83 reproject_with_depth,
+ * :86-106 check_geometric_consistency, :226-236 vote and averaged depth; utils/bilinear_sampler.py:32-41).
+ *   depth_ref [h*w], depth_src [S, h*w] (device);  cams [S][CER_GEO_CAM_FLOATS] (device), per source view, row-major fp32:
+ *     K_ref^-1 [9] | (E_src E_ref^-1) rows 0..2 [12] | K_src [9] | K_src^-1 [9] | (E_ref E_src^-1) rows 0..2 [12] | K_ref [9]
+ *   thre1, thre2: the reference's Python floats (mask i, i = 2..10: dist < i/thre1 and |d_reproj - d|/d < i/thre2).
+ * Outputs (any may be NULL): geo_mask [h*w] 0/1 (mask10 of all views, or mask_i of >= i views for some i < 1+S),
+ * depth_est [h*w] = (sum of mask10-consistent reprojected depths + depth_ref) / (count + 1), mask_count += area of geo_mask.
+ * Per-view tensors of the reference's API, written only when the pointer is given: masks9 [9, S, h*w] (0/1),
+ * depth_reprojected [S, h*w] (zero outside mask10), x_src, y_src, rel_diff [S, h*w]. */
+#define CER_GEO_CAM_FLOATS 60
+int cer_geo_consistency_f32(const float* depth_ref, const float* depth_src, const float* cams, int S, int h, int w,
+                            double thre1, double thre2, unsigned char* geo_mask, float* depth_est, unsigned int* mask_count,
+                            unsigned char* masks9, float* depth_reprojected, float* x_src, float* y_src, float* rel_diff,
+                            void* stream);
+
 /* Multi-GPU row-slab exchange (cer-mvs_amd/slab.py): up to CER_COPY_MAX_SEG contiguous fp32 ranges copied by ONE launch -
  * the pack of a rank's (net, disp) border strips into its send buffer, and the refresh of its halo rows from the gathered
  * strips.  n[i] floats from src[i] to dst[i]; n[i] == 0 skips a segment.  Device pointers; ranges must not overlap. */
