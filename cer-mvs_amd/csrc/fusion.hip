@@ -41,8 +41,12 @@ __device__ __forceinline__ float geo_sample(const float* __restrict__ img, int h
     return out;
 }
 
+struct GeoThresholds {
+    float dist[9], rel[9];                                 // (float)(i / thre1), (float)(i / thre2) for i = 2..10, rounded once on the host
+};
+
 __global__ __launch_bounds__(256) void geo_consistency_kernel(const float* __restrict__ depth_ref, const float* __restrict__ depth_src,
-                                                              const float* __restrict__ cams, int S, int h, int w, double thre1, double thre2,
+                                                              const float* __restrict__ cams, int S, int h, int w, const GeoThresholds th,
                                                               unsigned char* __restrict__ geo_mask, float* __restrict__ depth_est,
                                                               unsigned int* __restrict__ mask_count, unsigned char* __restrict__ masks9,
                                                               float* __restrict__ drep_out, float* __restrict__ xs_out,
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256) void geo_consistency_kernel(const float* __res
             bool m10 = false;
 #pragma unroll
             for (int i = 2; i <= 10; ++i) {
-                const bool m = dist < (float)((double)i / thre1) && rel < (float)((double)i / thre2);   // python float i/thre -> fp32                                // (:100-103)
+                const bool m = dist < th.dist[i - 2] && rel < th.rel[i - 2];                                    // (:100-103)                                // (:100-103)
                 cnt[i - 2] += m ? 1 : 0;
                 if (masks9) masks9[((long)(i - 2) * S + s) * P + p] = m ? 1 : 0;
                 if (i == 10) m10 = m;
@@ -95,9 +99,15 @@ __global__ __launch_bounds__(256) void geo_consistency_kernel(const float* __res
         if (geo_mask) geo_mask[p] = geo ? 1 : 0;
         if (depth_est) depth_est[p] = (dsum + d) / (float)(cnt[8] + 1); //                                         (:236)
     }
-    if (mask_count) {                                                   // mask area of this view, one atomic per wave
+    if (mask_count) {                 // mask area of this view: wave ballots -> one atomic per block, spread over 64 counters
+        __shared__ unsigned int wave_cnt[4];
         const unsigned long long b = __ballot(geo);
-        if ((threadIdx.x & 63) == 0 && b) atomicAdd(mask_count, (unsigned int)__popcll(b));
+        if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = (unsigned int)__popcll(b);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int c = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            if (c) atomicAdd(mask_count + (blockIdx.x & (CER_GEO_COUNTERS - 1)), c);
+        }
     }
 }
 
@@ -109,8 +119,13 @@ extern "C" int cer_geo_consistency_f32(const float* depth_ref, const float* dept
     if (S > 10) return CER_ESHAPE;                                      // the reference indexes masks[i-2] for i < 1+S <= 11 (fusion.py:226-228)
     if (!(thre1 > 0.0) || !(thre2 > 0.0)) return CER_EINVAL;
     const long P = (long)h * w;
+    GeoThresholds th;                                      // python: dist < i / thre1 compares an fp32 tensor with the double i / thre1 cast to fp32
+    for (int i = 2; i <= 10; ++i) {
+        th.dist[i - 2] = (float)((double)i / thre1);
+        th.rel[i - 2] = (float)((double)i / thre2);
+    }
     hipLaunchKernelGGL(geo_consistency_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, depth_ref, depth_src,
-                       cams, S, h, w, thre1, thre2, geo_mask, depth_est, mask_count, masks9, depth_reprojected, x_src, y_src, rel_diff);
+                       cams, S, h, w, th, geo_mask, depth_est, mask_count, masks9, depth_reprojected, x_src, y_src, rel_diff);
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }

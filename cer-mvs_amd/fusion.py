@@ -22,6 +22,7 @@ import torch
 from . import _lib as L
 
 CAM_FLOATS = 60
+COUNTERS = 64          # cer_mvs.h CER_GEO_COUNTERS: the mask area is accumulated over this many device counters
 
 
 def compose_cams(K_ref, E_ref, K_src, E_src):
@@ -98,15 +99,15 @@ def fuse_depth_maps(depths, Ks, Es, pairs, glb=0.25, rounds=10):
         srcs.append(depths[src].contiguous())
     masks = torch.zeros(N, H, W, device=dev, dtype=torch.uint8)
     est = torch.zeros(N, H, W, device=dev, dtype=torch.float32)
-    counts = torch.zeros(len(pairs), device=dev, dtype=torch.int32)
+    counts = torch.zeros(len(pairs), COUNTERS, device=dev, dtype=torch.int32)
     lo, hi, hist, thre = -2.0, 2.0, [], 0.0
     for _ in range(rounds):
         thre = (lo + hi) / 2
         counts.zero_()
         for k, (ref, _) in enumerate(pairs):
             _launch(depths[ref], srcs[k], cams[k], 10 ** thre * 4, 10 ** thre * 1300, geo_mask=masks[ref], depth_est=est[ref],
-                    count=counts[k:k + 1])
-        cnt = counts.cpu().numpy()                           # one synchronisation per round
+                    count=counts[k])
+        cnt = counts.sum(1).cpu().numpy()                    # one synchronisation per round
         # the reference averages per-view float32 means, geo_mask.float().mean().item() (fusion.py:238, :272)
         mean = float(np.mean([float(np.float32(c) / np.float32(H * W)) for c in cnt]))
         hist.append((thre, mean))

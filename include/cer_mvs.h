@@ -261,10 +261,13 @@ int cer_nchw_to_nhwc_border_f32(const float* src, float* dst, int N, int C, int 
  *     K_ref^-1 [9] | (E_src E_ref^-1) rows 0..2 [12] | K_src [9] | K_src^-1 [9] | (E_ref E_src^-1) rows 0..2 [12] | K_ref [9]
  *   thre1, thre2: the reference's Python floats (mask i, i = 2..10: dist < i/thre1 and |d_reproj - d|/d < i/thre2).
  * Outputs (any may be NULL): geo_mask [h*w] 0/1 (mask10 of all views, or mask_i of >= i views for some i < 1+S),
- * depth_est [h*w] = (sum of mask10-consistent reprojected depths + depth_ref) / (count + 1), mask_count += area of geo_mask.
+ * depth_est [h*w] = (sum of mask10-consistent reprojected depths + depth_ref) / (count + 1);
+ * mask_count [CER_GEO_COUNTERS] (unsigned): the area of geo_mask is ADDED, spread over the counters (their sum is the area -
+ * one hot address would serialise the blocks' atomics).
  * Per-view tensors of the reference's API, written only when the pointer is given: masks9 [9, S, h*w] (0/1),
  * depth_reprojected [S, h*w] (zero outside mask10), x_src, y_src, rel_diff [S, h*w]. */
 #define CER_GEO_CAM_FLOATS 60
+#define CER_GEO_COUNTERS 64
 int cer_geo_consistency_f32(const float* depth_ref, const float* depth_src, const float* cams, int S, int h, int w,
                             double thre1, double thre2, unsigned char* geo_mask, float* depth_est, unsigned int* mask_count,
                             unsigned char* masks9, float* depth_reprojected, float* x_src, float* y_src, float* rel_diff,

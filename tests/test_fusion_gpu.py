@@ -54,7 +54,7 @@ def test_fused_vote_equals_per_view_api_and_oracle(dev, golden):
     for ref in (0, 3):
         src = [j for j in range(V + 1) if j != ref]
         S, n = len(src), len(src) + 1
-        cnt = torch.zeros(1, device=dev, dtype=torch.int32)
+        cnt = torch.zeros(fusion.COUNTERS, device=dev, dtype=torch.int32)
         geo, est = fusion.vote(depths[ref].to(dev), K[ref], E[ref], depths[src].to(dev), K[src], E[src], 9.0, 2900.0, count=cnt)
         masks, mask, drep, _, _, _ = fusion.check_geometric_consistency(
             depths[ref][None].repeat(S, 1, 1).to(dev), K[ref][None].repeat(S, 1, 1), E[ref][None].repeat(S, 1, 1), depths[src].to(dev),
@@ -64,7 +64,7 @@ def test_fused_vote_equals_per_view_api_and_oracle(dev, golden):
         for i in range(2, n):
             lit = lit | (masks[i - 2].sum(0) >= i)
         assert torch.equal(geo.bool(), lit)
-        assert int(cnt.item()) == int(lit.sum().item())
+        assert int(cnt.sum().item()) == int(lit.sum().item())
         assert rel_l1(est.cpu(), ((drep.sum(0) + depths[ref].to(dev)) / (gsum + 1)).cpu()) < 1e-6
         om, oe = FO.vote(depths[ref], K[ref], E[ref], depths[src], K[src], E[src], 9.0, 2900.0)
         assert (geo.bool().cpu() != om).float().mean() < 5e-4

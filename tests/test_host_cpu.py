@@ -251,3 +251,50 @@ def test_synthetic_scene_is_reproducible(golden):
     assert tensor_checksum(images) == int(g["images_checksum"])
     assert images.shape == (1, 4, 3, 64, 96) and float(images.min()) >= 0 and float(images.max()) <= 255
     assert float(scale) == 1.0
+
+
+def test_fusion_host_logic():
+    """cer-mvs_amd/fusion.py host side (no GPU): camera chains equal the oracle's matrices, PFM round trip, PLY layout,
+    CPU tensors are refused."""
+    import io
+    from cer_mvs_amd import fusion
+    from cer_mvs_amd.inference import write_pfm
+    from cer_mvs_amd.synthetic import synthetic_scene
+    _, poses, intr, _ = synthetic_scene(32, 48, 3, seed=4)
+    K, E = intr[0], poses[0]
+    cams = fusion.compose_cams(K[0], E[0], K[1:], E[1:])
+    assert cams.shape == (3, fusion.CAM_FLOATS) and cams.dtype == torch.float32
+    for s in range(3):
+        assert torch.equal(cams[s, :9].view(3, 3), torch.inverse(K[0]))
+        assert torch.equal(cams[s, 9:21].view(3, 4), torch.matmul(E[1 + s], torch.inverse(E[0]))[:3])
+        assert torch.equal(cams[s, 21:30].view(3, 3), K[1 + s]) and torch.equal(cams[s, 51:60].view(3, 3), K[0])
+        assert torch.equal(cams[s, 39:51].view(3, 4), torch.matmul(E[0], torch.inverse(E[1 + s]))[:3])
+    with pytest.raises(RuntimeError, match="CUDA"):
+        fusion.vote(torch.ones(4, 4), K[0], E[0], torch.ones(2, 4, 4), K[1:3], E[1:3], 4.0, 1300.0)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        fusion.fuse_depth_maps(torch.ones(3, 4, 4), K[:3], E[:3], [(0, [1, 2])])
+
+
+def test_pfm_and_ply_io(tmp_path):
+    from cer_mvs_amd import fusion
+    from cer_mvs_amd.inference import write_pfm
+    d = hashed((7, 5), 61, 400.0, 800.0).numpy()
+    write_pfm(tmp_path / "a.pfm", d)
+    assert np.array_equal(fusion.read_pfm(tmp_path / "a.pfm"), d)
+    xyz = hashed((6, 3), 62, -5.0, 5.0).numpy()
+    rgb = (hashed((6, 3), 63, 0.0, 255.0).numpy()).astype(np.uint8)
+    fusion.write_ply(tmp_path / "p.ply", xyz, rgb)
+    raw = open(tmp_path / "p.ply", "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    assert head.startswith(b"ply\nformat binary_little_endian 1.0\nelement vertex 6\nproperty float x\n")
+    assert len(body) == 6 * 15
+    v = np.frombuffer(body, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("r", "u1"), ("g", "u1"), ("b", "u1")])
+    assert np.array_equal(np.stack([v["x"], v["y"], v["z"]], 1), xyz) and np.array_equal(np.stack([v["r"], v["g"], v["b"]], 1), rgb)
+    lib_null = ctypes.c_void_p(None)
+    from cer_mvs_amd import _lib
+    lib = _lib.load()
+    fake = ctypes.c_void_p(4096)
+    assert lib.cer_geo_consistency_f32(lib_null, fake, fake, 2, 8, 8, 4.0, 1300.0, lib_null, lib_null, lib_null, lib_null, lib_null, lib_null,
+                                       lib_null, lib_null, lib_null) == -1
+    assert lib.cer_geo_consistency_f32(fake, fake, fake, 11, 8, 8, 4.0, 1300.0, lib_null, lib_null, lib_null, lib_null, lib_null, lib_null,
+                                       lib_null, lib_null, lib_null) == -2      # the reference's vote indexes at most 9 masks
