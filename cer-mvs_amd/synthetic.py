@@ -153,6 +153,9 @@ def synthetic_depth_maps(H, W, V, seed=0, depth=600.0, ring_deg=4.0, focal_facto
         rays = Kinv @ np.stack([xs.ravel(), ys.ravel(), np.ones(H * W)])
         Rt = R.T
         lam = ((depth + (Rt @ t)[2]) / (Rt @ rays)[2]).reshape(H, W)
+        if noise == 0.0 and outliers == 0.0:                 # exact plane depths
+            out[v] = lam.astype(np.float32)
+            continue
         smooth = plane_texture(xs * 3.0, ys * 3.0, 0, seed + 100 + v) / 255.0 - 0.5          # value noise in [-0.5, 0.5]
         d = lam * (1.0 + 2.0 * noise * smooth)
         bx, by = (xs // 8).astype(np.int64), (ys // 8).astype(np.int64)
