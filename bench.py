@@ -297,6 +297,7 @@ def main():
                             else f"view-shard x{world} + all-reduce/stage") if shard else f"replica x{world}"),
                        **({"backend": "gloo (validation run, ranks may share a GPU)"} if (world > 1 and args.backend == "gloo") else {})},
             "roofline": roofline, "roofline_hbm_kernel": hbm, "kernels": kern,
+            "peak_device_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(H, W, V, cascade, {k: v.cpu() for k, v in sd.items()})
