@@ -436,42 +436,66 @@ extern "C" int cer_enc_merge_f32(const float* a, const float* a_stats, const flo
 // ---- stem: 7x7 stride-2 pad-3 convolution 3 -> 32 on the raw image (core/extractor.py:81,145; core/raft.py:40-41) ----
 // NCHW image in 0..255 -> x*(2/255) - 1 on the fly -> channels-last raw output [N, ho*wo, 32] + stats partials.
 // Direct fp32: one thread = one output pixel x 32 channels; weights [147][32] through the scalar cache.
-#define ST_PIX 256
+#define ST_PIX 256                      // threads per block; each thread owns TWO horizontally adjacent output pixels
+typedef float st_float2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(ST_PIX) void enc_stem_kernel(const float* __restrict__ img, const float* __restrict__ wgt, const float* __restrict__ bias,
                                                           float* __restrict__ out, float* __restrict__ part, int H, int W, int ho, int wo,
                                                           int nblk, int normalize) {
     __shared__ float red[4][32][2];
     const int n = blockIdx.y;
-    const long p = (long)blockIdx.x * ST_PIX + threadIdx.x;
+    const int wo2 = (wo + 1) / 2;                          // pixel pairs per output row
+    const long q = (long)blockIdx.x * ST_PIX + threadIdx.x;
     const long Po = (long)ho * wo;
-    const bool valid = p < Po;
-    const int oy = valid ? (int)(p / wo) : 0, ox = valid ? (int)(p % wo) : 0;
-    float acc[32];
+    const bool valid0 = q < (long)ho * wo2;
+    const int oy = valid0 ? (int)(q / wo2) : 0, ox = valid0 ? 2 * (int)(q % wo2) : 0;
+    const bool valid1 = valid0 && ox + 1 < wo;
+    float acc0[32], acc1[32];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) acc[c] = bias[c];
+    for (int c = 0; c < 32; ++c) acc0[c] = acc1[c] = bias[c];
     const float* im = img + (long)n * 3 * H * W;
     for (int ci = 0; ci < 3; ++ci)
+#pragma unroll 1
         for (int ky = 0; ky < 7; ++ky) {
             const int iy = oy * 2 + ky - 3;
             if (iy < 0 || iy >= H) continue;
-#pragma unroll 1
-            for (int kx = 0; kx < 7; ++kx) {
-                const int ix = ox * 2 + kx - 3;
+            // the two pixels' 7-tap windows overlap in 5 columns: 9 loads feed 14 taps, and every weight vector is used twice
+            float xr[9];
+            const float* row = im + ((long)ci * H + iy) * W;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int ix = ox * 2 + j - 3;
                 float x = 0.f;
                 if (ix >= 0 && ix < W) {
-                    x = im[((long)ci * H + iy) * W + ix];
+                    x = row[ix];
                     if (normalize) x = x * (2.0f / 255.0f) - 1.0f;
                 }
+                xr[j] = x;
+            }
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
                 // wave-uniform address: the 32 weights of this tap arrive through the scalar cache (s_load), no LDS traffic
                 const float* wr = wgt + ((ci * 7 + ky) * 7 + kx) * 32;
+                const st_float2 x0 = {xr[kx], xr[kx]}, x1 = {xr[kx + 2], xr[kx + 2]};
 #pragma unroll
-                for (int c = 0; c < 32; ++c) acc[c] = fmaf(x, wr[c], acc[c]);
+                for (int c = 0; c < 16; ++c) {               // v_pk_fma_f32: each component is the same fused multiply-add as fmaf
+                    const st_float2 ww = {wr[2 * c], wr[2 * c + 1]};
+                    st_float2 a = {acc0[2 * c], acc0[2 * c + 1]}, b = {acc1[2 * c], acc1[2 * c + 1]};
+                    a = __builtin_elementwise_fma(x0, ww, a);
+                    b = __builtin_elementwise_fma(x1, ww, b);
+                    acc0[2 * c] = a.x; acc0[2 * c + 1] = a.y;
+                    acc1[2 * c] = b.x; acc1[2 * c + 1] = b.y;
+                }
             }
         }
-    if (valid) {
-        float* o = out + ((long)n * Po + p) * 32;
+    if (valid0) {
+        float* o = out + ((long)n * Po + (long)oy * wo + ox) * 32;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(o + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        for (int k = 0; k < 8; ++k) *reinterpret_cast<float4*>(o + 4 * k) = make_float4(acc0[4 * k], acc0[4 * k + 1], acc0[4 * k + 2], acc0[4 * k + 3]);
+        if (valid1) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                *reinterpret_cast<float4*>(o + 32 + 4 * k) = make_float4(acc1[4 * k], acc1[4 * k + 1], acc1[4 * k + 2], acc1[4 * k + 3]);
+        }
     }
     if (part) {
         // 64 values per lane (32 sums, 32 sums of squares) -> butterfly: 63 exchanges leave the wave total of value l on lane l
@@ -480,8 +504,9 @@ __global__ __launch_bounds__(ST_PIX) void enc_stem_kernel(const float* __restric
         float v[64];
 #pragma unroll
         for (int c = 0; c < 32; ++c) {
-            v[c] = valid ? acc[c] : 0.f;
-            v[32 + c] = valid ? acc[c] * acc[c] : 0.f;
+            const float a = valid0 ? acc0[c] : 0.f, b = valid1 ? acc1[c] : 0.f;
+            v[c] = a + b;
+            v[32 + c] = a * a + b * b;
         }
 #pragma unroll
         for (int hb = 32; hb >= 1; hb >>= 1) {
@@ -504,7 +529,7 @@ __global__ __launch_bounds__(ST_PIX) void enc_stem_kernel(const float* __restric
     }
 }
 
-extern "C" int cer_enc_stem_tiles(int ho, int wo) { return (int)(((long)ho * wo + ST_PIX - 1) / ST_PIX); }
+extern "C" int cer_enc_stem_tiles(int ho, int wo) { return (int)(((long)ho * ((wo + 1) / 2) + ST_PIX - 1) / ST_PIX); }
 
 // wgt: [3*7*7][32] (ci, ky, kx major; output channel minor), device pointer
 extern "C" int cer_enc_stem_f32(const float* images, const float* wgt_k_co, const float* bias, float* out, float* stats_partial, int N, int H,

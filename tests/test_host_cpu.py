@@ -68,7 +68,7 @@ def test_argument_errors_of_the_conv_and_encoder_entry_points():
     assert lib.cer_enc_conv_f16x3(fake, null, 0, fake, null, fake, null, null, 1, 8, 8, 32, 32, 9, 2, 0, 0, 1.0, null) == -2   # stride 2 needs Cout % 64
     assert lib.cer_enc_conv_f16x3(null, null, 0, fake, null, fake, null, null, 1, 8, 8, 32, 32, 9, 1, 0, 0, 1.0, null) == -1
     assert lib.cer_enc_conv_tiles(296, 400, 1, 9, 64) == 13 * 37 and lib.cer_enc_conv_tiles(296, 400, 2, 9, 64) == 13 * 148
-    assert lib.cer_enc_stem_tiles(592, 800) == 1850
+    assert lib.cer_enc_stem_tiles(592, 800) == 925          # 592 rows x 400 pixel PAIRS / 256 threads
     assert lib.cer_enc_merge_f32(fake, null, null, null, fake, 1, 10, 30, 0, null) == -2                      # C % 4
     assert lib.cer_delta_sum_f32(null, 2, 0.0, fake, fake, null, 4, 4, null) == -1
     from cer_mvs_amd._lib import CopySegments
