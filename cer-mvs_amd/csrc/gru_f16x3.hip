@@ -30,6 +30,9 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+#ifndef HX_EPI2
+#define HX_EPI2 1     // epilogue through LDS with 16-byte global accesses (0: the direct 4-byte form, kept for A/B runs)
+#endif
 #ifndef HX_TH
 #define HX_TH 4                        // tile rows (8: experiment, one 8-wave block of 256 px per CU)
 #endif
@@ -242,10 +245,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = 0.f;
             if (a.init && !(HX_ABL & 8)) {
+                // (with the LDS epilogue the hoisted term is added there, through 16-byte loads)
+                if (!HX_EPI2 || EPI == HX_EPI_DELTA) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int gx = tx0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                    if (gy < a.h && gx < a.w) v[r] = a.init[((long)gy * a.w + gx) * a.cout + co];
+                    for (int r = 0; r < 16; ++r) {
+                        const int gx = tx0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                        if (gy < a.h && gx < a.w) v[r] = a.init[((long)gy * a.w + gx) * a.cout + co];
+                    }
                 }
             } else if (a.bias) {
                 const float b = a.bias[co];
@@ -454,6 +460,61 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
                 for (int idx = lane; idx < 9 * 32; idx += 64) {
                     const int tap = idx >> 5, gx = tx0 + (idx & 31);
                     if (gx < a.w) a.out[((long)blockIdx.y * 9 + tap) * a.h * a.w + (long)gy * a.w + gx] = Tl[idx];
+                }
+            }
+        }
+        return;
+    }
+    if constexpr (HX_EPI2 != 0) {
+        // Each wave transposes its tile through a private LDS patch (the activation / weight buffers are free now): the MFMA
+        // layout gives a lane one channel of 16 pixels, i.e. 4-byte accesses 512 B apart; after the transpose a lane owns 4
+        // consecutive channels of a pixel, so `init`, `aux`, `aux2` and the outputs move as 16-byte accesses (4x fewer
+        // vector-memory instructions - the epilogue is issue-bound, not bandwidth-bound).
+        constexpr int CW = WN * 32;                        // channels of a wave
+        constexpr int PITCH = CW + 4;                      // floats per pixel row of the patch
+        static_assert((long)NWAVES * 32 * PITCH * 4 <= (long)HX_A_BYTES + (long)NBUF * B_BYTES, "epilogue patch does not fit");
+        float* Et = reinterpret_cast<float*>(hx_smem) + wave * (32 * PITCH);
+        __syncthreads();                                   // main loop finished everywhere: LDS can be reused
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Et[((r & 3) + 8 * (r >> 2) + 4 * kg) * PITCH + n * 32 + li] = fmaf(accl[m][n][r], 1.0f / 2048.0f, accm[m][n][r]);
+            __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the patch is wave-private
+            const int gy = ty0 + wm * WM + m;
+            constexpr int G = CW / 4;                      // 4-channel groups per pixel
+#pragma unroll
+            for (int j = 0; j < 32 * G / 64; ++j) {
+                const int idx = lane + 64 * j;
+                const int px = idx / G, g = idx - px * G;
+                const int gx = tx0 + px;
+                float4 v = *reinterpret_cast<const float4*>(Et + px * PITCH + 4 * g);
+                if (gy >= a.h || gx >= a.w) continue;
+                const long pix = (long)gy * a.w + gx;
+                const int co = nb0 + wn * CW + 4 * g;
+                if (a.init) {
+                    const float4 t = cer_ld4(a.init + pix * a.cout + co);
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                if (EPI == CER_EPI_LINEAR) {
+                    *reinterpret_cast<float4*>(a.out + pix * a.cout + co) = v;
+                } else if (EPI == CER_EPI_RELU) {
+                    *reinterpret_cast<float4*>(a.out + pix * a.cout + co) = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                } else if (EPI == CER_EPI_GATES) {
+                    const float4 gt = make_float4(hx_sigmoid(v.x), hx_sigmoid(v.y), hx_sigmoid(v.z), hx_sigmoid(v.w));
+                    if (co < half) {
+                        *reinterpret_cast<float4*>(a.out + pix * half + co) = gt;
+                    } else {
+                        const float4 hp = cer_ld4(a.aux + pix * half + (co - half));
+                        *reinterpret_cast<float4*>(a.out2 + pix * half + (co - half)) = make_float4(gt.x * hp.x, gt.y * hp.y, gt.z * hp.z, gt.w * hp.w);
+                    }
+                } else if (EPI == CER_EPI_GRU) {
+                    const float4 z = cer_ld4(a.aux2 + pix * a.cout + co), hp = cer_ld4(a.aux + pix * a.cout + co);
+                    *reinterpret_cast<float4*>(a.out + pix * a.cout + co) =
+                        make_float4((1.0f - z.x) * hp.x + z.x * tanhf(v.x), (1.0f - z.y) * hp.y + z.y * tanhf(v.y),
+                                    (1.0f - z.z) * hp.z + z.z * tanhf(v.z), (1.0f - z.w) * hp.w + z.w * tanhf(v.w));
                 }
             }
         }
