@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void enc_conv_kernel(
                 if (gy >= a.ho || gx >= a.wo) continue;
                 const float v = fmaf(accl[m][n][r], 1.0f / 2048.0f, accm[m][n][r]);
                 if (EPI == EC_EPI_RAW) {
-                    a.out[(((long)img * a.ho + gy) * a.wo + gx) * a.cout + co] = v;
+                    // (the store itself goes through the LDS transpose below: 16-byte accesses)
                     ssum[n] += v;
                     ssq[n] = fmaf(v, v, ssq[n]);
                 } else if (EPI == EC_EPI_FMAP) {
@@ -222,9 +222,35 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void enc_conv_kernel(
             }
         }
     }
+    if (EPI == EC_EPI_RAW) {
+        // raw output through a wave-private LDS transpose: the MFMA layout gives a lane one channel of 16 pixels (4-byte stores
+        // 4*Cout bytes apart); afterwards a lane owns 4 consecutive channels of a pixel and stores 16 bytes
+        constexpr int CW = WN * 32, PITCH = CW + 4, G = CW / 4;
+        float* Et = reinterpret_cast<float*>(ec_smem) + (threadIdx.x >> 6) * (32 * PITCH);
+        __syncthreads();                                   // A/B LDS no longer needed
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Et[((r & 3) + 8 * (r >> 2) + 4 * kg) * PITCH + n * 32 + li] = fmaf(accl[m][n][r], 1.0f / 2048.0f, accm[m][n][r]);
+            __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the patch is wave-private
+            const int gy = ty0 + wm * WM + m;
+#pragma unroll
+            for (int j = 0; j < 32 * G / 64; ++j) {
+                const int idx = (threadIdx.x & 63) + 64 * j;
+                const int px = idx / G, g = idx - px * G;
+                const int gx = tx0 + px;
+                const float4 v = *reinterpret_cast<const float4*>(Et + px * PITCH + 4 * g);
+                if (gy < a.ho && gx < a.wo)
+                    *reinterpret_cast<float4*>(a.out + (((long)img * a.ho + gy) * a.wo + gx) * a.cout + nb0 + wn * CW + 4 * g) = v;
+            }
+        }
+    }
     if (EPI == EC_EPI_RAW && a.part) {
         // per-block partial statistics for the next instance norm: combine lane halves, then the WAVES_M waves through LDS
-        __syncthreads();                                   // A/B LDS no longer needed
+        __syncthreads();                                   // the transpose patches are no longer needed
         float* red = reinterpret_cast<float*>(ec_smem);    // [WAVES_M][NB][2]
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
@@ -287,6 +313,8 @@ static int ec_launch(EncArgs a, int nimg, int epi, hipStream_t st) {
     size_t smem = (size_t)HH * HW * EC_AS + NBUF * NB * 128;
     const size_t red = (size_t)WAVES_M * NB * 2 * sizeof(float);
     if (smem < red) smem = red;
+    const size_t patch = (size_t)WAVES_M * WAVES_N * 32 * (WN * 32 + 4) * sizeof(float);   // epilogue transpose patches
+    if (smem < patch) smem = patch;
     a.tiles_x = (a.wo + 31) / 32;
     const int tiles_y = (a.ho + TH - 1) / TH;
     a.nblk = a.tiles_x * tiles_y;
