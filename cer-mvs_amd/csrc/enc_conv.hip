@@ -17,6 +17,9 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+#ifndef ES_STREAM
+#define ES_STREAM 1                    // 32 -> 32 3x3 stride-1 convolutions through the persistent streaming kernel (0: tiled kernel)
+#endif
 #define EC_AS 144                      // LDS bytes per halo pixel: 32 hi | 32 lo | 16 pad
 #define EC_EPI_RAW 0                   // out = conv + bias (raw, pre-norm), optional stats partials
 #define EC_EPI_FMAP 1                  // out = (conv + bias) * scale into a (possibly bordered) channels-last map
@@ -137,16 +140,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void enc_conv_kernel(
                     const bool inside = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
                     float v[8] = {raw[i][0].x, raw[i][0].y, raw[i][0].z, raw[i][0].w, raw[i][1].x, raw[i][1].y, raw[i][1].z, raw[i][1].w};
                     half8 hi, lo;
+                    float xv[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float x = tf ? (v[e] - mu[e]) * rs[e] : v[e];
                         if (a.tf_relu) x = fmaxf(x, 0.f);
-                        if (!inside) x = 0.f;             // zero padding of the (normalised) activation
-                        _Float16 h_, l_;
-                        ec_split(x, h_, l_);
-                        hi[e] = h_;
-                        lo[e] = l_;
+                        xv[e] = inside ? x : 0.f;         // zero padding of the (normalised) activation
                     }
+                    cer_split8(xv, hi, lo);
                     *reinterpret_cast<half8*>(ldsA + row * EC_AS + g * 16) = hi;
                     *reinterpret_cast<half8*>(ldsA + row * EC_AS + 64 + g * 16) = lo;
                 }
@@ -274,6 +275,180 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void enc_conv_kernel(
     }
 }
 
+// ---- streaming variant for the half-resolution 32 -> 32 3x3 stride-1 convolutions (layer 1: core/extractor.py:87,109-111) ----
+// These four convolutions per encoder move 1.3 GB each for 96 GFLOP: they are memory-streaming kernels, and in the tiled kernel
+// above every one of the 20 350 blocks re-fetches the same 36 KiB of weights and pays its own prologue and per-tap barriers.
+// Here persistent 4-wave blocks (two per CU, so that one block's VALU/LDS "commit" phase overlaps the other's MFMAs) keep all
+// nine taps' weights in LDS and walk over the 8 x 32-pixel tiles, each as two 4 x 32 halves:
+//   wait for the prefetched halo of the half (registers) -> normalise + split + write the LDS tile -> barrier -> issue the global
+//   loads of the NEXT half into registers -> 9 taps x 2 k16-steps of MFMAs, fragments requested two steps ahead, with NO barrier
+//   and NO vector memory (weights resident) -> barrier -> raw output through a wave-private transpose that overlays the tile
+//   (16-byte stores) -> barrier.
+// Same arithmetic, same tiling for the partial statistics (one record per 8 x 32 tile) as enc_conv_kernel<8,1,1,1,...>.
+#ifndef ES_ABL
+#define ES_ABL 0                        // profiling ablations: 1 no MFMA loop, 2 no commit (LDS tile not written), 4 no output stores, 8 no halo loads
+#endif
+#define ES_TH 8                         // tile rows (statistics granularity); processed as two halves of ES_SH rows
+#define ES_SH 4
+#define ES_HH (ES_SH + 2)
+#define ES_HW 34
+#define ES_ROWS (ES_HH * ES_HW)                 // 204 halo pixels
+#define ES_A_BYTES (ES_ROWS * EC_AS)            // 29 376
+#define ES_B_BYTES (9 * 4096)                   // nine taps x (32 ch x 32 k x hi|lo) halves
+#define ES_NTHR 256
+__global__ __launch_bounds__(ES_NTHR, 2) void enc_conv32_stream_kernel(const EncArgs a, int total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char ec_smem[];
+    char* ldsA = ec_smem;
+    char* ldsB = ec_smem + ES_A_BYTES;
+    float* red = reinterpret_cast<float*>(ec_smem + ES_A_BYTES + ES_B_BYTES);      // [4 waves][32][2]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, kg = lane >> 5;
+    const int g = threadIdx.x & 3, prow0 = threadIdx.x >> 2;
+    constexpr int ITEMS = (ES_ROWS * 4 + ES_NTHR - 1) / ES_NTHR;       // 4
+    constexpr int RSTEP = ES_NTHR / 4;
+    static_assert(4 * 32 * 36 * 4 <= ES_A_BYTES, "transpose patches overlay the activation tile");
+    // all nine taps' weights: 36 pieces of 1 KiB, once per block
+    for (int piece = wave; piece < 36; piece += 4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.wpk + piece * 512 + lane * 8),
+                                         (__attribute__((address_space(3))) void*)(ldsB + piece * 1024), 16, 0, 0);
+    const float bias = a.bias ? a.bias[li] : 0.f;
+    float4 raw[ITEMS][2];
+    auto issue = [&](int hf) {                             // global loads of half-tile hf's halo (addresses clamped; masked at commit)
+        const int t = hf >> 1;
+        const int img = t / a.nblk, tile = t - img * a.nblk;
+        const int ty0 = (tile / a.tiles_x) * ES_TH + (hf & 1) * ES_SH, tx0 = (tile % a.tiles_x) * 32;
+        const float* src = a.src + (long)img * a.h * a.w * 32;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int row = min(prow0 + RSTEP * i, ES_ROWS - 1);
+            const int hy = row / ES_HW, hx = row - hy * ES_HW;
+            const int gy = min(max(ty0 + hy - 1, 0), a.h - 1), gx = min(max(tx0 + hx - 1, 0), a.w - 1);
+            const float* p = src + ((long)gy * a.w + gx) * 32 + 8 * g;
+            raw[i][0] = cer_ld4(p);
+            raw[i][1] = cer_ld4(p + 4);
+        }
+    };
+    int t = blockIdx.x;
+    if (t < total_tiles) issue(2 * t);
+    int cur_img = -1;
+    float mu[8], rs[8];
+    for (; t < total_tiles; t += gridDim.x) {
+        const int img = t / a.nblk, tile = t - img * a.nblk;
+        const int tx0 = (tile % a.tiles_x) * 32;
+        if (img != cur_img) {                              // producer statistics of this image (block-uniform branch)
+            cur_img = img;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                mu[e] = a.tf ? a.tf[2 * ((long)img * 32 + 8 * g + e)] : 0.f;
+                rs[e] = a.tf ? a.tf[2 * ((long)img * 32 + 8 * g + e) + 1] : 1.f;
+            }
+        }
+        float ssum = 0.f, ssq = 0.f;
+#pragma unroll 1
+        for (int sub = 0; sub < 2; ++sub) {
+            const int ty0 = (tile / a.tiles_x) * ES_TH + sub * ES_SH;
+            // ---- commit the prefetched halo: transform + split + LDS write
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const int row = prow0 + RSTEP * i;
+                if (row < ES_ROWS && !(ES_ABL & 2)) {
+                    const int hy = row / ES_HW, hx = row - hy * ES_HW;
+                    const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+                    const bool inside = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+                    const float v[8] = {raw[i][0].x, raw[i][0].y, raw[i][0].z, raw[i][0].w, raw[i][1].x, raw[i][1].y, raw[i][1].z, raw[i][1].w};
+                    half8 hi, lo;
+                    float xv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float x = a.tf ? (v[e] - mu[e]) * rs[e] : v[e];
+                        if (a.tf_relu) x = fmaxf(x, 0.f);
+                        xv[e] = inside ? x : 0.f;
+                    }
+                    cer_split8(xv, hi, lo);
+                    *reinterpret_cast<half8*>(ldsA + row * EC_AS + g * 16) = hi;
+                    *reinterpret_cast<half8*>(ldsA + row * EC_AS + 64 + g * 16) = lo;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): (first half) the weight DMAs have landed
+            __syncthreads();                               // tile (and weights) visible to every wave
+            {                                              // next half's halo travels during the MFMAs
+                const int nh = sub == 0 ? 2 * t + 1 : 2 * (t + (int)gridDim.x);
+                if (nh < 2 * total_tiles && !(ES_ABL & 8)) issue(nh);
+            }
+            // ---- 9 taps x 2 k16-steps, weights resident: no barrier, no vector memory.  Software pipeline in source: the
+            // fragments of step i+2 are requested before the MFMAs of step i and the scheduler is fenced per step - left alone,
+            // hipcc places every ds_read directly in front of the MFMA that needs it and pays the LDS latency 36 times per tile
+            floatx16 accm, accl;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accm[r] = bias; accl[r] = 0.f; }
+            half8 fa[3][2], fb[3][2];                      // [buffer][hi|lo]
+            auto load = [&](int buf, int i) {
+                const int tap = i >> 1, ks = i & 1, dy = tap / 3, dx = tap - dy * 3;
+                const char* p = ldsA + ((wave + dy) * ES_HW + li + dx) * EC_AS + ks * 32 + kg * 16;
+                fa[buf][0] = *reinterpret_cast<const half8*>(p);
+                fa[buf][1] = *reinterpret_cast<const half8*>(p + 64);
+                const char* q = ldsB + tap * 4096 + (ks * 2) * 1024 + lane * 16;
+                fb[buf][0] = *reinterpret_cast<const half8*>(q);
+                fb[buf][1] = *reinterpret_cast<const half8*>(q + 1024);
+            };
+            load(0, 0);
+            load(1, 1);
+#pragma unroll
+            for (int i = 0; i < ((ES_ABL & 1) ? 1 : 18); ++i) {
+                if (i + 2 < 18) load((i + 2) % 3, i + 2);
+                __builtin_amdgcn_sched_barrier(0);         // the requests stay in front of this step's MFMAs
+                const int b = i % 3;
+                accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[b][0], fb[b][0], accm, 0, 0, 0);
+                accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[b][0], fb[b][1], accl, 0, 0, 0);
+                accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[b][1], fb[b][0], accl, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();                               // every wave is done reading the tile: the patches may overlay it
+            // ---- epilogue: statistics in the MFMA layout, raw output through the transpose
+            const int gy = ty0 + wave;
+            float* Et = reinterpret_cast<float*>(ldsA) + wave * (32 * 36);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int px = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const float v = fmaf(accl[r], 1.0f / 2048.0f, accm[r]);
+                Et[px * 36 + li] = v;
+                if (gy < a.ho && tx0 + px < a.wo) {
+                    ssum += v;
+                    ssq = fmaf(v, v, ssq);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);            // the patch is wave-private
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = lane + 64 * j;
+                const int px = idx >> 3, g4 = idx & 7;
+                const float4 v = *reinterpret_cast<const float4*>(Et + px * 36 + 4 * g4);
+                if (gy < a.ho && tx0 + px < a.wo && !(ES_ABL & 4))
+                    *reinterpret_cast<float4*>(a.out + (((long)img * a.ho + gy) * a.wo + tx0 + px) * 32 + 4 * g4) = v;
+            }
+            if (a.part && sub == 1) {
+                const float s2 = ssum + __shfl_xor(ssum, 32), q2 = ssq + __shfl_xor(ssq, 32);
+                if (kg == 0) {
+                    red[(wave * 32 + li) * 2 + 0] = s2;
+                    red[(wave * 32 + li) * 2 + 1] = q2;
+                }
+            }
+            __syncthreads();                               // patches read back: the tile may be rewritten; partials visible
+        }
+        if (a.part && threadIdx.x < 32) {
+            float s2 = 0.f, q2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s2 += red[(i * 32 + threadIdx.x) * 2 + 0];
+                q2 += red[(i * 32 + threadIdx.x) * 2 + 1];
+            }
+            float* dst = a.part + (((long)img * a.nblk + tile) * 32 + threadIdx.x) * 2;
+            dst[0] = s2;
+            dst[1] = q2;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // generic weight packing: OIHW [Cout, Cin, k, k] (k = 1 or 3) -> [chunk32][tap][ntile32][k16-step][hi|lo][lane][8]
 extern "C" long cer_enc_conv_packed_size(int Cout, int Cin, int taps) {
@@ -363,6 +538,28 @@ extern "C" int cer_enc_conv_f16x3(const float* src, const float* tf_stats, int t
     a.out_border = out_border;
     a.out_scale = out_scale;
     hipStream_t st = (hipStream_t)stream;
+    if (stride == 1 && taps == 9 && Cin == 32 && Cout == 32 && epi == EC_EPI_RAW && ES_STREAM) {
+        // layer-1 shape: persistent streaming kernel, two 4-wave blocks per CU
+        a.tiles_x = (a.wo + 31) / 32;
+        a.nblk = a.tiles_x * ((a.ho + ES_TH - 1) / ES_TH);
+        const long total = (long)a.nblk * N;
+        if (total >= (1L << 31)) return CER_ESHAPE;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        }
+        const size_t smem = ES_A_BYTES + ES_B_BYTES + 4 * 32 * 2 * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)enc_conv32_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+                return CER_EINVAL;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(enc_conv32_stream_kernel, dim3((unsigned)(total < 2 * cus ? total : 2 * cus)), dim3(ES_NTHR), smem, st, a, (int)total);
+        CER_RETURN_IF_LAUNCH_FAILED();
+        return CER_OK;
+    }
     if (stride == 1 && taps == 9) {
         if (Cout % 64 == 0) return ec_launch<8, 1, 1, 2, 3, 4, 8, 1, 9>(a, N, epi, st);       // 8 x 32 px x 64 ch per block
         return ec_launch<8, 1, 1, 1, 3, 4, 8, 1, 9>(a, N, epi, st);                            // 8 x 32 px x 32 ch

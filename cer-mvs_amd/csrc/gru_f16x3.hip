@@ -90,13 +90,7 @@ __device__ __forceinline__ void hx_split(float v, _Float16& hi, _Float16& lo) {
 
 __device__ __forceinline__ void hx_write8(char* __restrict__ ldsA, int row, int g, const float (&v)[8]) {
     half8 hi, lo;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        _Float16 h, l;
-        hx_split(v[i], h, l);
-        hi[i] = h;
-        lo[i] = l;
-    }
+    cer_split8(v, hi, lo);                                 // packed conversions (common.hpp)
     *reinterpret_cast<half8*>(ldsA + row * HX_AS + g * 16) = hi;
     *reinterpret_cast<half8*>(ldsA + row * HX_AS + 64 + g * 16) = lo;
 }
