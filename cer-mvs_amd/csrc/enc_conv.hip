@@ -49,7 +49,7 @@ __device__ __forceinline__ void ec_split(float v, _Float16& hi, _Float16& lo) {
 
 template <int NB, int NWAVES>
 __device__ __forceinline__ void ec_issue_B(char* __restrict__ ldsB, const _Float16* __restrict__ slice) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
     constexpr int PIECES = NB / 8;
 #pragma unroll
     for (int i = 0; i < (PIECES + NWAVES - 1) / NWAVES; ++i) {
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void enc_conv_kernel(
     const int tile = blockIdx.x;
     const int ty0 = (tile / a.tiles_x) * TH, tx0 = (tile % a.tiles_x) * 32;      // output coordinates
     const int nb0 = blockIdx.y * NB;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int li = lane & 31, kg = lane >> 5;
     const int NT = a.cout / 32;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(ES_NTHR, 2) void enc_conv32_stream_kernel(const Enc
     char* ldsA = ec_smem;
     char* ldsB = ec_smem + ES_A_BYTES;
     float* red = reinterpret_cast<float*>(ec_smem + ES_A_BYTES + ES_B_BYTES);      // [4 waves][32][2]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
     const int li = lane & 31, kg = lane >> 5;
     const int g = threadIdx.x & 3, prow0 = threadIdx.x >> 2;
     constexpr int ITEMS = (ES_ROWS * 4 + ES_NTHR - 1) / ES_NTHR;       // 4
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(ST_PIX) void enc_stem_kernel(const float* __restric
     if (part) {
         // 64 values per lane (32 sums, 32 sums of squares) -> butterfly: 63 exchanges leave the wave total of value l on lane l
         // (a plain 6-step shuffle reduction per value was 768 ds_bpermute per wave and dominated the kernel)
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
         float v[64];
 #pragma unroll
         for (int c = 0; c < 32; ++c) {

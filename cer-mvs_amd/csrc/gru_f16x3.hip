@@ -181,7 +181,7 @@ __device__ __forceinline__ void hx_stage_disp9(char* __restrict__ ldsA, const fl
 // DMA the block's weight slice of one (chunk, tap) step into an LDS ring slot: NB/8 pieces of 1 KiB
 template <int NB, int NWAVES>
 __device__ __forceinline__ void hx_issue_B(char* __restrict__ ldsB, const _Float16* __restrict__ slice) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
 #pragma unroll
     for (int i = 0; i < NB / 8 / NWAVES; ++i) {
         const int piece = wave + NWAVES * i;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
     const int tile = blockIdx.x;
     const int ty0 = (tile / a.tiles_x) * HX_TH, tx0 = (tile % a.tiles_x) * HX_TW;
     const int nb0 = blockIdx.y * NB;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int li = lane & 31, kg = lane >> 5;
     const int NT = a.cout / 32;
@@ -365,6 +365,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
                             bh[n] = *reinterpret_cast<const half8*>(p);
                             bl[n] = *reinterpret_cast<const half8*>(p + 1024);
                         }
+#if defined(HX_FENCE)
+                        __builtin_amdgcn_sched_barrier(0);   // all fragment requests of this k16-step stay in front of its MFMAs
+#endif
 #pragma unroll
                         for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -380,6 +383,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
                                 }
                             }
                         if (ks == 0) HX_STAMP(2);
+#if defined(HX_FENCE)
+                        __builtin_amdgcn_sched_barrier(0);
+#endif
                     }
                 }
 #if HX_TRACE
