@@ -365,9 +365,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
                             bh[n] = *reinterpret_cast<const half8*>(p);
                             bl[n] = *reinterpret_cast<const half8*>(p + 1024);
                         }
-#if defined(HX_FENCE)
-                        __builtin_amdgcn_sched_barrier(0);   // all fragment requests of this k16-step stay in front of its MFMAs
-#endif
 #pragma unroll
                         for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -383,9 +380,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
                                 }
                             }
                         if (ks == 0) HX_STAMP(2);
-#if defined(HX_FENCE)
-                        __builtin_amdgcn_sched_barrier(0);
-#endif
                     }
                 }
 #if HX_TRACE
