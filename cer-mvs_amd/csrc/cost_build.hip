@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void cost_build_kernel(const float* __restrict
     // contiguous band of image rows - its private 4 MiB L2 then sees 1/8 of every source map instead of all of it.
     const unsigned nblk = gridDim.x, q8 = nblk / 8, r8 = nblk % 8, xcd = blockIdx.x % 8, within = blockIdx.x / 8;
     const unsigned bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
-    const long p = (long)bid * 4 + (threadIdx.x >> 6);
+    const long p = (long)bid * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform pixel index in SGPRs
     if (p >= P) return;                                    // wave-uniform
     const int sub = lane & 15, cx = (lane >> 4) & 1, cy = lane >> 5;
     const float px = (float)(p % w1), py = (float)(p / w1 + y0);     // y0: first image row of a row slab (multi-GPU)
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void cost_build_kernel(const float* __restrict
     const long P2C = (long)(h2 + 4) * wp * C;
     const int loff = (cy * wp + cx) * C + 4 * sub;         // this lane's corner + channel quad
     __shared__ __attribute__((aligned(16))) float wl_all[4][4 * 64];     // per wave: [corner][hypothesis] bilinear weights
-    float* wl = wl_all[threadIdx.x >> 6];
+    float* wl = wl_all[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
     const int corner = cy * 2 + cx;
     const int v_lo = SUM ? 0 : (int)blockIdx.y, v_hi = SUM ? V : (int)blockIdx.y + 1;
     float* orow = SUM ? vol + p * rs : vol + ((long)blockIdx.y * P + p) * rs;
