@@ -252,6 +252,13 @@ def main():
         rec = kernel_timing(model, inputs, scale)
     if rank == 0:
         P = (H // 4) * (W // 4)
+        if shard and args.mode == "shard":
+            # row-slab sharding: rank 0's kernels process its owned rows plus the halo, not the whole image - the per-launch
+            # roofline figures below are per rank and must use that pixel count
+            from cer_mvs_amd import slab as _slab
+            if _slab.can_shard(H // 4, world):
+                _, _, e0, e1 = _slab.slab_bounds(H // 4, world, 0)
+                P = (e1 - e0) * (W // 4)
         kern = {k: {"launches": n, "avg_us": 1e3 * t / n, "total_ms": t} for k, (n, t) in sorted(rec.items())}
         n_zr, t_zr = rec["conv3x3_gates_zr"]
         flops_zr = 2.0 * 9 * (64 + 49 + 64) * 128 * P            # algorithmic (unpadded K = net|disp49|corr), DESIGN.md
