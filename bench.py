@@ -306,6 +306,16 @@ def main():
             "roofline": roofline, "roofline_hbm_kernel": hbm, "kernels": kern,
             "peak_device_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
         }
+        # parity of THIS run's output: the default workload with the default seeds is exactly the configuration the reference
+        # was captured on (tests/golden/e2e_cfg2.npz, tools/gen_golden.py --only e2e_cfg2); committed fixture, no reference needed
+        gpath = os.path.join(REPO, "tests", "golden", "e2e_cfg2.npz")
+        if args.workload == "dtu_1600x1184_v10_it32" and (world == 1 or shard) and os.path.exists(gpath):
+            import numpy as np
+            ref = torch.from_numpy(np.load(gpath)["disp"]).double()
+            got = out.detach().cpu().double()
+            if got.shape == ref.shape:
+                result["parity"] = {"rel_l1_disparity_vs_reference_capture": float((got - ref).abs().sum() / ref.abs().sum()),
+                                    "tolerance": 1e-4, "fixture": "tests/golden/e2e_cfg2.npz"}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(H, W, V, cascade, {k: v.cpu() for k, v in sd.items()})
         else:

@@ -501,6 +501,15 @@ def test_end_to_end_cfg1(dev, golden, gru_precision):
     assert e_disp < TOL and e_depth < TOL
 
 
+def test_end_to_end_cfg2_bench_workload(dev, golden):
+    """BASELINE.json configs[1] - the bench workload itself: 1600x1184, 10 source views, cascade (64,64,16),(-1,320,16) =
+    32 GRU iterations, same scene / weight seeds as bench.py - against the reference's own output on it
+    (tools/gen_golden.py --only e2e_cfg2: 2.5 minutes of the reference on 8 CPU cores)."""
+    e_disp, e_depth = _run_e2e(dev, golden, "e2e_cfg2")
+    print(f"e2e_cfg2 rel-L1 disp {e_disp:.3e} depth {e_depth:.3e}")
+    assert e_disp < TOL and e_depth < TOL
+
+
 @pytest.mark.parametrize("name,G", [("e2e_tiny", 2), ("e2e_cfg1", 2), ("e2e_cfg1", 3), ("e2e_cfg1", 8)])
 def test_slab_sharded_forward_matches_reference_capture(dev, golden, name, G):
     """The multi-GPU row-slab algorithm (slab.py) with G ranks simulated in one process: same kernels, same halo

@@ -233,9 +233,14 @@ def main():
         "e2e_cfg1": lambda: gen_e2e("e2e_cfg1", 480, 640, 2, [(64, 64, 2), (-1, 320, 2)], seed=0),
         "caller": gen_caller,
     }
+    # BASELINE.json configs[1] - the bench workload itself (1600x1184, 10 source views, 32 GRU iterations; same scene and weight
+    # seeds as bench.py).  Minutes of CPU time, so only on request: --only e2e_cfg2
+    big = {"e2e_cfg2": lambda: gen_e2e("e2e_cfg2", 1184, 1600, 10, [(64, 64, 16), (-1, 320, 16)], seed=0)}
     for name, fn in jobs.items():
         if args.only in (None, name):
             fn()
+    if args.only in big:
+        big[args.only]()
 
 
 if __name__ == "__main__":
