@@ -28,3 +28,15 @@ def rel_l1(a, b):
     a = torch.as_tensor(a, dtype=torch.float64)
     b = torch.as_tensor(b, dtype=torch.float64)
     return float((a - b).abs().sum() / b.abs().sum().clamp_min(1e-300))
+
+
+_SCENES = {}
+
+
+def cached_scene(H, W, V, seed):
+    """synthetic_scene is pure numpy value noise (10 s at 1600x1184 x 11 views): generate once per session, hand out clones."""
+    from cer_mvs_amd.synthetic import synthetic_scene
+    key = (H, W, V, seed)
+    if key not in _SCENES:
+        _SCENES[key] = synthetic_scene(H, W, V, seed=seed)
+    return tuple(t.clone() for t in _SCENES[key])

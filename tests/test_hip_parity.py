@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_l1
+from conftest import cached_scene, rel_l1
 from test_oracle_golden import blank_state_dict, hashed
 
 pytestmark = pytest.mark.gpu
@@ -462,7 +462,7 @@ def _run_e2e(dev, golden, name, literal=False, gru_precision="f16x3"):
     g = golden(name)
     H, W, V = int(g["H"]), int(g["W"]), int(g["V"])
     cascade = [tuple(int(x) for x in c) for c in g["cascade"]]
-    images, poses, intr, scale = synthetic_scene(H, W, V, seed=int(g["scene_seed"]))
+    images, poses, intr, scale = cached_scene(H, W, V, int(g["scene_seed"]))
     assert tensor_checksum(images) == int(g["images_checksum"])
     model = RAFT(cascade=cascade, test_mode=True, gru_precision=gru_precision)
     model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(g["weight_seed"])))
@@ -510,7 +510,7 @@ def test_end_to_end_cfg2_bench_workload(dev, golden):
     assert e_disp < TOL and e_depth < TOL
 
 
-@pytest.mark.parametrize("name,G", [("e2e_tiny", 2), ("e2e_cfg1", 2), ("e2e_cfg1", 3), ("e2e_cfg1", 8)])
+@pytest.mark.parametrize("name,G", [("e2e_tiny", 2), ("e2e_cfg1", 2), ("e2e_cfg1", 3), ("e2e_cfg1", 8), ("e2e_cfg2", 8), ("e2e_cfg2", 4)])
 def test_slab_sharded_forward_matches_reference_capture(dev, golden, name, G):
     """The multi-GPU row-slab algorithm (slab.py) with G ranks simulated in one process: same kernels, same halo
     bookkeeping, only the collective is replaced by list passing.  Must equal the captures like the 1-GPU path."""
@@ -519,7 +519,7 @@ def test_slab_sharded_forward_matches_reference_capture(dev, golden, name, G):
     g = golden(name)
     H, W, V = int(g["H"]), int(g["W"]), int(g["V"])
     cascade = [tuple(int(x) for x in c) for c in g["cascade"]]
-    images, poses, intr, scale = synthetic_scene(H, W, V, seed=int(g["scene_seed"]))
+    images, poses, intr, scale = cached_scene(H, W, V, int(g["scene_seed"]))
     model = RAFT(cascade=cascade, test_mode=True)
     model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(g["weight_seed"])))
     model = model.to(dev).eval()
