@@ -15,6 +15,7 @@ The loader tuple has the reference's shapes: ``images [1,V+1,3,H,W]`` float32 in
 (reference: datasets/dtu.py returns exactly this tuple; inference.py:42).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -90,7 +91,7 @@ def synthetic_scene(H, W, V, seed=0, depth=600.0, ring_deg=4.0, focal_factor=1.8
     images = np.zeros((V + 1, 3, H, W), dtype=np.float32)
     poses = np.zeros((V + 1, 4, 4), dtype=np.float64)
     centre = np.array([0.0, 0.0, depth])
-    for v in range(V + 1):
+    def render(v):                                         # views are independent: rendered by a small thread pool below
         if v == 0:
             R = np.eye(3)
             t = np.zeros(3)
@@ -120,6 +121,15 @@ def synthetic_scene(H, W, V, seed=0, depth=600.0, ring_deg=4.0, focal_factor=1.8
         for c in range(3):
             g = plane_texture(ux, uy, c, seed)
             images[v, c] = np.floor(g + 0.5).astype(np.float32)
+
+    workers = max(1, min(V + 1, (os.cpu_count() or 1) // 2, 16))
+    if workers > 1 and H * W >= 256 * 256:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(workers) as pool:
+            list(pool.map(render, range(V + 1)))
+    else:
+        for v in range(V + 1):
+            render(v)
     intr = np.broadcast_to(K, (V + 1, 3, 3)).copy()
     return (torch.from_numpy(images)[None].contiguous(),
             torch.from_numpy(poses.astype(np.float32))[None].contiguous(),

@@ -510,6 +510,16 @@ def test_end_to_end_cfg2_bench_workload(dev, golden):
     assert e_disp < TOL and e_depth < TOL
 
 
+@pytest.mark.parametrize("name", ["e2e_blended", "e2e_tnt"])
+def test_end_to_end_other_baseline_configs(dev, golden, name):
+    """BASELINE.json configs[4] (BlendedMVS 2048x1536, 7 source views) and configs[2] (Tanks&Temples 3840x2160, 15 source
+    views), 16 GRU iterations each, against the reference's own output (tools/gen_golden.py --only e2e_blended | e2e_tnt:
+    4 and 26 minutes of the reference on 8 CPU cores)."""
+    e_disp, e_depth = _run_e2e(dev, golden, name)
+    print(f"{name} rel-L1 disp {e_disp:.3e} depth {e_depth:.3e}")
+    assert e_disp < TOL and e_depth < TOL
+
+
 @pytest.mark.parametrize("name,G", [("e2e_tiny", 2), ("e2e_cfg1", 2), ("e2e_cfg1", 3), ("e2e_cfg1", 8), ("e2e_cfg2", 8), ("e2e_cfg2", 4)])
 def test_slab_sharded_forward_matches_reference_capture(dev, golden, name, G):
     """The multi-GPU row-slab algorithm (slab.py) with G ranks simulated in one process: same kernels, same halo

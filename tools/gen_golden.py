@@ -235,7 +235,11 @@ def main():
     }
     # BASELINE.json configs[1] - the bench workload itself (1600x1184, 10 source views, 32 GRU iterations; same scene and weight
     # seeds as bench.py).  Minutes of CPU time, so only on request: --only e2e_cfg2
-    big = {"e2e_cfg2": lambda: gen_e2e("e2e_cfg2", 1184, 1600, 10, [(64, 64, 16), (-1, 320, 16)], seed=0)}
+    big = {"e2e_cfg2": lambda: gen_e2e("e2e_cfg2", 1184, 1600, 10, [(64, 64, 16), (-1, 320, 16)], seed=0),
+           # BASELINE.json configs[4] (BlendedMVS 2048x1536, 7 source views) and configs[2] (Tanks&Temples 3840x2160, 15 source
+           # views) at the cascades of bench.py's workloads of the same names
+           "e2e_blended": lambda: gen_e2e("e2e_blended", 1536, 2048, 7, [(64, 64, 8), (-1, 320, 8)], seed=0),
+           "e2e_tnt": lambda: gen_e2e("e2e_tnt", 2160, 3840, 15, [(64, 64, 8), (-1, 320, 8)], seed=0)}
     for name, fn in jobs.items():
         if args.only in (None, name):
             fn()
