@@ -93,8 +93,40 @@ def main():
         t1 = 4.0 * 10 ** float(torch.rand(1, generator=g) * 2 - 1)
         gm, est = fusion.vote(dm[0].to(dev), ks[0, 0], ps[0, 0], dm[srcs].to(dev), ks[0, srcs], ps[0, srcs], t1, t1 * 325.0)
         om, oe = FO.vote(dm[0], ks[0, 0], ps[0, 0], dm[srcs], ks[0, srcs], ps[0, srcs], t1, t1 * 325.0)
-        note("fusion_mask_mismatch", float((gm.bool().cpu() != om).float().mean()), 5e-3, (Hh, Ww, S))
+        mism = gm.bool().cpu() != om
+        if mism.any():
+            # a mismatch is legitimate only at a pixel sitting on a threshold (ulp-level difference of the fp32 evaluation order):
+            # measure the smallest relative distance of that pixel's (dist, rel-depth) pair to any of the 9 thresholds, any view
+            drep, xr, yr, _, _ = FO.reproject_with_depth(dm[0][None].repeat(S, 1, 1), ks[0, 0][None].repeat(S, 1, 1), ps[0, 0][None].repeat(S, 1, 1),
+                                                          dm[srcs], ks[0, srcs], ps[0, srcs])
+            yy, xx = torch.meshgrid(torch.arange(Hh), torch.arange(Ww), indexing="ij")
+            dist = torch.sqrt((xr - xx[None]) ** 2 + (yr - yy[None]) ** 2)
+            rl = torch.abs(drep - dm[0][None]) / dm[0][None]
+            margin = torch.full((Hh, Ww), 1e9)
+            for i in range(2, 11):
+                m1 = ((dist - i / t1).abs() / (i / t1)).min(0).values
+                m2 = ((rl - i / (t1 * 325.0)).abs() / (i / (t1 * 325.0))).min(0).values
+                margin = torch.minimum(margin, torch.minimum(m1, m2))
+            # (dist = |reprojected pixel - pixel| is a difference of O(W) coordinates: its fp32 error is ~1e-6 * W absolute, i.e.
+            # up to ~1e-3 relative to a threshold of a few tenths of a pixel - that is the legitimate borderline band)
+            note("fusion_mismatch_margin", float(margin[mism].max()), 3e-3, (Hh, Ww, S))
+        note("fusion_mask_mismatch", float(mism.float().mean()), 2e-2, (Hh, Ww, S))
         note("fusion_depth", rel(est, oe), 1e-4, (Hh, Ww, S))
+    # ---- whole forward at random small sizes against the torch oracle (encoders + both stages + GRU)
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+    for it in range(max(1, args.iters // 10)):
+        H, W, V = 4 * ri(9, 30), 4 * ri(9, 40), ri(1, 3)
+        cascade = [(64, 64, ri(1, 2)), (-1, 320, ri(1, 2))]
+        images, poses, intr, scale = synthetic_scene(H, W, V, seed=100 + it)
+        model = RAFT(cascade=cascade, test_mode=True)
+        sd = fill_state_dict(model.state_dict(), seed=50 + it)
+        model.load_state_dict(sd)
+        model = model.to(dev).eval()
+        with torch.no_grad():
+            got = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale).cpu()
+            ref = O.raft_forward(sd, images, poses, intr, scale, cascade=cascade)
+        note("e2e_vs_oracle", rel(got, ref), 1e-4, (H, W, V, cascade))
     print("OK", {k: f"{v:.2e}" for k, v in worst.items()})
 
 
