@@ -127,3 +127,12 @@ def test_full_size_properties(dev):
     bad = (depths[src] * 1.2).contiguous()
     m2, e2 = fusion.vote(depths[0], K[0], E[0], bad, K[src], E[src], 4.0, 1300.0)
     assert m2.float().mean() < 1e-3 and rel_l1(e2.cpu(), depths[0].cpu()) < 1e-3
+    # against the CPU oracle at full size, at a tight threshold that cuts through the noise (mask area ~0.5): the mask may
+    # differ only in the borderline band (dist is a difference of O(W) coordinates), the averaged depth not at all
+    from oracle import fusion_oracle as FO
+    noisy = synthetic_depth_maps(H, W, V, seed=1)
+    gm, est = fusion.vote(noisy[0].to(dev), K[0], E[0], noisy[src].to(dev), K[src], E[src], 33.0, 33.0 * 325)
+    om, oe = FO.vote(noisy[0], K[0], E[0], noisy[src], K[src], E[src], 33.0, 33.0 * 325)
+    assert 0.2 < om.float().mean() < 0.8
+    assert (gm.bool().cpu() != om).float().mean() < 2e-3
+    assert rel_l1(est.cpu(), oe) < 1e-6
