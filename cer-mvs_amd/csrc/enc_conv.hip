@@ -288,6 +288,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void enc_conv_kernel(
 #ifndef ES_ABL
 #define ES_ABL 0                        // profiling ablations: 1 no MFMA loop, 2 no commit (LDS tile not written), 4 no output stores, 8 no halo loads
 #endif
+#ifndef ES_TRACE
+#define ES_TRACE 0                      // debug build: per-wave phase cycle sums (s_memtime) written to a.out2 [blocks][4 waves][16] (u64)
+#endif
+#if ES_TRACE
+#define ES_T(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tsum[k] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define ES_T(k) do { } while (0)
+#endif
 #define ES_TH 8                         // tile rows (statistics granularity); processed as two halves of ES_SH rows
 #define ES_SH 4
 #define ES_HH (ES_SH + 2)
@@ -332,6 +340,10 @@ __global__ __launch_bounds__(ES_NTHR, 2) void enc_conv32_stream_kernel(const Enc
     if (t < total_tiles) issue(2 * t);
     int cur_img = -1;
     float mu[8], rs[8];
+#if ES_TRACE
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+    const unsigned long long tstart = tlast;
+#endif
     for (; t < total_tiles; t += gridDim.x) {
         const int img = t / a.nblk, tile = t - img * a.nblk;
         const int tx0 = (tile % a.tiles_x) * 32;
@@ -347,6 +359,10 @@ __global__ __launch_bounds__(ES_NTHR, 2) void enc_conv32_stream_kernel(const Enc
 #pragma unroll 1
         for (int sub = 0; sub < 2; ++sub) {
             const int ty0 = (tile / a.tiles_x) * ES_TH + sub * ES_SH;
+#if ES_TRACE
+            __builtin_amdgcn_s_waitcnt(0x0F70);            // (trace build) make the halo wait its own phase
+            ES_T(6);
+#endif
             // ---- commit the prefetched halo: transform + split + LDS write
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
@@ -369,8 +385,10 @@ __global__ __launch_bounds__(ES_NTHR, 2) void enc_conv32_stream_kernel(const Enc
                     *reinterpret_cast<half8*>(ldsA + row * EC_AS + 64 + g * 16) = lo;
                 }
             }
+            ES_T(0);                                       // commit (incl. waiting for the prefetched halo)
             __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): (first half) the weight DMAs have landed
             __syncthreads();                               // tile (and weights) visible to every wave
+            ES_T(1);                                       // vmcnt(0) + barrier
             {                                              // next half's halo travels during the MFMAs
                 const int nh = sub == 0 ? 2 * t + 1 : 2 * (t + (int)gridDim.x);
                 if (nh < 2 * total_tiles && !(ES_ABL & 8)) issue(nh);
@@ -403,7 +421,9 @@ __global__ __launch_bounds__(ES_NTHR, 2) void enc_conv32_stream_kernel(const Enc
                 accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[b][1], fb[b][0], accl, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            ES_T(2);                                       // halo issue + 18 MFMA steps
             __syncthreads();                               // every wave is done reading the tile: the patches may overlay it
+            ES_T(3);                                       // barrier
             // ---- epilogue: statistics in the MFMA layout, raw output through the transpose
             const int gy = ty0 + wave;
             float* Et = reinterpret_cast<float*>(ldsA) + wave * (32 * 36);
@@ -433,7 +453,9 @@ __global__ __launch_bounds__(ES_NTHR, 2) void enc_conv32_stream_kernel(const Enc
                     red[(wave * 32 + li) * 2 + 1] = q2;
                 }
             }
+            ES_T(4);                                       // epilogue (transpose, stores, statistics)
             __syncthreads();                               // patches read back: the tile may be rewritten; partials visible
+            ES_T(5);                                       // barrier
         }
         if (a.part && threadIdx.x < 32) {
             float s2 = 0.f, q2 = 0.f;
@@ -447,6 +469,14 @@ __global__ __launch_bounds__(ES_NTHR, 2) void enc_conv32_stream_kernel(const Enc
             dst[1] = q2;
         }
     }
+#if ES_TRACE
+    if (lane == 0 && a.out2) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(a.out2) + ((long)blockIdx.x * 4 + wave) * 16;
+        for (int k = 0; k < 7; ++k) o[k] = tsum[k];
+        o[8] = __builtin_readcyclecounter() - tstart;
+        o[9] = (unsigned long long)((total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
