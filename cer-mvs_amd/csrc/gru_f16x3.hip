@@ -10,16 +10,25 @@
 // 1.4e-7 after 16 GRU iterations) at a net 16/3 = 5.3x the fp32-MFMA rate.  The two scaled partial sums
 // live in separate fp32 accumulators and are combined once in the epilogue.
 //
-// Structure (per block: 4 waves, 4 x 32 pixel tile x NB output channels):
-//   * K loop over 32-channel chunks of the concatenated sources; per chunk the 6 x 34 halo is read once
-//     (fp32, coalesced), split to hi|lo f16 and stored to LDS with a 144-B pixel stride (conflict-free
-//     ds_read_b128 A fragments for every tap: 32 consecutive pixels x 16 B hit 16 distinct 16-B slots);
-//   * weights are pre-split and pre-packed on the host in B-fragment order; per (chunk, tap) the block's
-//     NB/8 KiB slice is DMA'd global->LDS with global_load_lds_dwordx4 (lane-linear image == fragment
-//     order), double-buffered: tap t+1 streams in while tap t is multiplied;
-//   * per tap and k16-step a wave reads its A hi/lo and B hi/lo fragments (ds_read_b128) and issues
-//     3 MFMAs per 32x32 output tile;
-//   * gate math in the epilogue, identical to the fp32 kernel.
+// Structure (per block: 8 waves = 4 pixel rows x 2 channel halves, 4 x 32 pixel tile x NB = 128 | 64 output channels, two
+// blocks per CU):
+//   * K loop over 32-channel chunks of the concatenated sources; per chunk the 6 x 34 halo is read once (fp32, coalesced),
+//     split to hi|lo f16 (two elements per instruction: common.hpp) and stored to LDS with a 144-B pixel stride
+//     (conflict-free ds_read_b128 A fragments for every tap);
+//   * the disparity encoder's 49 channels are generated from an LDS disparity tile; tiles whose pixels all have their 3x3
+//     neighbourhood inside the image evaluate that source as ONE 81-tap filter on the raw disparity (3 single-tap steps
+//     instead of 18; weights pre-summed by cer_conv3x3_f16x3_pack_collapsed);
+//   * weights are pre-split and pre-packed on the host in B-fragment order; per (chunk, tap) step the block's NB/8 KiB slice
+//     is DMA'd global->LDS with global_load_lds_dwordx4 (lane-linear image == fragment order) through a 3-slot ring two
+//     steps ahead of the multiply, with counted vmcnt waits; the wave index lives in an SGPR (readfirstlane) so that the
+//     piece addresses are uniform + lane offset (no spills in the tap loop);
+//   * per step and k16-step a wave reads its A hi/lo and B hi/lo fragments (ds_read_b128) and issues 3 MFMAs per 32x32
+//     output tile; the 64-channel configuration skews the MFMA stream half a tap against the LDS reads;
+//   * epilogue: the wave's tile goes through a private LDS transpose, so that the hoisted `init` term, the GRU operands and
+//     the outputs move as 16-byte accesses; gate math as in the fp32 kernel; CER_EPI_DELTA instead projects the hidden tile
+//     onto the nine taps of the 256->1 conv and writes only those planes.
+// Compile-time experiment switches (default off; DESIGN.md roadmap): HX_ABL (phase ablations), HX_TRACE (cycle stamps),
+// HX_CFG / HX_TH (other tilings), HX_EPI2=0 (direct 4-byte epilogue).
 #include "common.hpp"
 #include <stdlib.h>
 #include <string.h>
