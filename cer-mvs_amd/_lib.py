@@ -9,9 +9,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CER_MVS_LIB") or os.path.join(_HERE, "csrc", "libcermvs.so")
-ABI_VERSION = 1012
+ABI_VERSION = 1014
 CONV_MAX_SRC = 4
 EPI_LINEAR, EPI_RELU, EPI_GATES, EPI_GRU, EPI_DELTA = 0, 1, 2, 3, 4
+EPI_OUT_SPLIT, EPI_AUX_SPLIT = 0x100, 0x200       # cer_mvs.h: split32 activation layout flags, or-ed into `epi`
 
 _c = ctypes
 _P = _c.c_void_p
@@ -42,7 +43,7 @@ _SIGNATURES = {
     "cer_pyramid_f32": (_I, [_P, _L, _I, _I, _I, _F, _P]),
     "cer_corr_lookup_f32": (_I, [_P, _P, _P, _L, _P, _I, _L, _I, _I, _D, _I, _I, _P]),
     "cer_corr_encode_f32": (_I, [_P, _P, _P, _P, _I, _I, _L, _I, _P]),
-    "cer_lookup_encode_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _D, _I, _I, _I, _P]),
+    "cer_lookup_encode_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _D, _I, _I, _I, _I, _P]),
     "cer_conv3x3_packed_size": (_L, [_I, _I]),
     "cer_conv3x3_pack_f32": (_I, [_P, _P, _I, _I, _c.POINTER(_I), _c.POINTER(_I), _I]),
     "cer_conv3x3_f32": (_I, [_c.POINTER(ConvInputs), _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -69,6 +70,7 @@ _SIGNATURES = {
     "cer_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _L, _F, _P]),
     "cer_nchw_to_nhwc_border_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "cer_copy_segments_f32": (_I, [_c.POINTER(CopySegments), _P]),
+    "cer_split32_f32": (_I, [_P, _P, _L, _I, _I, _P]),
     "cer_geo_consistency_f32": (_I, [_P, _P, _P, _I, _I, _I, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 

@@ -83,6 +83,8 @@ struct ConvArgsX {
     const float* aux2;
     int h, w, cout;
     int tiles_x;
+    int out_split;                         // RELU / LINEAR: out, GATES: out2 (r*h), GRU: out are written in the split32 layout
+    int aux_split;                         // GATES / GRU: aux (the previous hidden state) is read in the split32 layout
 };
 
 __device__ __forceinline__ float hx_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -133,6 +135,57 @@ __device__ __forceinline__ void hx_stage_tensor(char* __restrict__ ldsA, const C
             hx_write8(ldsA, row, idx & 3, v);
         }
     }
+}
+
+// kind-3 chunk: the tensor already holds hi|lo f16 pairs ("split32": per pixel and 32-channel chunk 128 bytes = 32 hi halves |
+// 32 lo halves, written by a producer epilogue with out_split) - staging is two 16-byte loads and two 16-byte LDS writes per
+// (pixel, 8-channel group), no conversion arithmetic.
+template <int NTHR>
+__device__ __forceinline__ void hx_stage_presplit(char* __restrict__ ldsA, const ConvArgsX& a, int s, int c0, int ty0, int tx0) {
+    constexpr int ITEMS = (HX_ROWS * 4 + NTHR - 1) / NTHR;
+    float4 raw[ITEMS][2];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int idx = min((int)threadIdx.x + NTHR * i, HX_ROWS * 4 - 1);
+        const int row = idx >> 2, g = idx & 3;
+        const int hy = row / HX_HW, hx = row - hy * HX_HW;
+        const int gy = min(max(ty0 + hy - 1, 0), a.h - 1), gx = min(max(tx0 + hx - 1, 0), a.w - 1);
+        const float* p = a.src[s] + ((long)gy * a.w + gx) * a.ch[s] + c0;      // 32 floats = 128 bytes per (pixel, chunk)
+        raw[i][0] = cer_ld4(p + 4 * g);                    // 8 hi halves
+        raw[i][1] = cer_ld4(p + 16 + 4 * g);               // 8 lo halves
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int idx = threadIdx.x + NTHR * i;
+        if (idx < HX_ROWS * 4) {
+            const int row = idx >> 2, g = idx & 3;
+            const int hy = row / HX_HW, hx = row - hy * HX_HW;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            // zero padding by a bit mask on the f16 pairs (a select between two float4 aggregates makes hipcc park both in scratch
+            // and select a pointer)
+            const unsigned m = (gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) ? 0xFFFFFFFFu : 0u;
+            uint4 hi4 = *reinterpret_cast<const uint4*>(&raw[i][0]), lo4 = *reinterpret_cast<const uint4*>(&raw[i][1]);
+            hi4.x &= m; hi4.y &= m; hi4.z &= m; hi4.w &= m;
+            lo4.x &= m; lo4.y &= m; lo4.z &= m; lo4.w &= m;
+            *reinterpret_cast<uint4*>(ldsA + row * HX_AS + g * 16) = hi4;
+            *reinterpret_cast<uint4*>(ldsA + row * HX_AS + 64 + g * 16) = lo4;
+        }
+    }
+}
+
+// 8 consecutive channels (first one co, a multiple of 8) of pixel `pix` in a split32 tensor with C channels
+__device__ __forceinline__ void hx_store_split8(float* __restrict__ base, long pix, int C, int co, const float (&v)[8]) {
+    half8 hi, lo;
+    cer_split8(v, hi, lo);
+    char* p = reinterpret_cast<char*>(base) + (pix * C + (co & ~31)) * 4 + (co & 31) * 2;
+    *reinterpret_cast<half8*>(p) = hi;
+    *reinterpret_cast<half8*>(p + 64) = lo;
+}
+__device__ __forceinline__ void hx_load_split8(const float* __restrict__ base, long pix, int C, int co, float (&v)[8]) {
+    const char* p = reinterpret_cast<const char*>(base) + (pix * C + (co & ~31)) * 4 + (co & 31) * 2;
+    const half8 hi = *reinterpret_cast<const half8*>(p), lo = *reinterpret_cast<const half8*>(p + 64);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaf((float)lo[e], 1.0f / 2048.0f, (float)hi[e]);
 }
 
 // disparity tile (zero outside the image) -> LDS, once per block; feeds the on-the-fly disparity encoder
@@ -200,7 +253,9 @@ __device__ __forceinline__ void hx_issue_B(char* __restrict__ ldsB, const _Float
 }
 
 // WAVES_M x WAVES_N waves, each owning WM x WN MFMA tiles of 32 pixels x 32 channels; NBUF = weight ring depth
-template <int WAVES_M, int WAVES_N, int WM, int WN, int NBUF, int MINW, int EPI>
+// PS: the tensor sources are pre-split (kind 3) - a compile-time choice so that only ONE tensor staging routine is inlined into
+// the chunk loop (with both, the 128-channel kernels spill 16 VGPRs instead of 2)
+template <int WAVES_M, int WAVES_N, int WM, int WN, int NBUF, int MINW, int EPI, bool PS>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_kernel(const ConvArgsX a) {
     static_assert(WAVES_M * WM == HX_TH, "tile config");
     constexpr int NWAVES = WAVES_M * WAVES_N, NTHR = 64 * NWAVES;
@@ -329,8 +384,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
         for (int c0 = 0; c0 < chunk_end; c0 += HX_KC) {
             __syncthreads();                               // every wave has finished reading A (previous chunk, tap 8); ldsD visible
             if (!(HX_ABL & 4)) {
-                if (a.kind[s] == 0) hx_stage_tensor<NTHR>(ldsA, a, s, c0, ty0, tx0);
-                else if (c9) hx_stage_disp9<NTHR>(ldsA, ldsD, c0);
+                if (a.kind[s] != 1) {
+                    if constexpr (PS) hx_stage_presplit<NTHR>(ldsA, a, s, c0, ty0, tx0);
+                    else hx_stage_tensor<NTHR>(ldsA, a, s, c0, ty0, tx0);
+                } else if (c9) hx_stage_disp9<NTHR>(ldsA, ldsD, c0);
                 else hx_stage_disp<NTHR>(ldsA, ldsD, a, c0, ty0, tx0);
             }
 #pragma unroll 1
@@ -487,37 +544,61 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
                     Et[((r & 3) + 8 * (r >> 2) + 4 * kg) * PITCH + n * 32 + li] = fmaf(accl[m][n][r], 1.0f / 2048.0f, accm[m][n][r]);
             __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the patch is wave-private
             const int gy = ty0 + wm * WM + m;
-            constexpr int G = CW / 4;                      // 4-channel groups per pixel
-#pragma unroll
+            constexpr int G = CW / 8;                      // 8-channel groups per pixel
+#pragma unroll 1                                           // one item at a time: four interleaved items of 32 temporaries each spill
             for (int j = 0; j < 32 * G / 64; ++j) {
                 const int idx = lane + 64 * j;
                 const int px = idx / G, g = idx - px * G;
                 const int gx = tx0 + px;
-                float4 v = *reinterpret_cast<const float4*>(Et + px * PITCH + 4 * g);
+                const float4 va = *reinterpret_cast<const float4*>(Et + px * PITCH + 8 * g);
+                const float4 vb = *reinterpret_cast<const float4*>(Et + px * PITCH + 8 * g + 4);
                 if (gy >= a.h || gx >= a.w) continue;
                 const long pix = (long)gy * a.w + gx;
-                const int co = nb0 + wn * CW + 4 * g;
+                const int co = nb0 + wn * CW + 8 * g;
+                float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+                auto ld8 = [](const float* q, float (&o)[8]) {
+                    const float4 t0 = cer_ld4(q), t1 = cer_ld4(q + 4);
+                    o[0] = t0.x; o[1] = t0.y; o[2] = t0.z; o[3] = t0.w; o[4] = t1.x; o[5] = t1.y; o[6] = t1.z; o[7] = t1.w;
+                };
+                auto st8 = [](float* q, const float (&o)[8]) {
+                    *reinterpret_cast<float4*>(q) = make_float4(o[0], o[1], o[2], o[3]);
+                    *reinterpret_cast<float4*>(q + 4) = make_float4(o[4], o[5], o[6], o[7]);
+                };
                 if (a.init) {
-                    const float4 t = cer_ld4(a.init + pix * a.cout + co);
-                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                    float t[8];
+                    ld8(a.init + pix * a.cout + co, t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += t[e];
                 }
-                if (EPI == CER_EPI_LINEAR) {
-                    *reinterpret_cast<float4*>(a.out + pix * a.cout + co) = v;
-                } else if (EPI == CER_EPI_RELU) {
-                    *reinterpret_cast<float4*>(a.out + pix * a.cout + co) = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                if (EPI == CER_EPI_LINEAR || EPI == CER_EPI_RELU) {
+                    if (EPI == CER_EPI_RELU)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    if (a.out_split) hx_store_split8(a.out, pix, a.cout, co, v);
+                    else st8(a.out + pix * a.cout + co, v);
                 } else if (EPI == CER_EPI_GATES) {
-                    const float4 gt = make_float4(hx_sigmoid(v.x), hx_sigmoid(v.y), hx_sigmoid(v.z), hx_sigmoid(v.w));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = hx_sigmoid(v[e]);
                     if (co < half) {
-                        *reinterpret_cast<float4*>(a.out + pix * half + co) = gt;
+                        st8(a.out + pix * half + co, v);                                 // z stays fp32 (blend operand of the q conv)
                     } else {
-                        const float4 hp = cer_ld4(a.aux + pix * half + (co - half));
-                        *reinterpret_cast<float4*>(a.out2 + pix * half + (co - half)) = make_float4(gt.x * hp.x, gt.y * hp.y, gt.z * hp.z, gt.w * hp.w);
+                        float hp[8];
+                        if (a.aux_split) hx_load_split8(a.aux, pix, half, co - half, hp);
+                        else ld8(a.aux + pix * half + (co - half), hp);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= hp[e];
+                        if (a.out_split) hx_store_split8(a.out2, pix, half, co - half, v);
+                        else st8(a.out2 + pix * half + (co - half), v);
                     }
                 } else if (EPI == CER_EPI_GRU) {
-                    const float4 z = cer_ld4(a.aux2 + pix * a.cout + co), hp = cer_ld4(a.aux + pix * a.cout + co);
-                    *reinterpret_cast<float4*>(a.out + pix * a.cout + co) =
-                        make_float4((1.0f - z.x) * hp.x + z.x * tanhf(v.x), (1.0f - z.y) * hp.y + z.y * tanhf(v.y),
-                                    (1.0f - z.z) * hp.z + z.z * tanhf(v.z), (1.0f - z.w) * hp.w + z.w * tanhf(v.w));
+                    float z[8], hp[8];
+                    ld8(a.aux2 + pix * a.cout + co, z);
+                    if (a.aux_split) hx_load_split8(a.aux, pix, a.cout, co, hp);
+                    else ld8(a.aux + pix * a.cout + co, hp);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (1.0f - z[e]) * hp[e] + z[e] * tanhf(v[e]);
+                    if (a.out_split) hx_store_split8(a.out, pix, a.cout, co, v);
+                    else st8(a.out + pix * a.cout + co, v);
                 }
             }
         }
@@ -567,7 +648,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
 
 // ---------------------------------------------------------------------------------------- host side
 
-static int hx_padded_channels(int ch, int kind) { return kind == 1 ? 64 : ((ch + HX_KC - 1) / HX_KC) * HX_KC; }
+static int hx_padded_channels(int ch, int kind) { return kind == 1 ? 64 : ((ch + HX_KC - 1) / HX_KC) * HX_KC; }   // kinds 0 and 3: tensors
 
 extern "C" long cer_conv3x3_f16x3_packed_size(int Cout, int Kpad) {
     if (Cout <= 0 || Kpad <= 0 || Cout % 32 || Kpad % 32) return CER_ESHAPE;
@@ -695,20 +776,20 @@ extern "C" int cer_conv3x3_f16x3_pack_collapsed(const float* w, void* packed_v, 
     return CER_OK;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int NBUF, int MINW>
-static int hx_launch(const ConvArgsX& a, int epi, int nby, hipStream_t st) {
+template <int WAVES_M, int WAVES_N, int WM, int WN, int NBUF, int MINW, bool PS>
+static int hx_launch_ps(const ConvArgsX& a, int epi, int nby, hipStream_t st) {
     constexpr int NB = WAVES_N * WN * 32;
     const size_t smem = HX_A_BYTES + NBUF * NB * 128 + HX_D_BYTES;
     const int tiles_y = (a.h + HX_TH - 1) / HX_TH;
     dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)nby), block(64 * WAVES_M * WAVES_N);
     switch (epi) {
-        case CER_EPI_LINEAR: hipLaunchKernelGGL((conv3x3_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, CER_EPI_LINEAR>), grid, block, smem, st, a); break;
-        case CER_EPI_RELU: hipLaunchKernelGGL((conv3x3_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, CER_EPI_RELU>), grid, block, smem, st, a); break;
-        case CER_EPI_GATES: hipLaunchKernelGGL((conv3x3_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, CER_EPI_GATES>), grid, block, smem, st, a); break;
-        case CER_EPI_GRU: hipLaunchKernelGGL((conv3x3_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, CER_EPI_GRU>), grid, block, smem, st, a); break;
+        case CER_EPI_LINEAR: hipLaunchKernelGGL((conv3x3_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, CER_EPI_LINEAR, PS>), grid, block, smem, st, a); break;
+        case CER_EPI_RELU: hipLaunchKernelGGL((conv3x3_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, CER_EPI_RELU, PS>), grid, block, smem, st, a); break;
+        case CER_EPI_GATES: hipLaunchKernelGGL((conv3x3_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, CER_EPI_GATES, PS>), grid, block, smem, st, a); break;
+        case CER_EPI_GRU: hipLaunchKernelGGL((conv3x3_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, CER_EPI_GRU, PS>), grid, block, smem, st, a); break;
         case HX_EPI_DELTA:
             if constexpr (WAVES_N * WN * 32 == 128 && WM == 1) {
-                hipLaunchKernelGGL((conv3x3_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, HX_EPI_DELTA>), grid, block, smem, st, a);
+                hipLaunchKernelGGL((conv3x3_f16x3_kernel<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, HX_EPI_DELTA, PS>), grid, block, smem, st, a);
                 break;
             } else {
                 return CER_ESHAPE;
@@ -719,10 +800,25 @@ static int hx_launch(const ConvArgsX& a, int epi, int nby, hipStream_t st) {
     return CER_OK;
 }
 
+template <int WAVES_M, int WAVES_N, int WM, int WN, int NBUF, int MINW>
+static int hx_launch(const ConvArgsX& a, int epi, int nby, hipStream_t st) {
+    bool any3 = false, any0 = false;
+    for (int s = 0; s < a.nsrc; ++s) {
+        any3 = any3 || a.kind[s] == 3;
+        any0 = any0 || a.kind[s] == 0;
+    }
+    if (any3 && any0) return CER_EINVAL;                   // tensor sources of one call are all fp32 or all split32
+    if (any3) return hx_launch_ps<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, true>(a, epi, nby, st);
+    return hx_launch_ps<WAVES_M, WAVES_N, WM, WN, NBUF, MINW, false>(a, epi, nby, st);
+}
+
 extern "C" int cer_conv3x3_f16x3(const cer_conv_inputs* in, const void* packed_w, const void* packed_collapsed, const float* bias,
                                  const float* init, float* out, float* out2, const float* aux, const float* aux2, int h, int w, int Cout, int epi, void* stream) {
     if (!in || !packed_w || !out || h <= 0 || w <= 0 || Cout <= 0) return CER_EINVAL;
     if (in->nsrc <= 0 || in->nsrc > CER_CONV_MAX_SRC) return CER_EINVAL;
+    const int out_split = (epi & CER_EPI_OUT_SPLIT) != 0, aux_split = (epi & CER_EPI_AUX_SPLIT) != 0;
+    epi &= ~(CER_EPI_OUT_SPLIT | CER_EPI_AUX_SPLIT);
+    if ((out_split || aux_split) && (epi == HX_EPI_DELTA || !HX_EPI2)) return CER_EINVAL;
     if (epi == CER_EPI_GATES && (!out2 || !aux)) return CER_EINVAL;
     if (epi == CER_EPI_GRU && (!aux || !aux2)) return CER_EINVAL;
     if (epi == HX_EPI_DELTA && (!aux || Cout % 128 != 0)) return CER_EINVAL;
@@ -732,9 +828,10 @@ extern "C" int cer_conv3x3_f16x3(const cer_conv_inputs* in, const void* packed_w
     a.nsrc = in->nsrc;
     for (int s = 0; s < in->nsrc; ++s) {
         if (!in->src[s]) return CER_EINVAL;
-        if (in->kind[s] == 0 && (in->ch[s] % HX_KC != 0)) return CER_ESHAPE;
+        if (in->kind[s] != 0 && in->kind[s] != 1 && in->kind[s] != 3) return CER_EINVAL;
+        if (in->kind[s] != 1 && (in->ch[s] % HX_KC != 0)) return CER_ESHAPE;
         if (in->kind[s] == 1 && in->ch[s] != 49) return CER_ESHAPE;
-        if (in->kind[s] == 0 && !cer_aligned16(in->src[s])) return CER_EALIGN;
+        if (in->kind[s] != 1 && !cer_aligned16(in->src[s])) return CER_EALIGN;
         a.src[s] = in->src[s];
         a.ch[s] = in->ch[s];
         a.kind[s] = in->kind[s];
@@ -753,6 +850,8 @@ extern "C" int cer_conv3x3_f16x3(const cer_conv_inputs* in, const void* packed_w
     a.w = w;
     a.cout = Cout;
     a.tiles_x = (w + HX_TW - 1) / HX_TW;
+    a.out_split = out_split;
+    a.aux_split = aux_split;
     hipStream_t st = (hipStream_t)stream;
     // 128 output channels per block: 8 waves (4 x 2) of 32 px x 64 ch, 3-slot weight ring, 2 blocks (16 waves) per CU;
     //  64 output channels per block: 8 waves (4 x 2) of 32 px x 32 ch, 3-slot ring, 2 blocks (16 waves) per CU.
@@ -823,6 +922,35 @@ extern "C" int cer_delta_sum_f32(const float* T, int nhalf, float bias, const fl
     const long P = (long)h * w;
     hipLaunchKernelGGL(delta_sum_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, T, nhalf, bias, disp_in, disp_out,
                        delta, h, w);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}
+
+// ---- split32 layout conversion (model load / API boundaries): fp32 [P, C] <-> per pixel and 32-channel chunk 32 hi | 32 lo halves
+__global__ __launch_bounds__(256) void split32_kernel(const float* __restrict__ src, float* __restrict__ dst, long n8, int C, int inverse) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // one thread per 8 consecutive channels
+    if (i >= n8) return;
+    const long e = i * 8;
+    const long pix = e / C;
+    const int co = (int)(e - pix * C);
+    float v[8];
+    if (!inverse) {
+        const float4 t0 = cer_ld4(src + e), t1 = cer_ld4(src + e + 4);
+        v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+        hx_store_split8(dst, pix, C, co, v);
+    } else {
+        hx_load_split8(src, pix, C, co, v);
+        *reinterpret_cast<float4*>(dst + e) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(dst + e + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
+extern "C" int cer_split32_f32(const float* src, float* dst, long P, int C, int inverse, void* stream) {
+    if (!src || !dst || P <= 0 || C <= 0) return CER_EINVAL;
+    if (C % 32 != 0) return CER_ESHAPE;
+    if (!cer_aligned16(src) || !cer_aligned16(dst)) return CER_EALIGN;
+    const long n8 = P * C / 8;
+    hipLaunchKernelGGL(split32_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n8, C, inverse);
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(const float* __restrict__ v
 __global__ __launch_bounds__(256) void lookup_encode_kernel(const float* __restrict__ vol, const float* __restrict__ origin,
                                                             const float* __restrict__ disp, const float* __restrict__ wgt,
                                                             const float* __restrict__ bias, float* __restrict__ out, long P, int D, int rs,
-                                                            float incre, int L, int r, LevelInfo li) {
+                                                            float incre, int L, int r, LevelInfo li, int out_split) {
     extern __shared__ __attribute__((aligned(16))) float lk_smem[];
     const int rsp = rs + 4;
     const int taps = 2 * r + 1, K = L * taps;
@@ -123,6 +123,21 @@ __global__ __launch_bounds__(256) void lookup_encode_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = fmaf(f, wr[j], acc[j]);
     }
+    if (out_split) {
+        // split32 layout (cer_mvs.h): per pixel and 32-channel chunk 32 hi halves | 32 lo halves - the corr2 conv then stages
+        // this tensor with plain copies
+        char* dst = reinterpret_cast<char*>(out + (p0 + pix) * 64) + (grp >> 1) * 128 + (grp & 1) * 32;
+#pragma unroll
+        for (int j = 0; j < 16; j += 8) {
+            const float v[8] = {fmaxf(acc[j], 0.f), fmaxf(acc[j + 1], 0.f), fmaxf(acc[j + 2], 0.f), fmaxf(acc[j + 3], 0.f),
+                                fmaxf(acc[j + 4], 0.f), fmaxf(acc[j + 5], 0.f), fmaxf(acc[j + 6], 0.f), fmaxf(acc[j + 7], 0.f)};
+            cer_h8 hi, lo;
+            cer_split8(v, hi, lo);
+            *reinterpret_cast<cer_h8*>(dst + j * 2) = hi;
+            *reinterpret_cast<cer_h8*>(dst + 64 + j * 2) = lo;
+        }
+        return;
+    }
     float* dst = out + (p0 + pix) * 64 + grp * 16;
 #pragma unroll
     for (int j = 0; j < 16; j += 4)
@@ -159,7 +174,8 @@ extern "C" int cer_corr_lookup_f32(const float* vol, const float* origin, const 
 }
 
 extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, const float* disp, const float* w, const float* b, float* out,
-                                     long P, int D, int row_stride, double incre, int num_levels, int radius, int Cout, void* stream) {
+                                     long P, int D, int row_stride, double incre, int num_levels, int radius, int Cout, int out_split,
+                                     void* stream) {
     if (!vol || !origin || !disp || !w || !b || !out || P <= 0 || D <= 0) return CER_EINVAL;
     if (Cout != 64 || num_levels > 4) return CER_ESHAPE;
     if (!cer_aligned16(vol) || !cer_aligned16(out)) return CER_EALIGN;
@@ -169,7 +185,7 @@ extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, cons
     hipLaunchKernelGGL(lookup_encode_kernel, dim3((unsigned)((P + LK_PIX - 1) / LK_PIX)), dim3(256),
                        sizeof(float) * LK_PIX * (row_stride + 4 > num_levels * (2 * radius + 1) + 1 ? row_stride + 4 : num_levels * (2 * radius + 1) + 1),
                        (hipStream_t)stream, vol, origin, disp, w,
-                       b, out, P, D, row_stride, (float)incre, num_levels, radius, li);
+                       b, out, P, D, row_stride, (float)incre, num_levels, radius, li, out_split);
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }

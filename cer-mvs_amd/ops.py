@@ -101,14 +101,14 @@ def corr_encode(feats, w_t, b, out=None):
     return out
 
 
-def lookup_encode(vol, origin, disp, w_t, b, D, incre, num_levels, radius, out=None):
-    """Folded volume [P,rs] -> relu(conv1x1(lookup)) [P,64]."""
+def lookup_encode(vol, origin, disp, w_t, b, D, incre, num_levels, radius, out=None, out_split=False):
+    """Folded volume [P,rs] -> relu(conv1x1(lookup)) [P,64] (``out_split``: in the split32 layout, see ``split32``)."""
     P, rs = vol.shape
     if out is None:
         out = torch.empty(P, 64, device=vol.device, dtype=torch.float32)
     L.check(L.load().cer_lookup_encode_f32(L.dev_ptr(vol, "vol"), L.dev_ptr(origin, "origin"), L.dev_ptr(disp, "disp"),
                                            L.dev_ptr(w_t, "w"), L.dev_ptr(b, "b"), L.dev_ptr(out, "out"), P, D, rs, float(incre),
-                                           num_levels, radius, 64, L.cur_stream()), "lookup_encode")
+                                           num_levels, radius, 64, int(bool(out_split)), L.cur_stream()), "lookup_encode")
     return out
 
 
@@ -160,8 +160,12 @@ CONV_MODE = "f16x3"      # default arithmetic of ops.conv3x3: "f16x3" (split-f16
 COLLAPSE_DISP = True     # interior tiles of a conv with a disparity source use the 81-tap collapsed form (cer_mvs.h)
 
 
-def conv3x3(pc, srcs, h, w, epi, out=None, out2=None, aux=None, aux2=None, init=None, use_bias=True, mode=None):
-    """srcs: list of tensors matching ``pc.sources`` ([P,ch] for kind 0, disp [P] for kind 1)."""
+def conv3x3(pc, srcs, h, w, epi, out=None, out2=None, aux=None, aux2=None, init=None, use_bias=True, mode=None, out_split=False,
+            aux_split=False, kinds=None):
+    """srcs: list of tensors matching ``pc.sources`` ([P,ch] for kind 0, disp [P] for kind 1).
+    f16x3 mode only: ``kinds`` overrides the source kinds of this call (3 = the tensor is in the split32 layout, see
+    ``split32``); ``out_split`` writes the (RELU/LINEAR out, GATES out2, GRU out) result in that layout, ``aux_split`` reads
+    the previous hidden state ``aux`` from it."""
     mode = mode or CONV_MODE
     dev = srcs[0].device
     P = h * w
@@ -171,7 +175,7 @@ def conv3x3(pc, srcs, h, w, epi, out=None, out2=None, aux=None, aux2=None, init=
         ci.src[i] = t.data_ptr()
         L.dev_ptr(t, f"src{i}")
         ci.ch[i] = c
-        ci.kind[i] = k
+        ci.kind[i] = k if kinds is None else kinds[i]
     oc = pc.cout // 2 if epi == L.EPI_GATES else pc.cout
     if epi == L.EPI_DELTA:
         if mode != "f16x3":
@@ -188,8 +192,12 @@ def conv3x3(pc, srcs, h, w, epi, out=None, out2=None, aux=None, aux2=None, init=
             L.dev_ptr(aux2, "aux2"), h, w, pc.cout, epi, L.cur_stream())
     if mode == "f16x3":
         coll = L.dev_ptr(pc.packed_c, "packed_collapsed", torch.float16) if (COLLAPSE_DISP and pc.packed_c is not None) else None
+        flags = (L.EPI_OUT_SPLIT if out_split else 0) | (L.EPI_AUX_SPLIT if aux_split else 0)
+        tail = tail[:9] + (epi | flags,) + tail[10:]
         rc = L.load().cer_conv3x3_f16x3(ctypes.byref(ci), L.dev_ptr(pc.packed_x, "packed_w", torch.float16), coll, *tail)
     elif mode == "fp32":
+        if out_split or aux_split or (kinds is not None and 3 in kinds):
+            raise ValueError("the split32 layout exists only for the f16x3 kernels")
         rc = L.load().cer_conv3x3_f32(ctypes.byref(ci), L.dev_ptr(pc.packed, "packed_w"), *tail)
     else:
         raise ValueError(f"conv3x3: unknown mode {mode!r}")
@@ -284,3 +292,13 @@ def copy_segments(pairs):
         seg.dst[i] = dst.data_ptr()
         seg.n[i] = src.numel()
     L.check(L.load().cer_copy_segments_f32(ctypes.byref(seg), L.cur_stream()), "copy_segments")
+
+
+def split32(x, inverse=False, out=None):
+    """fp32 [P, C] (C % 32 == 0) -> the split32 layout of the f16x3 kernels (same shape / dtype, per pixel and 32-channel chunk
+    32 hi halves | 32 lo halves), or back (``inverse``; hi + 2^-11 lo, exact to 2^-22 relative)."""
+    P, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(L.load().cer_split32_f32(L.dev_ptr(x, "src"), L.dev_ptr(out, "dst"), P, C, int(bool(inverse)), L.cur_stream()), "split32")
+    return out

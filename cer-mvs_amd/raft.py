@@ -134,6 +134,7 @@ class RAFT(nn.Module):
         # until everything enqueued so far has finished)
         Pij = pij_matrices(poses[0], intrinsics[0], [0] * len(views), views).to(dev) if views else None
         net_l, inp_l, f1, f2 = self.encode(images, views)
+        net_l = ub.prepare_net(net_l)
         del images
 
         disp = torch.zeros(P, device=dev, dtype=torch.float32)

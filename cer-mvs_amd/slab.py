@@ -180,7 +180,7 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
         r0, r1, e0, e1 = slab_bounds(h, G, g)
         d = st[g]
         d.update(r0=r0, r1=r1, e0=e0, e1=e1, hs=e1 - e0)
-        d["net"] = d["net"][e0 * w:e1 * w].clone()
+        d["net"] = ub.prepare_net(d["net"][e0 * w:e1 * w].clone())
         d["inp"] = d["inp"][e0 * w:e1 * w].contiguous()
         d["f1s"] = d["f1"][e0 * w:e1 * w].contiguous()
         d["disp"] = torch.zeros((e1 - e0) * w, device=dev, dtype=torch.float32)

@@ -162,11 +162,34 @@ class UpdateBlock(nn.Module):
         p = self.packed(stage, inp_l.device)
         return (ops.conv3x3(p["zr_inp"], [inp_l], h, w, L.EPI_LINEAR, mode=self.conv_mode), ops.conv3x3(p["q_inp"], [inp_l], h, w, L.EPI_LINEAR, mode=self.conv_mode))
 
+    # f16x3 path: the loop's activations (hidden state, corr features, r*h) live in HBM in the "split32" layout - hi|lo f16
+    # pairs in the fp32 slots (cer_mvs.h) - written by the producers' epilogues, so that every conv stages its tensor sources
+    # with plain 16-byte copies instead of re-splitting them (staging was ~10 % of the conv time, VALU-bound).  The hidden
+    # state is therefore carried at 2^-22 relative resolution (the resolution the f16x3 products see anyway).
+    SPLIT_ACTS = True
+
+    def split_acts(self):
+        return self.SPLIT_ACTS and self.conv_mode == "f16x3"
+
+    def prepare_net(self, net_l):
+        """Hidden state [P,64] fp32 -> the layout ``step`` keeps it in (split32 on the f16x3 path)."""
+        return ops.split32(net_l) if self.split_acts() else net_l
+
     def step(self, vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws):
-        """One GRU iteration on the folded volume; updates ``net_l`` [P,64] and ``disp`` [P] in place.
+        """One GRU iteration on the folded volume; updates ``net_l`` [P,64] (see ``prepare_net``) and ``disp`` [P] in place.
         ``ws``: dict of scratch tensors (c1, c2, z, rn, hid) reused across iterations."""
         p = self.packed(stage, net_l.device)
         hzr, hq = hoisted
+        if self.split_acts():
+            ops.lookup_encode(vol, origin, disp, p["w0t"], p["b0"], D, incre, self.num_levels, self.radius, out=ws["c1"], out_split=True)
+            ops.conv3x3(p["corr2"], [ws["c1"]], h, w, L.EPI_RELU, out=ws["c2"], kinds=[3], out_split=True)
+            ops.conv3x3(p["zr_rest"], [net_l, disp, ws["c2"]], h, w, L.EPI_GATES, out=ws["z"], out2=ws["rn"], aux=net_l, init=hzr,
+                        kinds=[3, 1, 3], out_split=True, aux_split=True)
+            ops.conv3x3(p["q_rest"], [ws["rn"], disp, ws["c2"]], h, w, L.EPI_GRU, out=net_l, aux=net_l, aux2=ws["z"], init=hq,
+                        kinds=[3, 1, 3], out_split=True, aux_split=True)
+            ops.conv3x3(p["d1"], [net_l], h, w, L.EPI_DELTA, mode="f16x3", out=ws["T"], aux=p["d2proj"], kinds=[3])
+            ops.delta_sum(ws["T"], p["d2b"], disp, h, w, disp_out=disp, want_delta=False)
+            return
         ops.lookup_encode(vol, origin, disp, p["w0t"], p["b0"], D, incre, self.num_levels, self.radius, out=ws["c1"])
         ops.conv3x3(p["corr2"], [ws["c1"]], h, w, L.EPI_RELU, out=ws["c2"])
         ops.conv3x3(p["zr_rest"], [net_l, disp, ws["c2"]], h, w, L.EPI_GATES, out=ws["z"], out2=ws["rn"], aux=net_l, init=hzr)

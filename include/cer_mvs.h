@@ -118,6 +118,7 @@ int cer_corr_encode_f32(const float* feats, const float* w, const float* b, floa
 int cer_lookup_encode_f32(const float* vol, const float* origin, const float* disp,
                           const float* w, const float* b, float* out,
                           long P, int D, int row_stride, double incre, int num_levels, int radius, int Cout,
+                          int out_split /* 1: out in the split32 layout (below) for the f16x3 corr2 conv */,
                           void* stream);
 
 /* ------------------------------------------------------------------------------------
@@ -143,6 +144,13 @@ int cer_lookup_encode_f32(const float* vol, const float* origin, const float* di
 #define CER_EPI_RELU 1
 #define CER_EPI_GATES 2
 #define CER_EPI_GRU 3
+/* "split32" activation layout (f16x3 kernels only): a [P, C] tensor (C % 32 == 0) whose fp32 slots hold, per pixel and
+ * 32-channel chunk, 32 hi halves followed by 32 lo halves (x = hi + 2^-11 lo; same bytes as fp32).  A producer epilogue
+ * writes it with CER_EPI_OUT_SPLIT or'ed into `epi` (RELU / LINEAR: out; GATES: out2 = r*h; GRU: out), a consumer reads it
+ * as source kind 3 (staging = plain 16-byte copies, no conversion arithmetic) or, with CER_EPI_AUX_SPLIT, as the previous
+ * hidden state `aux` of the GATES / GRU epilogues (reconstructed as hi + 2^-11 lo).  cer_split32_f32 converts. */
+#define CER_EPI_OUT_SPLIT 0x100
+#define CER_EPI_AUX_SPLIT 0x200
 #define CER_EPI_DELTA 4   /* cer_conv3x3_f16x3 only - see cer_delta_proj_pack */
 
 typedef struct {
@@ -183,6 +191,9 @@ int cer_conv3x3_f16x3(const cer_conv_inputs* in, const void* packed_w, const voi
                       const float* bias, const float* init,
                       float* out, float* out2, const float* aux, const float* aux2,
                       int h, int w, int Cout, int epi, void* stream);
+
+/* fp32 [P, C] -> split32 (inverse = 0) or back (inverse = 1); C % 32 == 0. */
+int cer_split32_f32(const float* src, float* dst, long P, int C, int inverse, void* stream);
 
 /* Fused delta head (reference: core/update.py:68-71,114; core/raft.py:101).  cer_conv3x3_f16x3 with epi =
  * CER_EPI_DELTA computes hid = relu(conv3x3(net)) (Cout = 256) but never writes it: each 128-channel block

@@ -265,6 +265,40 @@ def test_cost_build_fused_pyramid_equals_two_pass(dev, D):
     assert a[:, :D].abs().sum() > 0
 
 
+def test_conv3x3_split32_layout(dev):
+    """Activations in the split32 layout (hi|lo f16 pairs in the fp32 slots, cer_mvs.h): a conv fed by pre-split sources
+    (kind 3) is BIT-identical to the same conv splitting fp32 sources in its staging loop; CER_EPI_OUT_SPLIT writes exactly
+    split32(fp32 result); the GRU / GATES epilogues reading the hidden state from the split layout differ from the fp32
+    read only by the 2^-22 reconstruction."""
+    from cer_mvs_amd import _lib as L, ops
+    h, w = 13, 70
+    P = h * w
+    net = torch.tanh(hashed((P, 64), 501, -2, 2)).to(dev)
+    c2 = torch.relu(hashed((P, 64), 502, -1, 2)).to(dev)
+    disp = hashed((P,), 503, 0.0005, 0.0025).to(dev)
+    init = hashed((P, 128), 504, -0.3, 0.3).to(dev)
+    rt = ops.split32(ops.split32(net), inverse=True)
+    assert (rt - net).abs().max() <= net.abs().max() * 2.0 ** -21
+    pc = ops.PackedConv3x3(hashed((128, 177, 3, 3), 505, -0.05, 0.05), None, [(64, 0), (49, 1), (64, 0)], dev)
+    z0, rh0 = ops.conv3x3(pc, [net, disp, c2], h, w, L.EPI_GATES, aux=net, init=init)
+    z1, rh1 = ops.conv3x3(pc, [ops.split32(net), disp, ops.split32(c2)], h, w, L.EPI_GATES, aux=net, init=init, kinds=[3, 1, 3])
+    assert torch.equal(z0, z1) and torch.equal(rh0, rh1)
+    z2, rh2 = ops.conv3x3(pc, [net, disp, c2], h, w, L.EPI_GATES, aux=net, init=init, out_split=True)
+    assert torch.equal(z2, z0) and torch.equal(rh2, ops.split32(rh0))
+    z3, rh3 = ops.conv3x3(pc, [net, disp, c2], h, w, L.EPI_GATES, aux=ops.split32(net), init=init, aux_split=True)
+    assert torch.equal(z3, z0) and rel_l1(rh3.cpu(), rh0.cpu()) < 1e-6
+    pq = ops.PackedConv3x3(hashed((64, 177, 3, 3), 506, -0.05, 0.05), None, [(64, 0), (49, 1), (64, 0)], dev)
+    initq = hashed((P, 64), 507, -0.3, 0.3).to(dev)
+    n0 = ops.conv3x3(pq, [rh0, disp, c2], h, w, L.EPI_GRU, aux=net, aux2=z0, init=initq)
+    n1 = ops.conv3x3(pq, [ops.split32(rh0), disp, ops.split32(c2)], h, w, L.EPI_GRU, aux=ops.split32(net), aux2=z0, init=initq,
+                     kinds=[3, 1, 3], out_split=True, aux_split=True)
+    assert rel_l1(ops.split32(n1, inverse=True).cpu(), n0.cpu()) < 1e-6
+    pr = ops.PackedConv3x3(hashed((64, 64, 3, 3), 508, -0.1, 0.1), hashed((64,), 509, -0.1, 0.1), [(64, 0)], dev)
+    r0 = ops.conv3x3(pr, [c2], h, w, L.EPI_RELU)
+    r1 = ops.conv3x3(pr, [ops.split32(c2)], h, w, L.EPI_RELU, kinds=[3], out_split=True)
+    assert torch.equal(r1, ops.split32(r0))
+
+
 @pytest.mark.parametrize("h,w,cout", [(20, 140, 128), (13, 101, 64), (24, 96, 64)])
 def test_conv3x3_collapsed_disparity_tiles(dev, h, w, cout):
     """Interior tiles evaluate the disparity source as one 81-tap filter on the raw disparity (cer_mvs.h,
