@@ -130,6 +130,8 @@ int cer_lookup_encode_f32(const float* vol, const float* origin, const float* di
  *   kind 0: a tensor [h*w, ch[s]]                              (ch multiple of 16)
  *   kind 1: the disparity encoder of disp [h*w] (update.py:80-85,97): 49 channels
  *           100*(disp0[y+uy-3, x+ux-3] - disp[y,x]) (disp0 = zero-padded disp), padded to 64
+ *   kind 3: (cer_conv3x3_f16x3 only) a tensor [h*w, ch[s]] in the split32 layout described below (ch multiple of 32);
+ *           the tensor sources of one call are all kind 0 or all kind 3; weights are packed as for kind 0
  * Weights are pre-packed by cer_conv3x3_pack_f32.  acc is initialised from `init` [h*w, Cout]
  * when non-NULL, else from bias [Cout] (or 0).  Epilogues (epi):
  *   0 LINEAR  out[p,co]  = acc
