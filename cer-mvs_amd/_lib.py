@@ -9,10 +9,14 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CER_MVS_LIB") or os.path.join(_HERE, "csrc", "libcermvs.so")
-ABI_VERSION = 1014
+ABI_VERSION = 1021
 CONV_MAX_SRC = 4
 EPI_LINEAR, EPI_RELU, EPI_GATES, EPI_GRU, EPI_DELTA = 0, 1, 2, 3, 4
 EPI_OUT_SPLIT, EPI_AUX_SPLIT = 0x100, 0x200       # cer_mvs.h: split32 activation layout flags, or-ed into `epi`
+# cer_mvs.h, "s16" convs: log2 scales of the split16 activation classes (|x| <= 1: hidden state, r*h; ReLU outputs; generated
+# disparity features)
+S16_UNIT, S16_RELU, S16_DISP = 14, 4, 6
+S16_FRAG16, S16_ACC32, S16_F32X8 = 0, 1, 2        # cer_s16_layout_f32 layouts
 
 _c = ctypes
 _P = _c.c_void_p
@@ -43,7 +47,7 @@ _SIGNATURES = {
     "cer_pyramid_f32": (_I, [_P, _L, _I, _I, _I, _F, _P]),
     "cer_corr_lookup_f32": (_I, [_P, _P, _P, _L, _P, _I, _L, _I, _I, _D, _I, _I, _P]),
     "cer_corr_encode_f32": (_I, [_P, _P, _P, _P, _I, _I, _L, _I, _P]),
-    "cer_lookup_encode_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _D, _I, _I, _I, _I, _P]),
+    "cer_lookup_encode_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _D, _I, _I, _I, _I, _I, _I, _P]),
     "cer_conv3x3_packed_size": (_L, [_I, _I]),
     "cer_conv3x3_pack_f32": (_I, [_P, _P, _I, _I, _c.POINTER(_I), _c.POINTER(_I), _I]),
     "cer_conv3x3_f32": (_I, [_c.POINTER(ConvInputs), _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -71,6 +75,15 @@ _SIGNATURES = {
     "cer_nchw_to_nhwc_border_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "cer_copy_segments_f32": (_I, [_c.POINTER(CopySegments), _P]),
     "cer_split32_f32": (_I, [_P, _P, _L, _I, _I, _P]),
+    "cer_conv3x3_s16_packed_size": (_L, [_I, _c.POINTER(_I), _c.POINTER(_I), _I, _I]),
+    "cer_conv3x3_s16_scale": (_I, [_P, _I, _I, _c.POINTER(_I), _c.POINTER(_I), _c.POINTER(_I), _I]),
+    "cer_conv3x3_s16_pack": (_I, [_P, _P, _I, _I, _c.POINTER(_I), _c.POINTER(_I), _c.POINTER(_I), _I, _I, _I]),
+    "cer_conv3x3_s16": (_I, [_c.POINTER(ConvInputs), _c.POINTER(_I), _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "cer_delta_proj_s16_packed_size": (_L, [_I]),
+    "cer_delta_proj_s16_pack": (_I, [_P, _P, _I, _c.POINTER(_I)]),
+    "cer_s16_padded_pixels": (_L, [_I, _I]),
+    "cer_s16_layout_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "cer_s16_rows_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cer_geo_consistency_f32": (_I, [_P, _P, _P, _I, _I, _I, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 

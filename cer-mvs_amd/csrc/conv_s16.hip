@@ -1,0 +1,925 @@
+// K3, round 2: the update block's 3x3 convolutions (reference: core/update.py:13-25,61-71,80-85,87-120) as barrier-light
+// implicit GEMMs on v_mfma_f32_32x32x16_f16 with fp32-class accuracy, ONE accumulator per output tile.
+//
+// Arithmetic ("s16": split-f16, single accumulator).  Every fp32 operand x is carried as two halves of  xs = x * 2^k  (k: a
+// per-tensor power of two, exact):  hi = f16(xs),  lo = f16(xs - hi)  (UNSCALED residual; |xs - hi - lo| <= max(2^-22 |xs|,
+// 2^-25)), and  x*w ~= (xh*wh + xh*wl + xl*wh) / (2^kx 2^kw):  three f16 MFMAs into the SAME fp32 accumulator (the dropped
+// xl*wl term is 2^-22 relative).  Measured on the MI355X (tools/ubench/mfma_merge_acc.hip, K = 1248): error / sum|x||w| rms
+// 1.6e-8 against 2.7e-8 for an fp32 fmaf chain and 1.0e-8 for round 1's two-accumulator form - the MFMA adder shows no
+// truncation bias, so the merged form is fp32-class.  It halves the accumulator registers, which is what makes the structure
+// below possible.  All sources of one conv share the product scale S = 2^kx(src) * 2^kw(src) (cer_conv3x3_s16_scale).
+//
+// Activation layout "split16": a [P, C] tensor keeps, per pixel and 16-channel group, 16 hi halves | 16 lo halves (64 bytes) in
+// the bytes of the fp32 slots - written by the producers' epilogues, staged by the consumers with plain 16-byte copies.
+//
+// Structure (block = 4 waves, 2 blocks per CU = 2 waves per SIMD, 256 VGPRs per wave):
+//   * tile = TH x 16 pixels; wave (wm, wn) owns MT m-tiles of 32 pixels (2 rows x 16) x 32 output channels: MT accumulators;
+//   * MFMA orientation: A = weights (rows = channels), B = activations (columns = pixels), so a lane ends up with channels
+//     8j + 4kg + 0..3 of ONE pixel: after one v_permlane32_swap per register pair a lane owns 8 consecutive channels - the
+//     epilogue loads / stores 16-byte vectors straight from the accumulators (no LDS transpose), and the delta head's
+//     projection takes them as B fragments directly;
+//   * weights never touch LDS: each wave loads ITS 32-channel slice of a (half-chunk, tap) step - 2 x 1 KiB, lane-linear in
+//     fragment order - straight into registers two steps ahead; with the 1 x 4 wave layout no two waves of a block load the
+//     same bytes, so there is no weight ring, no DMA and NO per-step barrier;
+//   * activations: per 16-channel half-chunk the halo tile ((TH+2) x 18 pixels x 64 B, XOR-swizzled 16-byte slots: conflict
+//     -free ds_read_b128 for every tap) is loaded to registers at the first tap of the previous half-chunk and written to the
+//     other LDS buffer five taps later; ONE barrier per half-chunk (9 taps), placed before the last tap so that the operand
+//     prefetch of the next half-chunk's first tap is already legal; fragments are double-buffered in registers one step ahead;
+//   * the disparity encoder's 49 channels are generated from an LDS disparity tile: interior tiles use the collapsed 81-tap
+//     form (6 single-tap steps), border tiles the literal one (4 half-chunks x 9 taps) - same algebra as round 1;
+//   * the hoisted `init` term / bias is the accumulators' initial value (16-byte loads in the prologue).
+#include "common.hpp"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define SX_TW 16                           // tile width in pixels
+#define SX_HW 18                           // halo columns
+#define SX_PITCH 20                        // LDS pixels per halo row (pitch % 4 == 0 keeps (q % 4) == (col % 4))
+#define SX_ROWB (SX_PITCH * 64)            // LDS bytes per halo row
+#define SX_DTW 24                          // disparity tile columns (halo + 3 each side)
+#define SX_EPI_DELTA 4
+#define SX_HID_LOG2 4                      // scale of the delta head's hidden activations (relu outputs)
+#ifndef SX_ABL
+#define SX_ABL 0     // profiling ablations (variant builds only): 1 no tensor staging, 2 weights always from step 0 (L1 hits), 4 no epilogue
+#endif               // stores, 8 no barriers in the main loop, 16 no MFMA, 32 no activation fragment reads
+#ifndef SX_TRACE
+#define SX_TRACE 0   // variant builds only (tools/trace_s16.py): per wave cycle stamps + HW_ID written to `aux2` (GATES: unused there)
+#endif
+
+struct S16Args {
+    const char* src[CER_CONV_MAX_SRC];     // tensors (frag16) first, the disparity source (fp32 [P]) last
+    int ch[CER_CONV_MAX_SRC];
+    int kind[CER_CONV_MAX_SRC];            // 2 = frag16 tensor, 1 = disparity
+    int nsrc;
+    const _Float16* wpk;                   // literal packing
+    const _Float16* wpk_c;                 // collapsed packing (interior tiles) or null
+    const float* bias;
+    const float* init;                     // acc32 layout
+    float* out;
+    float* out2;
+    const float* aux;
+    const float* aux2;
+    int h, w, cout, tiles_x, ntiles, ny, mtx, mty;
+    float S, invS;                         // accumulator = S * conv
+    float out_scale;                       // frag16 outputs
+    float aux_inv;                         // 1 / scale of the frag16 hidden state read by GATES / GRU
+    float disp_scale;                      // generated disparity features
+    float proj_inv;                        // DELTA: 1 / (hidden scale * w2 scale)
+    int out_split;
+};
+
+// ---- operand split: 8 fp32 -> hi | lo halves of v * scale (packed conversions)
+__device__ __forceinline__ void sx_split8(const float (&v)[8], float scale, half8& hi, half8& lo) {
+    cer_h2 h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        cer_f2 x = (cer_f2){v[2 * i], v[2 * i + 1]} * scale;
+        x = __builtin_elementwise_min(__builtin_elementwise_max(x, (cer_f2){-65504.0f, -65504.0f}), (cer_f2){65504.0f, 65504.0f});
+        h[i] = __builtin_convertvector(x, cer_h2);
+        l[i] = __builtin_convertvector(x - __builtin_convertvector(h[i], cer_f2), cer_h2);
+    }
+    hi = (half8){h[0].x, h[0].y, h[1].x, h[1].y, h[2].x, h[2].y, h[3].x, h[3].y};
+    lo = (half8){l[0].x, l[0].y, l[1].x, l[1].y, l[2].x, l[2].y, l[3].x, l[3].y};
+}
+__device__ __forceinline__ void sx_join8(const half8 hi, const half8 lo, float inv, float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = ((float)hi[e] + (float)lo[e]) * inv;
+}
+__device__ __forceinline__ float sx_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct SxStage {                           // what to put into the NEXT activation buffer
+    int kind;                              // 0 nothing, 2 tensor half-chunk, 1 literal disparity group, 3 collapsed disparity group
+    const char* base;                      // tensor: source + 2048 * group
+    long mtb;                              // tensor: bytes per m-tile (channels / 16 * 2048)
+    int g;                                 // disparity group index
+};
+
+template <int WM_, int WN_, int MT, int EPI>
+__global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
+    constexpr int TH = WM_ * 2 * MT, HR = TH + 2;
+    constexpr int ABUF = HR * SX_ROWB;
+    constexpr int NPIX = HR * SX_HW, NITEM = NPIX * 4, ITEMS = (NITEM + 255) / 256;
+    constexpr int NB = WN_ * 32;
+    constexpr int DROWS = HR + 6;
+    extern __shared__ __attribute__((aligned(16))) char sx_smem[];
+    float* ldsD = reinterpret_cast<float*>(sx_smem + 2 * ABUF);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN_, wn = wave % WN_;
+    const int li = lane & 31, kg = lane >> 5;
+#if SX_TRACE
+    unsigned long long trace_t[24];
+    int trace_n = 0;
+    trace_t[trace_n++] = __builtin_readcyclecounter();
+#define SX_STAMP() do { if (trace_n < 24) trace_t[trace_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SX_STAMP() do { } while (0)
+#endif
+
+    // ---- block -> (tile, channel block): consecutive virtual ids stay on one XCD (blocks are dealt round-robin over the 8
+    // XCDs), so neighbouring tiles - which share halo lines - and the channel blocks of one tile meet in the same L2
+    int vid;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+        vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int tile = vid / a.ny, by = vid - tile * a.ny;
+    const int tile_y = tile / a.tiles_x, tile_x = tile - tile_y * a.tiles_x;
+    const int ty0 = tile_y * TH, tx0 = tile_x * SX_TW;
+    const int nb0 = by * NB;
+    const int NT = a.cout >> 5;
+
+    // ---- sources: tensors, then (optionally) the disparity
+    int ntens = a.nsrc;
+    const float* dsrc = nullptr;
+    if (a.kind[a.nsrc - 1] == 1) { ntens = a.nsrc - 1; dsrc = reinterpret_cast<const float*>(a.src[a.nsrc - 1]); }
+    const bool coll = dsrc && a.wpk_c && ty0 >= 1 && ty0 + TH <= a.h - 1 && tx0 >= 1 && tx0 + SX_TW <= a.w - 1;
+    int nsteps = 0;
+    for (int s = 0; s < ntens; ++s) nsteps += (a.ch[s] >> 4) * 9;
+    if (dsrc) nsteps += coll ? 6 : 36;
+    const char* wlane = reinterpret_cast<const char*>(coll ? a.wpk_c : a.wpk) + ((long)(nb0 >> 5) + wn) * 2048 + lane * 16;
+    const long wstep = (long)NT * 2048;    // bytes per step
+
+    // ---- per-lane LDS addresses of the activation fragments: pixel (row 2*(wm*MT+m) + (li>>4) + dy, col (li&15) + dx) of the
+    // halo tile; 16-byte slot kg (hi) / kg ^ 2 (lo), XOR-swizzled with ((col >> 2) & 3)
+    int xh[3], xl[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int col = (li & 15) + dx;
+        const int base = (2 * wm * MT + (li >> 4)) * SX_ROWB + col * 64;
+        const int sl = kg ^ ((col >> 2) & 3);
+        xh[dx] = base + sl * 16;
+        xl[dx] = base + (sl ^ 2) * 16;
+    }
+
+    // ---- staging items of this thread: (halo pixel n, physical slot ps); the source piece is plane (hl, kg) = logical slot of
+    // the pixel's m-tile: frag16 byte offset  mt * mtb + group * 2048 + logical * 512 + li * 16
+    int st_pk[ITEMS];                      // m-tile | li << 20 | logical << 25 | valid << 27 | in-range << 28
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int it = tid + 256 * i;
+        const int n = min(it >> 2, NPIX - 1), ps = it & 3;
+        const int r = n / SX_HW, c = n - r * SX_HW;
+        const int gy = ty0 + r - 1, gx = tx0 + c - 1;
+        const bool valid = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+        const int cy = min(max(gy, 0), a.h - 1), cx = min(max(gx, 0), a.w - 1);
+        const int logical = ps ^ ((c >> 2) & 3);
+        st_pk[i] = ((cy >> 1) * a.mtx + (cx >> 4)) | ((((cy & 1) << 4) | (cx & 15)) << 20) | (logical << 25) | ((valid ? 1 : 0) << 27) |
+                   ((it < NITEM ? 1 : 0) << 28);
+    }
+    // the items are staged in two batches (taps 0 -> 3 and 3 -> 6 of the previous group) through the same registers
+    constexpr int IB = (ITEMS + 1) / 2;
+    uint4 raw[IB];
+    // `vary` = 0 at run time, but derived from the loop counter: everything computed from (tid ^ vary) is re-derived where it is
+    // used instead of being hoisted out of the MFMA loop as a loop invariant (hipcc otherwise keeps ~100 such registers alive
+    // across the loop and spills them)
+    int vary = 0;
+    auto stage_load = [&](const SxStage& st, int batch) {
+#pragma unroll
+        for (int k = 0; k < IB; ++k) {
+            const int i = batch * IB + k;
+            if (i >= ITEMS) break;
+            const int pk = st_pk[i] ^ vary;
+            const char* p = st.base + (long)(pk & 0xFFFFF) * st.mtb + (((pk >> 25) & 3) * 512 + ((pk >> 20) & 31) * 16);
+            raw[k] = *reinterpret_cast<const uint4*>(p);
+        }
+    };
+    auto stage_store = [&](int bufoff, int batch) {
+        const int tid_ = tid ^ vary;
+#pragma unroll
+        for (int k = 0; k < IB; ++k) {
+            const int i = batch * IB + k;
+            if (i >= ITEMS) break;
+            const int pk = st_pk[i] ^ vary;
+            const unsigned m = (pk & (1 << 27)) ? 0xFFFFFFFFu : 0u;            // zero padding of the feature map
+            uint4 v = raw[k];
+            v.x &= m; v.y &= m; v.z &= m; v.w &= m;
+            const int it = tid_ + 256 * i;
+            const int n = it >> 2, r = n / SX_HW, c = n - r * SX_HW;
+            if (pk & (1 << 28)) *reinterpret_cast<uint4*>(sx_smem + bufoff + (r * SX_PITCH + c) * 64 + (it & 3) * 16) = v;
+        }
+    };
+    // literal disparity features, group g (channels 16g .. 16g+15 of 100 * (unfold7x7(d) - d), core/update.py:80-85,97)
+    auto gen_literal = [&](int g, int bufoff) {
+        for (int n = tid ^ vary; n < NPIX; n += 256) {
+            const int r = n / SX_HW, c = n - r * SX_HW;
+            const int gy = ty0 + r - 1, gx = tx0 + c - 1;
+            const bool inside = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;    // the 3x3 conv zero-pads the FEATURE map
+            const float ctr = ldsD[(r + 3) * SX_DTW + c + 3];
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int chn = 16 * g + k;
+                const int uy = (chn * 37) >> 8, ux = chn - 7 * uy;              // chn / 7, chn % 7 for chn < 64
+                v[k] = (inside && chn < 49) ? 100.0f * (ldsD[(r + uy) * SX_DTW + c + ux] - ctr) : 0.f;
+            }
+            char* px = sx_smem + bufoff + (r * SX_PITCH + c) * 64;
+            const int key = (c >> 2) & 3;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                const float u[8] = {v[8 * kh], v[8 * kh + 1], v[8 * kh + 2], v[8 * kh + 3], v[8 * kh + 4], v[8 * kh + 5], v[8 * kh + 6], v[8 * kh + 7]};
+                half8 hi, lo;
+                sx_split8(u, a.disp_scale, hi, lo);
+                *reinterpret_cast<half8*>(px + ((kh ^ key) * 16)) = hi;
+                *reinterpret_cast<half8*>(px + (((2 + kh) ^ key) * 16)) = lo;
+            }
+        }
+    };
+    // collapsed disparity features, group g: channel s = (sy, sx) of the 9x9 window holds 100 * (d[p + s - 4] - d[p]); only the
+    // tile's own pixels (the centre tap) are read
+    auto gen_collapsed = [&](int g, int bufoff) {
+        for (int n = tid ^ vary; n < TH * SX_TW; n += 256) {
+            const int pr = n >> 4, pc = n & 15;
+            const float ctr = ldsD[(pr + 4) * SX_DTW + pc + 4];
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int s = 16 * g + k;
+                const int sy = (s * 57) >> 9, sx = s - 9 * sy;                  // s / 9, s % 9 for s < 96
+                v[k] = (s < 81) ? 100.0f * (ldsD[(pr + sy) * SX_DTW + pc + sx] - ctr) : 0.f;
+            }
+            const int c = pc + 1;
+            char* px = sx_smem + bufoff + ((pr + 1) * SX_PITCH + c) * 64;
+            const int key = (c >> 2) & 3;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                const float u[8] = {v[8 * kh], v[8 * kh + 1], v[8 * kh + 2], v[8 * kh + 3], v[8 * kh + 4], v[8 * kh + 5], v[8 * kh + 6], v[8 * kh + 7]};
+                half8 hi, lo;
+                sx_split8(u, a.disp_scale, hi, lo);
+                *reinterpret_cast<half8*>(px + ((kh ^ key) * 16)) = hi;
+                *reinterpret_cast<half8*>(px + (((2 + kh) ^ key) * 16)) = lo;
+            }
+        }
+    };
+    // staging schedule inside a 9-tap group: tap 0 load batch 0; tap 3 write batch 0, load batch 1; tap 6 write batch 1 (or
+    // generate the disparity group); the barrier follows before tap 8
+    auto stage_tap = [&](const SxStage& st, int bufoff, int t) {
+        if (st.kind == 2) {
+            if (SX_ABL & 1) return;
+            if (t == 0) stage_load(st, 0);
+            if (t == 3) { stage_store(bufoff, 0); stage_load(st, 1); }
+            if (t == 6) stage_store(bufoff, 1);
+        } else if (t == 6) {
+            if (st.kind == 1) gen_literal(st.g, bufoff);
+            else if (st.kind == 3) gen_collapsed(st.g, bufoff);
+        }
+    };
+    auto barrier = [&]() {
+        __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): this wave's LDS writes have landed, its reads returned
+        if (!(SX_ABL & 8)) __builtin_amdgcn_s_barrier();
+    };
+
+    // ---- the group sequence: tensors chunk by chunk (two half-chunk groups of 9 taps), then the disparity source
+    // stage descriptor of group number `gi` (or kind 0 past the end)
+    int ngroups_t = 0;
+    for (int s = 0; s < ntens; ++s) ngroups_t += a.ch[s] >> 4;
+    const int ngroups = ngroups_t + (dsrc ? (coll ? 6 : 4) : 0);
+    auto describe = [&](int gi) {
+        SxStage st;
+        st.kind = 0; st.base = nullptr; st.mtb = 0; st.g = 0;
+        if (gi >= ngroups) return st;
+        if (gi >= ngroups_t) { st.kind = coll ? 3 : 1; st.g = gi - ngroups_t; return st; }
+        int s = 0, g = gi;
+        while (g >= (a.ch[s] >> 4)) { g -= a.ch[s] >> 4; ++s; }
+        st.kind = 2; st.base = a.src[s] + g * 2048; st.mtb = (long)(a.ch[s] >> 4) * 2048;
+        return st;
+    };
+
+    // ---- prologue
+    if (dsrc) {
+        for (int idx = tid; idx < DROWS * SX_DTW; idx += 256) {
+            const int r = idx / SX_DTW, c = idx - r * SX_DTW;
+            const int gy = ty0 + r - 4, gx = tx0 + c - 4;
+            ldsD[idx] = (gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) ? dsrc[(long)gy * a.w + gx] : 0.f;
+        }
+    }
+    // m-tile m of this wave: m-tile row (ty0 >> 1) + wm*MT + m, column tile_x (tiles are whole m-tiles; rows past the image's
+    // last m-tile row do not exist in the tensors)
+    const int mrow0 = (ty0 >> 1) + wm * MT;
+    const long mt0 = (long)mrow0 * a.mtx + tile_x;
+    floatx16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const bool ok = mrow0 + m < a.mty;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.init) {                                  // acc32 layout: one 1-KiB line per (m-tile, n-tile, j)
+                if (ok) v = cer_ld4(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.init) +
+                                                                     (((mt0 + (long)m * a.mtx) * NT + (nb0 >> 5) + wn) * 4 + j) * 1024 + lane * 16));
+            } else if (a.bias) {
+                v = cer_ld4(a.bias + nb0 + wn * 32 + 8 * j + 4 * kg);
+            }
+            acc[m][4 * j + 0] = v.x * a.S; acc[m][4 * j + 1] = v.y * a.S; acc[m][4 * j + 2] = v.z * a.S; acc[m][4 * j + 3] = v.w * a.S;
+        }
+    }
+    {
+        const SxStage st0 = describe(0);
+        if (dsrc && st0.kind != 2) barrier();              // the disparity tile feeds the generators
+        stage_tap(st0, 0, 0);
+        stage_tap(st0, 0, 3);
+        stage_tap(st0, 0, 6);
+        barrier();
+    }
+
+    struct XFrag { half8 h[MT], l[MT]; };
+    struct WFrag { half8 h, l; };
+    XFrag fx;                                              // activation fragments of the CURRENT step; each m-tile's pair is re-loaded
+    WFrag fw[3];                                           // for the next step as soon as its last MFMA of this step has issued
+    auto load_x = [&](XFrag& f, int ph, int pl, int rowoff) {      // rowoff: compile-time (dy rows)
+        if (SX_ABL & 32) return;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            f.h[m] = *reinterpret_cast<const half8*>(sx_smem + ph + (2 * m) * SX_ROWB + rowoff);
+            f.l[m] = *reinterpret_cast<const half8*>(sx_smem + pl + (2 * m) * SX_ROWB + rowoff);
+        }
+    };
+    auto load_w = [&](WFrag& f, int step) {
+        const char* p = wlane + ((SX_ABL & 2) ? 0L : (long)min(step, nsteps - 1) * wstep);
+        f.h = *reinterpret_cast<const half8*>(p);
+        f.l = *reinterpret_cast<const half8*>(p + 1024);
+    };
+    // one step: 3 * MT MFMAs (consecutive MFMAs hit different accumulators), and the next step's fragments rolled in behind them
+    auto mma_roll = [&](const WFrag& w, int ph, int pl, int rowoff) {
+        if (SX_ABL & 16) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(fx.h[m]), "v"(fx.l[m]), "v"(w.h), "v"(w.l));
+#endif
+            load_x(fx, ph, pl, rowoff);
+            return;
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h, fx.h[m], acc[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h, fx.l[m], acc[m], 0, 0, 0);
+            if (!(SX_ABL & 32)) fx.l[m] = *reinterpret_cast<const half8*>(sx_smem + pl + (2 * m) * SX_ROWB + rowoff);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.l, fx.h[m], acc[m], 0, 0, 0);
+            if (!(SX_ABL & 32)) fx.h[m] = *reinterpret_cast<const half8*>(sx_smem + ph + (2 * m) * SX_ROWB + rowoff);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // first tap of group gi inside its buffer: tap 0 (dy = dx = 0), or the centre tap for a collapsed disparity group
+    const bool first_is_centre0 = describe(0).kind == 3;
+    load_w(fw[0], 0);
+    load_w(fw[1], 1);
+    if (first_is_centre0) load_x(fx, xh[1], xl[1], SX_ROWB);
+    else load_x(fx, xh[0], xl[0], 0);
+
+    SX_STAMP();                                            // [1] prologue done
+    int step = 0, gi = 0;                                  // gi: group of the current step; its buffer is (gi & 1) * ABUF
+    // ---- tensor half-chunks and literal disparity groups: 9 taps each
+    const int ngroups9 = ngroups_t + ((dsrc && !coll) ? 4 : 0);
+    for (; gi < ngroups9; ++gi, step += 9) {
+        vary = (gi >> 28) * 0x11111111;
+        const SxStage nx = describe(gi + 1);
+        const int bufC = (gi & 1) * ABUF, bufN = ABUF - bufC;
+        const bool nxt_centre = nx.kind == 3;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // (1) staging of the next group into the other buffer
+            if (t == 0 || t == 3 || t == 6) stage_tap(nx, bufN, t);
+            if (t == 8) barrier();                         // next group's data complete and visible; nobody reads its buffer's old contents any more
+            // (2) weights of step t + 2
+            load_w(fw[(t + 2) % 3], step + t + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            // (3) multiply step t, rolling in the operands of step t + 1
+            if (t < 8) mma_roll(fw[t % 3], xh[(t + 1) % 3] + bufC, xl[(t + 1) % 3] + bufC, ((t + 1) / 3) * SX_ROWB);
+            else if (nxt_centre) mma_roll(fw[t % 3], xh[1] + bufN, xl[1] + bufN, SX_ROWB);
+            else mma_roll(fw[t % 3], xh[0] + bufN, xl[0] + bufN, 0);
+        }
+        SX_STAMP();                                        // after every group
+    }
+    // ---- collapsed disparity: 6 groups of one (centre) tap
+    if (dsrc && coll) {
+        vary = (gi >> 28) * 0x11111111;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int bufC = ((gi + t) & 1) * ABUF, bufN = ABUF - bufC;
+            if (t < 5) {
+                gen_collapsed(t + 1, bufN);
+                barrier();
+            }
+            load_w(fw[(t + 2) % 3], step + t + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_roll(fw[t % 3], xh[1] + bufN, xl[1] + bufN, SX_ROWB);
+        }
+        step += 6;
+        gi += 6;
+    }
+    SX_STAMP();                                            // main loop done
+
+    // ---- epilogue.  acc[m][4j + e] = S * conv for channel nb0 + wn*32 + 8j + 4kg + e of the lane's pixel.
+    // v_permlane32_swap on register pairs (j = 2jp, 2jp + 1): lanes 0-31 end up with channels 16jp + 0..7, lanes 32-63 with
+    // 16jp + 8..15 of their pixel - 8 consecutive channels starting at cb = nb0 + wn*32 + 16jp + 8kg: exactly this lane's
+    // 16-byte pieces of the frag16 planes (hi | lo) of group cb >> 4, so every tensor access below is one contiguous KiB per wave.
+    const int half = a.cout >> 1;
+    if (SX_ABL & 4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(acc[m]));
+#endif
+        return;
+    }
+    if constexpr (EPI == SX_EPI_DELTA) {
+        // delta head, fused (core/update.py:68-71): hid = relu(conv) stays in registers; its hi|lo halves ARE B fragments of the
+        // projection  T[tap][p] = sum_c w2[tap][c] * hid[p][c]  over this wave's 32 channels (2 k16-steps x 3 MFMAs per m-tile);
+        // the four waves' partial tap planes are summed through LDS and leave as [9][P] planes for cer_delta_sum_f32.
+        static_assert(EPI != SX_EPI_DELTA || WM_ == 1, "the DELTA epilogue is built for the 1 x 4 wave layout");
+        const _Float16* w2 = reinterpret_cast<const _Float16*>(a.aux) + ((long)(by * WN_ + wn) * 2) * 1024;     // [jp][hi|lo][lane][8]
+        float* red = reinterpret_cast<float*>(sx_smem);    // [wn][m][tap 9][32 px]
+        static_assert(WN_ * MT * 9 * 32 * 4 <= 2 * ABUF, "reduction scratch does not fit");
+        barrier();                                         // every wave has finished reading the activation buffers
+        const float hs = a.invS * (float)(1 << SX_HID_LOG2);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            floatx16 tm;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tm[r] = 0.f;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[m][8 * jp + e]), __float_as_uint(acc[m][8 * jp + 4 + e]), false, false);
+                    v[e] = fmaxf(__uint_as_float(sw[0]), 0.f);
+                    v[4 + e] = fmaxf(__uint_as_float(sw[1]), 0.f);
+                }
+                half8 hh, hl;
+                sx_split8(v, hs, hh, hl);
+                const half8 wh = *reinterpret_cast<const half8*>(w2 + (jp * 2 + 0) * 512 + lane * 8);
+                const half8 wl = *reinterpret_cast<const half8*>(w2 + (jp * 2 + 1) * 512 + lane * 8);
+                tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hh, tm, 0, 0, 0);
+                tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hl, tm, 0, 0, 0);
+                tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hh, tm, 0, 0, 0);
+            }
+            // tm[r]: tap (r&3) + 8(r>>2) + 4kg of pixel li: kg = 0 holds taps 0-3 and 8, kg = 1 taps 4-7
+            float* rp = red + ((wn * MT + m) * 9) * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rp[(r + 4 * kg) * 32] = tm[r];
+            if (kg == 0) rp[8 * 32] = tm[4];
+        }
+        barrier();
+        const long P = (long)a.h * a.w;
+        for (int idx = tid; idx < MT * 9 * 32; idx += 256) {
+            const int m = idx / (9 * 32), rem = idx - m * 9 * 32, tap = rem >> 5, px = rem & 31;
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < WN_; ++q) s += red[((q * MT + m) * 9 + tap) * 32 + px];
+            const int gy = ty0 + 2 * m + (px >> 4), gx = tx0 + (px & 15);
+            if (gy < a.h && gx < a.w) a.out[((long)by * 9 + tap) * P + (long)gy * a.w + gx] = s * a.proj_inv;
+        }
+        return;
+    } else {
+        const int nt = (nb0 >> 5) + wn;                    // this wave's 32-channel tile of the output
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (mrow0 + m >= a.mty) continue;              // wave-uniform: the m-tile row is past the image
+            const long mt = mt0 + (long)m * a.mtx;
+            if (EPI == CER_EPI_LINEAR && !a.out_split) {   // acc32 layout: the accumulators as they are (a later conv's `init`)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.out) + ((mt * NT + nt) * 4 + j) * 1024 + lane * 16) =
+                        make_float4(acc[m][4 * j] * a.invS, acc[m][4 * j + 1] * a.invS, acc[m][4 * j + 2] * a.invS, acc[m][4 * j + 3] * a.invS);
+                continue;
+            }
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[m][8 * jp + e]), __float_as_uint(acc[m][8 * jp + 4 + e]), false, false);
+                    v[e] = __uint_as_float(sw[0]) * a.invS;
+                    v[4 + e] = __uint_as_float(sw[1]) * a.invS;
+                }
+                // frag16 planes of channel group g of a C-channel tensor: ((mt * C/16 + g) * 2 + hl) * 1024 + lane * 16
+                auto st_split = [&](float* base, int G, int g, const float (&o)[8]) {
+                    half8 hi, lo;
+                    sx_split8(o, a.out_scale, hi, lo);
+                    char* p = reinterpret_cast<char*>(base) + ((mt * G + g) * 2) * 1024 + lane * 16;
+                    *reinterpret_cast<half8*>(p) = hi;
+                    *reinterpret_cast<half8*>(p + 1024) = lo;
+                };
+                auto ld_split = [&](const float* base, int G, int g, float (&o)[8]) {
+                    const char* p = reinterpret_cast<const char*>(base) + ((mt * G + g) * 2) * 1024 + lane * 16;
+                    sx_join8(*reinterpret_cast<const half8*>(p), *reinterpret_cast<const half8*>(p + 1024), a.aux_inv, o);
+                };
+                // fp32 "swapped" layout (z): ((mt * C/16 + g) * 2 + q) * 1024 + lane * 16, q = first / second float4 of the 8 channels
+                auto st_f32 = [&](float* base, int G, int g, const float (&o)[8]) {
+                    char* p = reinterpret_cast<char*>(base) + ((mt * G + g) * 2) * 1024 + lane * 16;
+                    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+                    *reinterpret_cast<float4*>(p + 1024) = make_float4(o[4], o[5], o[6], o[7]);
+                };
+                const int gl = (((nt * 32) % half) >> 4) + jp;                   // GATES: 16-channel group inside z / r*h
+                if (EPI == CER_EPI_LINEAR || EPI == CER_EPI_RELU) {
+                    if (EPI == CER_EPI_RELU)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    st_split(a.out, a.cout >> 4, nt * 2 + jp, v);
+                } else if (EPI == CER_EPI_GATES) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = sx_sigmoid(v[e]);
+                    if (nt * 32 < half) {
+                        st_f32(a.out, half >> 4, gl, v);                         // z stays fp32 (blend operand of the q conv)
+                    } else {
+                        float hp[8];
+                        ld_split(a.aux, half >> 4, gl, hp);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= hp[e];
+                        st_split(a.out2, half >> 4, gl, v);
+                    }
+                } else if (EPI == CER_EPI_GRU) {
+                    float hp[8];
+                    ld_split(a.aux, a.cout >> 4, nt * 2 + jp, hp);
+                    const char* zp = reinterpret_cast<const char*>(a.aux2) + ((mt * (a.cout >> 4) + nt * 2 + jp) * 2) * 1024 + lane * 16;
+                    const float4 z0 = *reinterpret_cast<const float4*>(zp), z1 = *reinterpret_cast<const float4*>(zp + 1024);
+                    const float z[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (1.0f - z[e]) * hp[e] + z[e] * tanhf(v[e]);
+                    st_split(a.out, a.cout >> 4, nt * 2 + jp, v);
+                }
+            }
+        }
+    }
+#if SX_TRACE
+    if ((EPI == CER_EPI_GATES || EPI == CER_EPI_GRU) && lane == 0) {
+        unsigned long long* tb = (unsigned long long*)(EPI == CER_EPI_GATES ? (const void*)a.aux2 : (const void*)a.out2) + ((long)blockIdx.x * 4 + wave) * 32;
+        tb[0] = (unsigned long long)trace_n;
+        tb[1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+        tb[2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+        tb[3] = __builtin_readcyclecounter();
+        tb[4] = (unsigned long long)nsteps;
+#pragma unroll
+        for (int k = 0; k < 24; ++k) tb[8 + k] = trace_t[k];
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------- host side
+
+static int sx_order(const int* kind, int nsrc, int* order) {               // tensors first, the disparity source last
+    int n = 0, nd = 0;
+    for (int s = 0; s < nsrc; ++s) if (kind[s] != 1) order[n++] = s;
+    for (int s = 0; s < nsrc; ++s) if (kind[s] == 1) { order[n++] = s; ++nd; }
+    return nd;
+}
+
+static long sx_steps(const int* ch, const int* kind, int nsrc, int collapsed) {
+    long steps = 0;
+    for (int s = 0; s < nsrc; ++s) steps += kind[s] == 1 ? (collapsed ? 6 : 36) : (ch[s] / 16) * 9;
+    return steps;
+}
+
+extern "C" long cer_conv3x3_s16_packed_size(int Cout, const int* ch, const int* kind, int nsrc, int collapsed) {
+    if (!ch || !kind || nsrc <= 0 || nsrc > CER_CONV_MAX_SRC || Cout <= 0 || Cout % 32) return CER_ESHAPE;
+    int nd = 0;
+    for (int s = 0; s < nsrc; ++s) {
+        if (kind[s] == 1) { ++nd; if (ch[s] != 49) return CER_ESHAPE; }
+        else if (ch[s] % 32) return CER_ESHAPE;
+    }
+    if (nd > 1 || (collapsed && nd == 0)) return CER_ESHAPE;
+    return sx_steps(ch, kind, nsrc, collapsed) * (Cout / 32) * 1024;        // in halves
+}
+
+// collapsed 81-tap filter of the disparity source (see gru_f16x3.hip: cer_conv3x3_f16x3_pack_collapsed), fp64 sums
+static double sx_w9(const float* w, int Cin, int co, int c, int sidx) {
+    if (sidx >= 81) return 0.0;
+    const int sy = sidx / 9, sx = sidx % 9;
+    double acc = 0.0;
+    for (int ty = 0; ty < 3; ++ty)
+        for (int tx = 0; tx < 3; ++tx) {
+            const int uy = sy - ty, ux = sx - tx;
+            if (uy >= 0 && uy < 7 && ux >= 0 && ux < 7) acc += (double)w[((long)co * Cin + c + uy * 7 + ux) * 9 + ty * 3 + tx];
+        }
+    if (sy >= 3 && sy <= 5 && sx >= 3 && sx <= 5) {
+        const int t = (sy - 3) * 3 + (sx - 3);
+        for (int u = 0; u < 49; ++u) acc -= (double)w[((long)co * Cin + c + u) * 9 + t];
+    }
+    return acc;
+}
+
+// log2 of the product scale S shared by all sources: the largest power of two that keeps every scaled weight
+// |w| * S / 2^log2sx(src) below 2^14 (f16 max 65504), for the literal and the collapsed packing alike.  Returns CER_ESHAPE
+// (as a value < -1000) if some source's largest scaled weight would then fall below 2 (its lo half would lose bits).
+extern "C" int cer_conv3x3_s16_scale(const float* w, int Cout, int Cin, const int* ch, const int* kind, const int* log2sx, int nsrc) {
+    if (!w || !ch || !kind || !log2sx || nsrc <= 0 || nsrc > CER_CONV_MAX_SRC) return -100000;
+    double wmax[CER_CONV_MAX_SRC];
+    int c = 0;
+    for (int s = 0; s < nsrc; ++s) {
+        double m = 0.0;
+        for (int co = 0; co < Cout; ++co) {
+            for (int i = 0; i < ch[s]; ++i)
+                for (int t = 0; t < 9; ++t) m = fmax(m, fabs((double)w[((long)co * Cin + c + i) * 9 + t]));
+            if (kind[s] == 1)
+                for (int sidx = 0; sidx < 81; ++sidx) m = fmax(m, fabs(sx_w9(w, Cin, co, c, sidx)));
+        }
+        wmax[s] = m;
+        c += ch[s];
+    }
+    if (c != Cin) return -100000;
+    int best = 1000;
+    for (int s = 0; s < nsrc; ++s) {
+        if (wmax[s] <= 0.0) continue;
+        const int k = (int)floor(log2(16384.0 / wmax[s])) + log2sx[s];
+        best = k < best ? k : best;
+    }
+    if (best == 1000) best = 14;
+    return best;
+}
+
+static void sx_pack_slice(_Float16* packed, long step, int NT, int nt, const double* col /* [16 k][32 co] */, double scale) {
+    for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 8; ++e) {
+            float v = (float)(col[((lane >> 5) * 8 + e) * 32 + (lane & 31)] * scale);
+            v = v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v);
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (float)hi);
+            const long base = (step * NT + nt) * 2;
+            packed[(base + 0) * 512 + lane * 8 + e] = hi;
+            packed[(base + 1) * 512 + lane * 8 + e] = lo;
+        }
+}
+
+// OIHW fp32 -> [step][ntile32][hi|lo][lane][8] halves of w * 2^(log2S - log2sx(src)); steps: tensors in source order
+// (32-channel chunk, 16-channel half, tap), then the disparity source (collapsed: 6 single-tap groups of the 81-tap filter;
+// literal: 4 groups x 9 taps of the 49 unfold channels)
+extern "C" int cer_conv3x3_s16_pack(const float* w, void* packed_v, int Cout, int Cin, const int* ch, const int* kind, const int* log2sx,
+                                    int nsrc, int collapsed, int log2S) {
+    if (!w || !packed_v || !ch || !kind || !log2sx) return CER_EINVAL;
+    if (cer_conv3x3_s16_packed_size(Cout, ch, kind, nsrc, collapsed) < 0) return CER_ESHAPE;
+    int order[CER_CONV_MAX_SRC], c0[CER_CONV_MAX_SRC];
+    sx_order(kind, nsrc, order);
+    int c = 0;
+    for (int s = 0; s < nsrc; ++s) { c0[s] = c; c += ch[s]; }
+    if (c != Cin) return CER_ESHAPE;
+    _Float16* packed = (_Float16*)packed_v;
+    const int NT = Cout / 32;
+    double col[16 * 32];
+    long step = 0;
+    for (int oi = 0; oi < nsrc; ++oi) {
+        const int s = order[oi];
+        const double scale = ldexp(1.0, log2S - log2sx[s]);
+        if (kind[s] != 1) {
+            for (int g = 0; g < ch[s] / 16; ++g)
+                for (int tap = 0; tap < 9; ++tap, ++step)
+                    for (int nt = 0; nt < NT; ++nt) {
+                        for (int k = 0; k < 16; ++k)
+                            for (int j = 0; j < 32; ++j) col[k * 32 + j] = w[((long)(nt * 32 + j) * Cin + c0[s] + g * 16 + k) * 9 + tap];
+                        sx_pack_slice(packed, step, NT, nt, col, scale);
+                    }
+        } else if (collapsed) {
+            for (int g = 0; g < 6; ++g, ++step)
+                for (int nt = 0; nt < NT; ++nt) {
+                    for (int k = 0; k < 16; ++k)
+                        for (int j = 0; j < 32; ++j) col[k * 32 + j] = sx_w9(w, Cin, nt * 32 + j, c0[s], g * 16 + k);
+                    sx_pack_slice(packed, step, NT, nt, col, scale);
+                }
+        } else {
+            for (int g = 0; g < 4; ++g)
+                for (int tap = 0; tap < 9; ++tap, ++step)
+                    for (int nt = 0; nt < NT; ++nt) {
+                        for (int k = 0; k < 16; ++k)
+                            for (int j = 0; j < 32; ++j) {
+                                const int ci = g * 16 + k;
+                                col[k * 32 + j] = ci < 49 ? w[((long)(nt * 32 + j) * Cin + c0[s] + ci) * 9 + tap] : 0.0;
+                            }
+                        sx_pack_slice(packed, step, NT, nt, col, scale);
+                    }
+        }
+    }
+    return CER_OK;
+}
+
+// delta head projection: w2 OIHW [1, C, 3, 3] -> A fragments [C/32][k16-step 2][hi|lo][lane][8]: lane (tap = lane & 31, kg = lane >> 5)
+// holds channels 32*blk + 16*jp + 8*kg + e, scaled by 2^log2s (tap >= 9: zero)
+extern "C" long cer_delta_proj_s16_packed_size(int C) { return C % 128 ? CER_ESHAPE : (long)(C / 32) * 2 * 2 * 512; }
+
+extern "C" int cer_delta_proj_s16_pack(const float* w2, void* packed_v, int C, int* log2s_out) {
+    if (!w2 || !packed_v || !log2s_out) return CER_EINVAL;
+    if (C % 128) return CER_ESHAPE;
+    double m = 0.0;
+    for (long i = 0; i < (long)C * 9; ++i) m = fmax(m, fabs((double)w2[i]));
+    const int log2s = m > 0.0 ? (int)floor(log2(16384.0 / m)) : 14;
+    *log2s_out = log2s;
+    _Float16* packed = (_Float16*)packed_v;
+    for (int blk = 0; blk < C / 32; ++blk)
+        for (int jp = 0; jp < 2; ++jp)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int tap = lane & 31, c = blk * 32 + jp * 16 + (lane >> 5) * 8 + e;
+                    float v = tap < 9 ? (float)ldexp((double)w2[(long)c * 9 + tap], log2s) : 0.f;
+                    v = v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v);
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    packed[(((long)blk * 2 + jp) * 2 + 0) * 512 + lane * 8 + e] = hi;
+                    packed[(((long)blk * 2 + jp) * 2 + 1) * 512 + lane * 8 + e] = lo;
+                }
+    return CER_OK;
+}
+
+template <int WM_, int WN_, int MT>
+static int sx_launch(S16Args& a, int epi, hipStream_t st) {
+    constexpr int TH = WM_ * 2 * MT, HR = TH + 2;
+    const size_t smem = 2 * HR * SX_ROWB + (HR + 6) * SX_DTW * 4;
+    const int tiles_y = (a.h + TH - 1) / TH;
+    a.tiles_x = (a.w + SX_TW - 1) / SX_TW;
+    a.mtx = a.tiles_x;
+    a.mty = (a.h + 1) / 2;
+    if ((long)a.mtx * a.mty >= (1L << 20)) return CER_ESHAPE;
+    a.ntiles = a.tiles_x * tiles_y;
+    a.ny = a.cout / (WN_ * 32);
+    dim3 grid((unsigned)(a.ntiles * a.ny)), block(256);
+    switch (epi) {
+        case CER_EPI_LINEAR: hipLaunchKernelGGL((conv3x3_s16_kernel<WM_, WN_, MT, CER_EPI_LINEAR>), grid, block, smem, st, a); break;
+        case CER_EPI_RELU: hipLaunchKernelGGL((conv3x3_s16_kernel<WM_, WN_, MT, CER_EPI_RELU>), grid, block, smem, st, a); break;
+        case CER_EPI_GATES: hipLaunchKernelGGL((conv3x3_s16_kernel<WM_, WN_, MT, CER_EPI_GATES>), grid, block, smem, st, a); break;
+        case CER_EPI_GRU: hipLaunchKernelGGL((conv3x3_s16_kernel<WM_, WN_, MT, CER_EPI_GRU>), grid, block, smem, st, a); break;
+        case SX_EPI_DELTA:
+            if constexpr (WM_ == 1) {
+                hipLaunchKernelGGL((conv3x3_s16_kernel<WM_, WN_, MT, SX_EPI_DELTA>), grid, block, smem, st, a);
+                break;
+            } else {
+                return CER_ESHAPE;
+            }
+        default: return CER_EINVAL;
+    }
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}
+
+static int sx_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+extern "C" int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, const void* packed_w, const void* packed_collapsed, int log2S,
+                               const float* bias, const float* init, float* out, float* out2, const float* aux, const float* aux2, int h,
+                               int w, int Cout, int epi, int log2s_out, int log2s_aux, int tile_mt, void* stream) {
+    if (!in || !log2sx || !packed_w || !out || h <= 0 || w <= 0 || Cout <= 0) return CER_EINVAL;
+    if (in->nsrc <= 0 || in->nsrc > CER_CONV_MAX_SRC) return CER_EINVAL;
+    const int out_split = (epi & CER_EPI_OUT_SPLIT) != 0;
+    epi &= ~(CER_EPI_OUT_SPLIT | CER_EPI_AUX_SPLIT);
+    if (epi == CER_EPI_GATES && (!out2 || !aux || Cout != 128)) return CER_EINVAL;
+    if (epi == CER_EPI_GRU && (!aux || !aux2)) return CER_EINVAL;
+    if (epi == SX_EPI_DELTA && (!aux || Cout % 128 != 0)) return CER_EINVAL;
+    if (Cout % 64 != 0) return CER_ESHAPE;
+    if ((long)h * w >= (1L << 27)) return CER_ESHAPE;
+    if (!cer_aligned16(packed_w) || !cer_aligned16(packed_collapsed) || !cer_aligned16(init) || !cer_aligned16(bias) || !cer_aligned16(out) ||
+        !cer_aligned16(out2) || !cer_aligned16(aux) || !cer_aligned16(aux2))
+        return CER_EALIGN;
+    S16Args a;
+    memset(&a, 0, sizeof(a));
+    int order[CER_CONV_MAX_SRC];
+    const int nd = sx_order(in->kind, in->nsrc, order);
+    if (nd > 1) return CER_ESHAPE;
+    a.nsrc = in->nsrc;
+    for (int oi = 0; oi < in->nsrc; ++oi) {
+        const int s = order[oi];
+        if (!in->src[s]) return CER_EINVAL;
+        if (in->kind[s] != 1 && in->kind[s] != 2) return CER_EINVAL;
+        if (in->kind[s] == 2 && (in->ch[s] % 32 != 0 || !cer_aligned16(in->src[s]))) return CER_ESHAPE;
+        if (in->kind[s] == 1 && in->ch[s] != 49) return CER_ESHAPE;
+        a.src[oi] = reinterpret_cast<const char*>(in->src[s]);
+        a.ch[oi] = in->ch[s];
+        a.kind[oi] = in->kind[s];
+        if (in->kind[s] == 1) a.disp_scale = ldexpf(1.0f, log2sx[s]);
+    }
+    a.wpk = (const _Float16*)packed_w;
+    a.wpk_c = (const _Float16*)packed_collapsed;
+    a.bias = bias;
+    a.init = init;
+    a.out = out;
+    a.out2 = out2;
+    a.aux = aux;
+    a.aux2 = aux2;
+    a.h = h;
+    a.w = w;
+    a.cout = Cout;
+    a.S = ldexpf(1.0f, log2S);
+    a.invS = ldexpf(1.0f, -log2S);
+    a.out_scale = ldexpf(1.0f, log2s_out);
+    a.aux_inv = ldexpf(1.0f, -log2s_aux);
+    a.proj_inv = ldexpf(1.0f, -(SX_HID_LOG2 + log2s_aux));         // DELTA: log2s_aux carries the projection weights' scale
+    a.out_split = out_split;
+    hipStream_t st = (hipStream_t)stream;
+    const int ncu = sx_num_cus();
+    if (Cout % 128 == 0) {
+        // 1 x 4 waves, tile 2*MT x 16: pick the tile height that leaves the fewest idle CU-rounds (tile_mt forces it)
+        // (tile_mt = 5 - 10-row tiles, fewer idle CU-rounds at 296 x 400 - is kept for experiments: it still spills registers)
+        return tile_mt == 5 ? sx_launch<1, 4, 5>(a, epi, st) : sx_launch<1, 4, 4>(a, epi, st);
+    }
+    if (epi == SX_EPI_DELTA || epi == CER_EPI_GATES) return CER_ESHAPE;
+    int mt = tile_mt;
+    if (mt != 3 && mt != 4) {
+        long best = -1;
+        for (int c = 3; c <= 4; ++c) {
+            const long nblk = (long)((h + 4 * c - 1) / (4 * c)) * ((w + SX_TW - 1) / SX_TW) * (Cout / 64);
+            const long cost = ((nblk + ncu - 1) / ncu) * c;
+            if (best < 0 || cost < best) { best = cost; mt = c; }
+        }
+    }
+    return mt == 3 ? sx_launch<2, 2, 3>(a, epi, st) : sx_launch<2, 2, 4>(a, epi, st);
+}
+
+// ---- layout conversion (model load / API boundaries / tests): plain fp32 [h*w, C] <-> the m-tile-major layouts of the s16 convs.
+// An m-tile = 2 rows x 16 columns of pixels, lane order li = (y & 1) * 16 + (x & 15); tensors hold ceil(h/2) * ceil(w/16) m-tiles.
+//   layout 0 "frag16": per (m-tile, 16-channel group): 1 KiB of hi halves | 1 KiB of lo halves of x * 2^log2s; inside a plane
+//            piece (kg = (c >> 3) & 1, li) holds channels 8kg .. 8kg+7: the B-fragment order of v_mfma_f32_32x32x16_f16;
+//   layout 1 "acc32":  fp32, per (m-tile, 32-channel tile, j < 4): 1 KiB, lane (kg, li) holds channels 8j + 4kg + 0..3 (the MFMA
+//            accumulator order; `init` of cer_conv3x3_s16 and its LINEAR output);
+//   layout 2 "f32x8":  fp32, per (m-tile, 16-channel group, q < 2): 1 KiB, lane (kg, li) holds channels 8kg + 4q + 0..3 (the GATES
+//            epilogue's z).
+//   layout 3: frag16 pieces copied verbatim (no arithmetic): the plain side holds, per pixel and 8 channels, hi 16 B | lo 16 B -
+//            used to move image rows of a frag16 tensor (the row-slab halo exchange, slab.py).
+// The plain side covers image rows [y0, y0 + nrows) only.
+__global__ __launch_bounds__(256) void s16_layout_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int C, int layout,
+                                                         float scale, float inv, int inverse, int y0, int nrows) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // one thread per (pixel, 8 consecutive channels)
+    const long n8 = (long)nrows * w * (C / 8);
+    if (i >= n8) return;
+    const long pix = i / (C / 8);
+    const int cb = (int)(i - pix * (C / 8)) * 8;
+    const int y = y0 + (int)(pix / w), x = (int)(pix % w);
+    const long mt = (long)(y >> 1) * ((w + 15) >> 4) + (x >> 4);
+    const int li = ((y & 1) << 4) | (x & 15);
+    char* t = reinterpret_cast<char*>(inverse ? const_cast<float*>(src) : dst);
+    float* plain = (inverse ? dst : const_cast<float*>(src)) + pix * C + cb;
+    char *p0, *p1;                                         // the two 16-byte pieces of this thread
+    if (layout == 0 || layout == 3) {
+        p0 = t + ((mt * (C >> 4) + (cb >> 4)) * 2) * 1024 + ((((cb >> 3) & 1) << 5) | li) * 16;
+        p1 = p0 + 1024;
+    } else if (layout == 1) {
+        p0 = t + ((mt * (C >> 5) + (cb >> 5)) * 4 + ((cb & 31) >> 3)) * 1024 + li * 16;
+        p1 = p0 + 512;                                     // kg = 1
+    } else {
+        p0 = t + ((mt * (C >> 4) + (cb >> 4)) * 2) * 1024 + ((((cb >> 3) & 1) << 5) | li) * 16;
+        p1 = p0 + 1024;
+    }
+    float v[8];
+    if (!inverse) {
+        const float4 t0 = cer_ld4(plain), t1 = cer_ld4(plain + 4);
+        v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+        if (layout == 0) {
+            half8 hi, lo;
+            sx_split8(v, scale, hi, lo);
+            *reinterpret_cast<half8*>(p0) = hi;
+            *reinterpret_cast<half8*>(p1) = lo;
+        } else {
+            *reinterpret_cast<float4*>(p0) = t0;
+            *reinterpret_cast<float4*>(p1) = t1;
+        }
+    } else {
+        if (layout == 0) {
+            sx_join8(*reinterpret_cast<const half8*>(p0), *reinterpret_cast<const half8*>(p1), inv, v);
+            *reinterpret_cast<float4*>(plain) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(plain + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            *reinterpret_cast<float4*>(plain) = *reinterpret_cast<const float4*>(p0);
+            *reinterpret_cast<float4*>(plain + 4) = *reinterpret_cast<const float4*>(p1);
+        }
+    }
+}
+
+extern "C" long cer_s16_padded_pixels(int h, int w) { return (h <= 0 || w <= 0) ? CER_EINVAL : (long)((h + 1) / 2) * ((w + 15) / 16) * 32; }
+
+extern "C" int cer_s16_layout_f32(const float* src, float* dst, int h, int w, int C, int layout, int log2s, int inverse, void* stream) {
+    if (!src || !dst || h <= 0 || w <= 0 || C <= 0 || layout < 0 || layout > 2) return CER_EINVAL;
+    if (C % (layout == 1 ? 32 : 16) != 0) return CER_ESHAPE;
+    if (!cer_aligned16(src) || !cer_aligned16(dst)) return CER_EALIGN;
+    const long n8 = (long)h * w * (C / 8);
+    hipLaunchKernelGGL(s16_layout_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, w, C, layout,
+                       ldexpf(1.0f, log2s), ldexpf(1.0f, -log2s), inverse, 0, h);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}
+
+// image rows [y0, y0 + nrows) of a frag16 tensor (h x w image, C channels) -> rows [nrows * w, C] (to_tensor = 0) or back (= 1);
+// bit-exact copies of the hi | lo pieces (the row-slab halo exchange)
+extern "C" int cer_s16_rows_f32(float* tensor, float* rows, int h, int w, int C, int y0, int nrows, int to_tensor, void* stream) {
+    if (!tensor || !rows || h <= 0 || w <= 0 || C <= 0 || y0 < 0 || nrows <= 0 || y0 + nrows > h) return CER_EINVAL;
+    if (C % 16 != 0) return CER_ESHAPE;
+    if (!cer_aligned16(tensor) || !cer_aligned16(rows)) return CER_EALIGN;
+    const long n8 = (long)nrows * w * (C / 8);
+    if (to_tensor)
+        hipLaunchKernelGGL(s16_layout_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, tensor, w, C, 3, 1.0f, 1.0f, 0, y0, nrows);
+    else
+        hipLaunchKernelGGL(s16_layout_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tensor, rows, w, C, 3, 1.0f, 1.0f, 1, y0, nrows);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}

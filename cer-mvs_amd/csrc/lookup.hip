@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(const float* __restrict__ v
 __global__ __launch_bounds__(256) void lookup_encode_kernel(const float* __restrict__ vol, const float* __restrict__ origin,
                                                             const float* __restrict__ disp, const float* __restrict__ wgt,
                                                             const float* __restrict__ bias, float* __restrict__ out, long P, int D, int rs,
-                                                            float incre, int L, int r, LevelInfo li, int out_split) {
+                                                            float incre, int L, int r, LevelInfo li, int out_split, float out_scale, int img_w) {
     extern __shared__ __attribute__((aligned(16))) float lk_smem[];
     const int rsp = rs + 4;
     const int taps = 2 * r + 1, K = L * taps;
@@ -122,6 +122,27 @@ __global__ __launch_bounds__(256) void lookup_encode_kernel(const float* __restr
         const float* wr = wgt + k * 64 + grp * 16;           // wave-uniform: scalar loads
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = fmaf(f, wr[j], acc[j]);
+    }
+    if (out_split == 2) {
+        // frag16 layout (cer_mvs.h, conv_s16.hip): this thread's 16 channels are group `grp` of its pixel's m-tile: four 16-byte
+        // pieces (hi | lo planes x channel octets) of relu(acc) * out_scale
+        const long p = p0 + pix;
+        const int y = (int)(p / img_w), x = (int)(p - (long)y * img_w);
+        const long mt = (long)(y >> 1) * ((img_w + 15) >> 4) + (x >> 4);
+        char* dst = reinterpret_cast<char*>(out) + ((mt * 4 + grp) * 2) * 1024 + (((y & 1) << 4) | (x & 15)) * 16;
+#pragma unroll
+        for (int j = 0; j < 16; j += 8) {
+            cer_h8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xs = fminf(fmaxf(acc[j + e], 0.f) * out_scale, 65504.0f);
+                hi[e] = (_Float16)xs;
+                lo[e] = (_Float16)(xs - (float)hi[e]);
+            }
+            *reinterpret_cast<cer_h8*>(dst + (j >> 3) * 512) = hi;
+            *reinterpret_cast<cer_h8*>(dst + 1024 + (j >> 3) * 512) = lo;
+        }
+        return;
     }
     if (out_split) {
         // split32 layout (cer_mvs.h): per pixel and 32-channel chunk 32 hi halves | 32 lo halves - the corr2 conv then stages
@@ -175,9 +196,10 @@ extern "C" int cer_corr_lookup_f32(const float* vol, const float* origin, const 
 
 extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, const float* disp, const float* w, const float* b, float* out,
                                      long P, int D, int row_stride, double incre, int num_levels, int radius, int Cout, int out_split,
-                                     void* stream) {
+                                     int log2s_out, int img_w, void* stream) {
     if (!vol || !origin || !disp || !w || !b || !out || P <= 0 || D <= 0) return CER_EINVAL;
     if (Cout != 64 || num_levels > 4) return CER_ESHAPE;
+    if (out_split == 2 && (img_w <= 0 || P % img_w != 0)) return CER_ESHAPE;
     if (!cer_aligned16(vol) || !cer_aligned16(out)) return CER_EALIGN;
     LevelInfo li;
     int rc = level_info(D, row_stride, num_levels, radius, &li);
@@ -185,7 +207,7 @@ extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, cons
     hipLaunchKernelGGL(lookup_encode_kernel, dim3((unsigned)((P + LK_PIX - 1) / LK_PIX)), dim3(256),
                        sizeof(float) * LK_PIX * (row_stride + 4 > num_levels * (2 * radius + 1) + 1 ? row_stride + 4 : num_levels * (2 * radius + 1) + 1),
                        (hipStream_t)stream, vol, origin, disp, w,
-                       b, out, P, D, row_stride, (float)incre, num_levels, radius, li, out_split);
+                       b, out, P, D, row_stride, (float)incre, num_levels, radius, li, out_split, ldexpf(1.0f, log2s_out), img_w);
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }

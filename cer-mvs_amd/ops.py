@@ -101,14 +101,16 @@ def corr_encode(feats, w_t, b, out=None):
     return out
 
 
-def lookup_encode(vol, origin, disp, w_t, b, D, incre, num_levels, radius, out=None, out_split=False):
-    """Folded volume [P,rs] -> relu(conv1x1(lookup)) [P,64] (``out_split``: in the split32 layout, see ``split32``)."""
+def lookup_encode(vol, origin, disp, w_t, b, D, incre, num_levels, radius, out=None, out_split=False, log2s=0, img_w=0):
+    """Folded volume [P,rs] -> relu(conv1x1(lookup)) [P,64] (``out_split``: True / 1 = split32 layout, see ``split32``;
+    2 = frag16 layout of an image ``img_w`` pixels wide with scale 2^log2s, see ``s16_layout``: ``out`` [s16_pixels, 64])."""
     P, rs = vol.shape
     if out is None:
-        out = torch.empty(P, 64, device=vol.device, dtype=torch.float32)
+        rows = s16_pixels(P // img_w, img_w) if int(out_split) == 2 else P
+        out = torch.zeros(rows, 64, device=vol.device, dtype=torch.float32)
     L.check(L.load().cer_lookup_encode_f32(L.dev_ptr(vol, "vol"), L.dev_ptr(origin, "origin"), L.dev_ptr(disp, "disp"),
                                            L.dev_ptr(w_t, "w"), L.dev_ptr(b, "b"), L.dev_ptr(out, "out"), P, D, rs, float(incre),
-                                           num_levels, radius, 64, int(bool(out_split)), L.cur_stream()), "lookup_encode")
+                                           num_levels, radius, 64, int(out_split), int(log2s), int(img_w), L.cur_stream()), "lookup_encode")
     return out
 
 
@@ -302,3 +304,131 @@ def split32(x, inverse=False, out=None):
         out = torch.empty_like(x)
     L.check(L.load().cer_split32_f32(L.dev_ptr(x, "src"), L.dev_ptr(out, "dst"), P, C, int(bool(inverse)), L.cur_stream()), "split32")
     return out
+
+
+# ------------------------------------------------------------------------------------ "s16" convolutions (csrc/conv_s16.hip)
+def s16_pixels(h, w):
+    """Rows of an s16 tensor of an h x w image: whole m-tiles (2 rows x 16 columns), cer_s16_padded_pixels."""
+    return (h + 1) // 2 * ((w + 15) // 16) * 32
+
+
+def s16_layout(x, h, w, layout, log2s=0, inverse=False, out=None):
+    """Plain fp32 [h*w, C] -> m-tile-major layout ``layout`` (L.S16_FRAG16 with scale 2^log2s | L.S16_ACC32 | L.S16_F32X8, see
+    cer_mvs.h) as a [s16_pixels(h, w), C] tensor, or back (``inverse``)."""
+    C = x.shape[1]
+    if out is None:
+        out = torch.zeros(s16_pixels(h, w), C, device=x.device, dtype=torch.float32) if not inverse else \
+            torch.empty(h * w, C, device=x.device, dtype=torch.float32)
+    if x.shape[0] != (s16_pixels(h, w) if inverse else h * w):
+        raise ValueError(f"s16_layout: {tuple(x.shape)} does not match a {h}x{w} image")
+    L.check(L.load().cer_s16_layout_f32(L.dev_ptr(x, "src"), L.dev_ptr(out, "dst"), h, w, C, int(layout), int(log2s), int(bool(inverse)),
+                                        L.cur_stream()), "s16_layout")
+    return out
+
+
+def s16_rows(tensor, rows, h, w, y0, nrows, to_tensor):
+    """Image rows [y0, y0+nrows) of a frag16 tensor [s16_pixels(h,w), C] <-> ``rows`` (flat, nrows*w*C floats), bit-exact."""
+    C = tensor.shape[1]
+    if rows.numel() != nrows * w * C:
+        raise ValueError("s16_rows: buffer size mismatch")
+    L.check(L.load().cer_s16_rows_f32(L.dev_ptr(tensor, "tensor"), L.dev_ptr(rows, "rows"), h, w, C, int(y0), int(nrows), int(bool(to_tensor)),
+                                      L.cur_stream()), "s16_rows")
+
+
+def to_frag16(x, h, w, log2s, out=None):
+    return s16_layout(x, h, w, L.S16_FRAG16, log2s, out=out)
+
+
+def from_frag16(x, h, w, log2s):
+    return s16_layout(x, h, w, L.S16_FRAG16, log2s, inverse=True)
+
+
+class PackedConvS16:
+    """A 3x3 conv's weights packed for ``conv3x3_s16``.  ``sources``: list of (channels, kind, log2 scale) in the weight's
+    input-channel order; kind 2 = frag16 tensor, kind 1 = disparity encoder (49 channels, generated in the kernel)."""
+
+    def __init__(self, weight, bias, sources, device):
+        lib = L.load()
+        w = weight.detach().to("cpu", torch.float32).contiguous()
+        Cout, Cin = w.shape[0], w.shape[1]
+        self.sources = list(sources)
+        n = len(sources)
+        self.ch = (ctypes.c_int * n)(*[c for c, _, _ in sources])
+        self.kind = (ctypes.c_int * n)(*[k for _, k, _ in sources])
+        self.log2sx = (ctypes.c_int * L.CONV_MAX_SRC)(*([s for _, _, s in sources] + [0] * (L.CONV_MAX_SRC - n)))
+        wp = ctypes.c_void_p(w.data_ptr())
+        self.log2S = lib.cer_conv3x3_s16_scale(wp, Cout, Cin, self.ch, self.kind, self.log2sx, n)
+        if self.log2S < -1000:
+            raise RuntimeError("conv3x3_s16: cannot scale these weights / sources")
+
+        def pack(collapsed):
+            size = lib.cer_conv3x3_s16_packed_size(Cout, self.ch, self.kind, n, collapsed)
+            if size <= 0:
+                raise RuntimeError(f"conv3x3_s16 pack: unsupported shape Cout={Cout} sources={sources}")
+            t = torch.empty(size, dtype=torch.float16)
+            L.check(lib.cer_conv3x3_s16_pack(wp, ctypes.c_void_p(t.data_ptr()), Cout, Cin, self.ch, self.kind, self.log2sx, n, collapsed,
+                                             self.log2S), "conv3x3_s16_pack")
+            return t.to(device)
+        self.packed = pack(0)
+        self.packed_c = pack(1) if any(k == 1 for _, k, _ in sources) else None
+        self.bias = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
+        self.cout = Cout
+
+
+def delta_proj_pack_s16(w2, device):
+    """w2 [1,C,3,3] (delta{s}.2.weight) -> (packed projection fragments for the s16 EPI_DELTA, log2 of their scale)."""
+    lib = L.load()
+    w = w2.detach().to("cpu", torch.float32).contiguous()
+    C = w.shape[1]
+    size = lib.cer_delta_proj_s16_packed_size(C)
+    if size <= 0:
+        raise RuntimeError(f"delta projection pack: unsupported C={C}")
+    packed = torch.empty(size, dtype=torch.float16)
+    log2s = ctypes.c_int(0)
+    L.check(lib.cer_delta_proj_s16_pack(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(packed.data_ptr()), C, ctypes.byref(log2s)), "delta_proj_s16_pack")
+    return packed.to(device), log2s.value
+
+
+TILE_MT = 0              # 0: let the library choose the tile height; tests force 3 / 4 / 5
+
+
+def conv3x3_s16(pc, srcs, h, w, epi, out=None, out2=None, aux=None, aux2=None, init=None, use_bias=True, out_split=False,
+                log2s_out=0, log2s_aux=0):
+    """srcs: tensors matching ``pc.sources`` (frag16 [s16_pixels(h,w), ch] for kind 2, plain disp [h*w] for kind 1).  Every
+    tensor except the disparity and the DELTA planes is in an m-tile-major layout (cer_mvs.h, ``s16_layout``):
+    LINEAR: ``out`` acc32 (or frag16 with scale 2^log2s_out when ``out_split``); RELU: frag16; GATES: (z f32x8, r*h frag16),
+    aux = h frag16 (2^log2s_aux); GRU: new h frag16, aux = h frag16, aux2 = z f32x8; DELTA: plain tap planes [Cout/128, 9, h*w],
+    aux = (packed projection, log2 scale); ``init``: acc32."""
+    dev = srcs[0].device
+    P, PP = h * w, s16_pixels(h, w)
+    ci = L.ConvInputs()
+    ci.nsrc = len(srcs)
+    for i, (t, (c, k, _)) in enumerate(zip(srcs, pc.sources)):
+        if t.numel() != (P if k == 1 else PP * c):
+            raise ValueError(f"conv3x3_s16: source {i} has {t.numel()} elements, expected {(P if k == 1 else PP * c)}")
+        ci.src[i] = t.data_ptr()
+        L.dev_ptr(t, f"src{i}")
+        ci.ch[i] = c
+        ci.kind[i] = k
+    oc = pc.cout // 2 if epi == L.EPI_GATES else pc.cout
+    if epi == L.EPI_DELTA:
+        aux, log2s_aux = aux
+        if out is None:
+            out = torch.empty(pc.cout // 128, 9, P, device=dev, dtype=torch.float32)
+    if out is None:
+        out = torch.zeros(PP, oc, device=dev, dtype=torch.float32)
+    if epi == L.EPI_GATES and out2 is None:
+        out2 = torch.zeros(PP, oc, device=dev, dtype=torch.float32)
+    for name, t in (("out", out), ("out2", out2), ("aux", aux if epi != L.EPI_DELTA else None), ("aux2", aux2), ("init", init)):
+        if t is not None and epi != L.EPI_DELTA and t.shape[0] != PP:
+            raise ValueError(f"conv3x3_s16: {name} must have {PP} (padded) pixel rows, got {tuple(t.shape)}")
+    bias = pc.bias if (use_bias and init is None) else None
+    aux_p = L.dev_ptr(aux, "aux", torch.float16) if epi == L.EPI_DELTA else L.dev_ptr(aux, "aux")
+    coll = L.dev_ptr(pc.packed_c, "packed_collapsed", torch.float16) if (COLLAPSE_DISP and pc.packed_c is not None) else None
+    flags = L.EPI_OUT_SPLIT if (out_split or epi in (L.EPI_RELU, L.EPI_GATES, L.EPI_GRU)) else 0
+    rc = L.load().cer_conv3x3_s16(ctypes.byref(ci), pc.log2sx, L.dev_ptr(pc.packed, "packed_w", torch.float16), coll, pc.log2S,
+                                  L.dev_ptr(bias, "bias"), L.dev_ptr(init, "init"), L.dev_ptr(out, "out"), L.dev_ptr(out2, "out2"), aux_p,
+                                  L.dev_ptr(aux2, "aux2"), h, w, pc.cout, epi | flags, int(log2s_out), int(log2s_aux), int(TILE_MT),
+                                  L.cur_stream())
+    L.check(rc, "conv3x3[s16]")
+    return (out, out2) if epi == L.EPI_GATES else out

@@ -10,8 +10,8 @@ reference that a caller can observe, all deliberate (SURVEY.md §8(a) "quirks"):
   * computation is fp32 end to end by default (``precision="fp32"``); the reference's GPU path runs
     encoders + GRU under fp16 autocast (raft.py:9,55), selectable with ``precision="amp"`` for the
     encoders only.  ``gru_precision`` picks the arithmetic of the update block's 3x3 convolutions:
-    "f16x3" (default: split-f16 MFMA with two fp32 accumulators, fp32-equivalent accuracy, 5.3x the
-    fp32-MFMA rate) or "fp32" (exact v_mfma_f32_16x16x4_f32).
+    "s16" (default: split-f16 MFMA into one fp32 accumulator, fp32-class accuracy, the barrier-light kernels of
+    csrc/conv_s16.hip), "f16x3" (round-1 kernels: two fp32 accumulators) or "fp32" (exact v_mfma_f32_16x16x4_f32).
 Multi-GPU: ``view_group`` = a torch.distributed process group (one rank per GPU, RCCL over xGMI).  ``shard="slab"``
 (default): source views are sharded for the encoders (all-gather of the feature maps), image rows are sharded for the cost
 volume and the GRU loop with a 7-row halo exchange per iteration (slab.py) - strong scaling of one depth map;
@@ -30,7 +30,7 @@ from .update import UpdateBlock
 
 class RAFT(nn.Module):
     def __init__(self, cascade=[(64, 64, 8), (-1, 320, 8)], encoder_type="HR", dim_fmap=64, dim_net=64, dim_inp=64,
-                 test_mode=False, precision="fp32", view_group=None, gru_precision="f16x3", encoder_backend="hip", shard="slab"):
+                 test_mode=False, precision="fp32", view_group=None, gru_precision="s16", encoder_backend="hip", shard="slab"):
         super().__init__()
         self.cascade = [tuple(c) for c in cascade]
         self.encoder_type = encoder_type
@@ -134,12 +134,12 @@ class RAFT(nn.Module):
         # until everything enqueued so far has finished)
         Pij = pij_matrices(poses[0], intrinsics[0], [0] * len(views), views).to(dev) if views else None
         net_l, inp_l, f1, f2 = self.encode(images, views)
-        net_l = ub.prepare_net(net_l)
+        net_l = ub.prepare_net(net_l, h, w)
         del images
 
         disp = torch.zeros(P, device=dev, dtype=torch.float32)
         hoisted = ub.hoist(inp_l, h, w)
-        ws = ub.workspace(P, dev)
+        ws = ub.workspace(h, w, dev)
         for stage, (D, incre, T) in enumerate(self.stages()):
             single = self.view_group is None   # no cross-rank sum between the build and the pooling: fuse them
             if views:

@@ -104,27 +104,41 @@ def _device_copy(pairs):
     ops.copy_segments(pairs)
 
 
-def pack_strips(net, disp, buf, w, r0, r1, e0, halo=HALO, copy=_device_copy):
+def pack_strips(net, disp, buf, w, r0, r1, e0, halo=HALO, copy=_device_copy, rows=None):
     """The first / last ``halo`` OWNED rows of net [rows_ext*w, C] and disp [rows_ext*w] -> buf (flat:
-    net top | net bottom | disp top | disp bottom).  All four ranges are contiguous: one cer_copy_segments_f32 launch."""
+    net top | net bottom | disp top | disp bottom).  All four ranges are contiguous: one cer_copy_segments_f32 launch.
+    ``rows(net, flat, y0, nrows, to_tensor)``: row mover for a hidden state kept in an m-tile-major layout (s16 path)."""
     C = net.shape[1]
     n, t0, b0 = halo * w, (r0 - e0) * w, (r1 - halo - e0) * w
+    if rows is not None:
+        rows(net, buf[:n * C], r0 - e0, halo, False)
+        rows(net, buf[n * C:2 * n * C], r1 - halo - e0, halo, False)
+        copy([(disp[t0:t0 + n], buf[2 * n * C:2 * n * C + n]), (disp[b0:b0 + n], buf[2 * n * C + n:])])
+        return
     copy([(net[t0:t0 + n], buf[:n * C]), (net[b0:b0 + n], buf[n * C:2 * n * C]),
           (disp[t0:t0 + n], buf[2 * n * C:2 * n * C + n]), (disp[b0:b0 + n], buf[2 * n * C + n:])])
 
 
-def unpack_halo(net, disp, allbuf, w, g, G, r0, r1, e0, e1, halo=HALO, copy=_device_copy):
+def unpack_halo(net, disp, allbuf, w, g, G, r0, r1, e0, e1, halo=HALO, copy=_device_copy, rows=None):
     """Refresh the halo rows of (net, disp) from the gathered strips allbuf [G, 2*halo*w*(C+1)] (layout of pack_strips),
-    one launch; same row bookkeeping as refresh_halo."""
+    one launch; same row bookkeeping as refresh_halo.  ``rows``: see pack_strips."""
     C = net.shape[1]
     n = halo * w
     pairs = []
     if g > 0 and r0 > e0:          # rows [e0, r0) = the last (r0-e0) rows of rank g-1's bottom strip
         k, src = (r0 - e0) * w, allbuf[g - 1]
-        pairs += [(src[n * C + (n - k) * C:2 * n * C], net[:k]), (src[2 * n * C + n + (n - k):], disp[:k])]
+        if rows is not None:
+            rows(net, src[n * C + (n - k) * C:2 * n * C], 0, r0 - e0, True)
+        else:
+            pairs += [(src[n * C + (n - k) * C:2 * n * C], net[:k])]
+        pairs += [(src[2 * n * C + n + (n - k):], disp[:k])]
     if g < G - 1 and e1 > r1:      # rows [r1, e1) = the first (e1-r1) rows of rank g+1's top strip
         k, src, o = (e1 - r1) * w, allbuf[g + 1], (r1 - e0) * w
-        pairs += [(src[:k * C], net[o:o + k]), (src[2 * n * C:2 * n * C + k], disp[o:o + k])]
+        if rows is not None:
+            rows(net, src[:k * C], r1 - e0, e1 - r1, True)
+        else:
+            pairs += [(src[:k * C], net[o:o + k])]
+        pairs += [(src[2 * n * C:2 * n * C + k], disp[o:o + k])]
     if pairs:
         copy(pairs)
 
@@ -180,13 +194,15 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
         r0, r1, e0, e1 = slab_bounds(h, G, g)
         d = st[g]
         d.update(r0=r0, r1=r1, e0=e0, e1=e1, hs=e1 - e0)
-        d["net"] = ub.prepare_net(d["net"][e0 * w:e1 * w].clone())
+        d["net"] = ub.prepare_net(d["net"][e0 * w:e1 * w].clone(), e1 - e0, w)
         d["inp"] = d["inp"][e0 * w:e1 * w].contiguous()
         d["f1s"] = d["f1"][e0 * w:e1 * w].contiguous()
         d["disp"] = torch.zeros((e1 - e0) * w, device=dev, dtype=torch.float32)
         d["hoist"] = ub.hoist(d["inp"], e1 - e0, w)
-        d["ws"] = ub.workspace((e1 - e0) * w, dev)
+        d["ws"] = ub.workspace(e1 - e0, w, dev)
         d["strips"] = torch.empty(2 * HALO * w * (d["net"].shape[1] + 1), device=dev, dtype=torch.float32)
+        # s16 path: the hidden state lives in the m-tile-major frag16 layout - image rows move through cer_s16_rows_f32
+        d["rows"] = (lambda t, flat, y0, nr, to_t, hs=e1 - e0: ops.s16_rows(t, flat, hs, w, y0, nr, to_t)) if ub.conv_mode == "s16" else None
 
     for stage, (D, incre, T) in enumerate(model.stages()):
         for g in ex.ranks:
@@ -207,7 +223,7 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
                     d["plan_step"] = L.LaunchPlan(keep=(d["vol"], d["origin"]))
                     with L.recording(d["plan_step"]):
                         ub.step(d["vol"], d["origin"], d["net"], d["disp"], d["hoist"], stage, d["hs"], w, D, incre, d["ws"])
-                        pack_strips(d["net"], d["disp"], d["strips"], w, d["r0"], d["r1"], d["e0"])
+                        pack_strips(d["net"], d["disp"], d["strips"], w, d["r0"], d["r1"], d["e0"], rows=d["rows"])
                 else:
                     d["plan_step"].replay()
                 send.append(d["strips"])
@@ -217,7 +233,7 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
                 if record:
                     d["plan_halo"] = L.LaunchPlan(keep=(gathered[i],))
                     with L.recording(d["plan_halo"]):
-                        unpack_halo(d["net"], d["disp"], gathered[i], w, g, G, d["r0"], d["r1"], d["e0"], d["e1"])
+                        unpack_halo(d["net"], d["disp"], gathered[i], w, g, G, d["r0"], d["r1"], d["e0"], d["e1"], rows=d["rows"])
                 else:
                     d["plan_halo"].replay()
 

@@ -102,7 +102,9 @@ class UpdateBlock(nn.Module):
         i_planes = dim_inp + dim1_corr + size_disp_enc ** 2
         for i in (range(n_cascade) if not share_gru else [""]):
             setattr(self, f"gru{i}", ConvGRU(h_planes=dim_net, i_planes=i_planes))
-        self.conv_mode = "f16x3"          # "f16x3" (split-f16 MFMA, fp32-equivalent) or "fp32" (exact fp32 MFMA)
+        # arithmetic of the 3x3 convolutions: "s16" (split-f16 MFMA, one accumulator, barrier-light kernels of conv_s16.hip: the
+        # fast path), "f16x3" (round-1 split-f16 kernels, two accumulators) or "fp32" (exact fp32 MFMA)
+        self.conv_mode = "s16"
         self._packed = {}
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.refresh_weights())
 
@@ -150,6 +152,17 @@ class UpdateBlock(nn.Module):
         p["zr_inp"] = ops.PackedConv3x3(wzr[:, s_inp], bzr, [(di, 0)], device)
         p["q_inp"] = ops.PackedConv3x3(wq[:, s_inp], bq, [(di, 0)], device)
         p["d1"] = ops.PackedConv3x3(de[0].weight, de[0].bias, [(dn_, 0)], device)
+        if self.conv_mode == "s16":
+            # s16 fast path (csrc/conv_s16.hip): every loop tensor lives in HBM in the split16 layout with a per-class power-of-two
+            # scale (hidden state and r*h: |x| <= 1; ReLU outputs; generated disparity features)
+            U, R, Dp = L.S16_UNIT, L.S16_RELU, L.S16_DISP
+            p["s_corr2"] = ops.PackedConvS16(ce[2].weight, ce[2].bias, [(64, 2, R)], device)
+            p["s_zr"] = ops.PackedConvS16(wzr[:, rest], None, [(dn_, 2, U), (49, 1, Dp), (64, 2, R)], device)
+            p["s_q"] = ops.PackedConvS16(wq[:, rest], None, [(dn_, 2, U), (49, 1, Dp), (64, 2, R)], device)
+            p["s_zr_inp"] = ops.PackedConvS16(wzr[:, s_inp], bzr, [(di, 2, R)], device)
+            p["s_q_inp"] = ops.PackedConvS16(wq[:, s_inp], bq, [(di, 2, R)], device)
+            p["s_d1"] = ops.PackedConvS16(de[0].weight, de[0].bias, [(dn_, 2, U)], device)
+            p["s_d2proj"] = ops.delta_proj_pack_s16(de[2].weight, device)
         p["d2w"] = f32(de[2].weight[0].permute(1, 2, 0).reshape(9, -1))    # [tap, C]
         p["d2proj"] = ops.delta_proj_pack(de[2].weight, device)
         p["d2b"] = float(de[2].bias.detach().float().cpu()[0])
@@ -160,6 +173,9 @@ class UpdateBlock(nn.Module):
     def hoist(self, inp_l, h, w, stage=0):
         """Contribution of the constant `inp` slice (+ biases) to the z|r and q pre-activations."""
         p = self.packed(stage, inp_l.device)
+        if self.conv_mode == "s16":     # (the results are in the acc32 layout: they seed the accumulators of the loop's convs)
+            inp_s = ops.to_frag16(inp_l, h, w, L.S16_RELU)
+            return (ops.conv3x3_s16(p["s_zr_inp"], [inp_s], h, w, L.EPI_LINEAR), ops.conv3x3_s16(p["s_q_inp"], [inp_s], h, w, L.EPI_LINEAR))
         return (ops.conv3x3(p["zr_inp"], [inp_l], h, w, L.EPI_LINEAR, mode=self.conv_mode), ops.conv3x3(p["q_inp"], [inp_l], h, w, L.EPI_LINEAR, mode=self.conv_mode))
 
     # f16x3 path: the loop's activations (hidden state, corr features, r*h) live in HBM in the "split32" layout - hi|lo f16
@@ -171,15 +187,35 @@ class UpdateBlock(nn.Module):
     def split_acts(self):
         return self.SPLIT_ACTS and self.conv_mode == "f16x3"
 
-    def prepare_net(self, net_l):
-        """Hidden state [P,64] fp32 -> the layout ``step`` keeps it in (split32 on the f16x3 path)."""
+    def prepare_net(self, net_l, h, w):
+        """Hidden state [h*w,64] fp32 -> the layout ``step`` keeps it in (frag16 on the s16 path, split32 on the f16x3 path)."""
+        if self.conv_mode == "s16":
+            return ops.to_frag16(net_l, h, w, L.S16_UNIT)
         return ops.split32(net_l) if self.split_acts() else net_l
+
+    def restore_net(self, net_l, h, w):
+        """Inverse of ``prepare_net``: the hidden state as plain fp32 [h*w,64]."""
+        if self.conv_mode == "s16":
+            return ops.from_frag16(net_l, h, w, L.S16_UNIT)
+        return ops.split32(net_l, inverse=True) if self.split_acts() else net_l
 
     def step(self, vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws):
         """One GRU iteration on the folded volume; updates ``net_l`` [P,64] (see ``prepare_net``) and ``disp`` [P] in place.
         ``ws``: dict of scratch tensors (c1, c2, z, rn, hid) reused across iterations."""
         p = self.packed(stage, net_l.device)
         hzr, hq = hoisted
+        if self.conv_mode == "s16":
+            U, R = L.S16_UNIT, L.S16_RELU
+            ops.lookup_encode(vol, origin, disp, p["w0t"], p["b0"], D, incre, self.num_levels, self.radius, out=ws["c1"], out_split=2, log2s=R,
+                              img_w=w)
+            ops.conv3x3_s16(p["s_corr2"], [ws["c1"]], h, w, L.EPI_RELU, out=ws["c2"], out_split=True, log2s_out=R)
+            ops.conv3x3_s16(p["s_zr"], [net_l, disp, ws["c2"]], h, w, L.EPI_GATES, out=ws["z"], out2=ws["rn"], aux=net_l, init=hzr,
+                            log2s_out=U, log2s_aux=U)
+            ops.conv3x3_s16(p["s_q"], [ws["rn"], disp, ws["c2"]], h, w, L.EPI_GRU, out=net_l, aux=net_l, aux2=ws["z"], init=hq,
+                            log2s_out=U, log2s_aux=U)
+            ops.conv3x3_s16(p["s_d1"], [net_l], h, w, L.EPI_DELTA, out=ws["T"], aux=p["s_d2proj"])
+            ops.delta_sum(ws["T"], p["d2b"], disp, h, w, disp_out=disp, want_delta=False)
+            return
         if self.split_acts():
             ops.lookup_encode(vol, origin, disp, p["w0t"], p["b0"], D, incre, self.num_levels, self.radius, out=ws["c1"], out_split=True)
             ops.conv3x3(p["corr2"], [ws["c1"]], h, w, L.EPI_RELU, out=ws["c2"], kinds=[3], out_split=True)
@@ -219,8 +255,12 @@ class UpdateBlock(nn.Module):
             if after is not None:
                 after(i)
 
-    @staticmethod
-    def workspace(P, device):
+    def workspace(self, h, w, device):
+        """Scratch tensors of the loop for an h x w image (s16 path: m-tile-major layouts over whole m-tiles, ops.s16_pixels)."""
+        P = h * w
+        if self.conv_mode == "s16":
+            z = lambda c: torch.zeros(ops.s16_pixels(h, w), c, device=device, dtype=torch.float32)
+            return {"c1": z(64), "c2": z(64), "z": z(64), "rn": z(64), "T": torch.empty(2, 9, P, device=device, dtype=torch.float32)}
         e = lambda c: torch.empty(P, c, device=device, dtype=torch.float32)
         return {"c1": e(64), "c2": e(64), "z": e(64), "rn": e(64), "hid": e(256),
                 "T": torch.empty(2, 9, P, device=device, dtype=torch.float32)}
@@ -261,14 +301,15 @@ class UpdateBlock(nn.Module):
             # stack(dim=2).view(...) in the reference interleaves [part][channel]: channel-major then part
             agg = torch.stack(parts, dim=1).reshape(1, -1, P).contiguous()
             c1 = ops.corr_encode(agg, p["w0t"], p["b0"])
-        c2 = ops.conv3x3(p["corr2"], [c1], ht, wd, L.EPI_RELU, mode=self.conv_mode)
-        z, rn = ops.conv3x3(p["zr_full"], [net_l, inp_l, disp_l, c2], ht, wd, L.EPI_GATES, mode=self.conv_mode, aux=net_l)
-        new = ops.conv3x3(p["q_full"], [rn, inp_l, disp_l, c2], ht, wd, L.EPI_GRU, mode=self.conv_mode, aux=net_l, aux2=z)
-        if self.conv_mode == "f16x3":
+        mode = "f16x3" if self.conv_mode == "s16" else self.conv_mode      # the literal API runs on the general round-1 kernels
+        c2 = ops.conv3x3(p["corr2"], [c1], ht, wd, L.EPI_RELU, mode=mode)
+        z, rn = ops.conv3x3(p["zr_full"], [net_l, inp_l, disp_l, c2], ht, wd, L.EPI_GATES, mode=mode, aux=net_l)
+        new = ops.conv3x3(p["q_full"], [rn, inp_l, disp_l, c2], ht, wd, L.EPI_GRU, mode=mode, aux=net_l, aux2=z)
+        if mode == "f16x3":
             T = ops.conv3x3(p["d1"], [new], ht, wd, L.EPI_DELTA, mode="f16x3", aux=p["d2proj"])
             _, delta = ops.delta_sum(T, p["d2b"], disp_l, ht, wd)
         else:
-            hid = ops.conv3x3(p["d1"], [new], ht, wd, L.EPI_RELU, mode=self.conv_mode)
+            hid = ops.conv3x3(p["d1"], [new], ht, wd, L.EPI_RELU, mode=mode)
             _, delta = ops.delta_tail(hid, p["d2w"], p["d2b"], disp_l, ht, wd)
         net_out = ops.nhwc_to_nchw(new).view(batch, num, ch, ht, wd)
         return net_out, delta.view(batch, num, ht, wd)

@@ -118,8 +118,9 @@ int cer_corr_encode_f32(const float* feats, const float* w, const float* b, floa
 int cer_lookup_encode_f32(const float* vol, const float* origin, const float* disp,
                           const float* w, const float* b, float* out,
                           long P, int D, int row_stride, double incre, int num_levels, int radius, int Cout,
-                          int out_split /* 1: out in the split32 layout (below) for the f16x3 corr2 conv */,
-                          void* stream);
+                          int out_split /* 0: fp32 [P, Cout]; 1: split32 layout (f16x3 convs); 2: frag16 layout of an image
+                                           img_w pixels wide with scale 2^log2s_out (s16 convs) - both below */,
+                          int log2s_out, int img_w, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * 3x3, stride 1, zero-padded convolution as an implicit GEMM on exact-fp32 MFMA
@@ -193,6 +194,52 @@ int cer_conv3x3_f16x3(const cer_conv_inputs* in, const void* packed_w, const voi
                       const float* bias, const float* init,
                       float* out, float* out2, const float* aux, const float* aux2,
                       int h, int w, int Cout, int epi, void* stream);
+
+/* ---- round 2: the same convolutions, "s16" form (csrc/conv_s16.hip) - the update block's fast path.
+ * Arithmetic: every fp32 operand x is carried as the two f16 halves of xs = x * 2^k (k a per-tensor power of two):
+ * hi = f16(xs), lo = f16(xs - hi) (unscaled residual), and x*w ~= (xh*wh + xh*wl + xl*wh) / (2^kx 2^kw): three
+ * v_mfma_f32_32x32x16_f16 into ONE fp32 accumulator per tile (fp32-class: measured rms error 1.6e-8 of sum|x||w| at
+ * K = 1248, an fp32 fmaf chain has 2.7e-8).  All sources of a conv share the product scale 2^log2S = 2^kx(src) 2^kw(src).
+ *
+ * Tensor layouts (m-tile-major, so that every wave-level access of the kernels is one contiguous KiB).  An m-tile is 2 rows x
+ * 16 columns of pixels, lane order li = (y & 1) * 16 + (x & 15); a tensor of an h x w image holds ceil(h/2) * ceil(w/16)
+ * m-tiles = cer_s16_padded_pixels(h, w) pixels (allocate [padded pixels, C] floats; padding pixels are never read as data).
+ *   "frag16" (split activations, C % 16 == 0): per (m-tile, 16-channel group) 1 KiB of hi halves | 1 KiB of lo halves of
+ *       x * 2^log2s; inside a plane the 16-byte piece (kg = (c >> 3) & 1, li) holds channels 8kg .. 8kg+7 (MFMA fragment order);
+ *   "acc32"  (fp32, C % 32 == 0): per (m-tile, 32-channel tile, j < 4) 1 KiB, lane (kg, li) holds channels 8j + 4kg + 0..3 -
+ *       the accumulator order: `init` of cer_conv3x3_s16 and the output of its LINEAR epilogue;
+ *   "f32x8"  (fp32, C % 16 == 0): per (m-tile, 16-channel group, q < 2) 1 KiB, lane (kg, li) holds channels 8kg + 4q + 0..3 -
+ *       the z gate between the GATES and GRU epilogues.
+ * cer_s16_layout_f32 converts plain fp32 [h*w, C] to layout 0 | 1 | 2 (inverse = 0; log2s used by layout 0) or back.
+ *
+ * Sources: kind 2 = frag16 tensor (C % 32 == 0) with scale 2^log2sx[s]; kind 1 = disparity [P] fp32, plain (49 encoder
+ * channels, generated in the kernel with scale 2^log2sx[s]; at most one).  `ch`/`kind` list the sources in the weights'
+ * input-channel order; the packing reorders steps itself (tensors first, disparity last).
+ * cer_conv3x3_s16_scale returns log2S for a weight tensor (< -1000 on error); cer_conv3x3_s16_pack builds the literal
+ * (collapsed = 0) or collapsed (= 1, needs a kind-1 source; used by interior tiles) packing, size in 2-byte halves from
+ * cer_conv3x3_s16_packed_size.  HOST pointers.
+ * cer_conv3x3_s16: bias (fp32 [Cout], plain) or init (acc32 [., Cout]) - at most one - seed the accumulators; epilogues:
+ *   LINEAR: out acc32 [., Cout];  with CER_EPI_OUT_SPLIT or'ed in, and RELU always: out frag16 with scale 2^log2s_out;
+ *   GATES (Cout = 128): out = z f32x8 [., 64], out2 = r * h frag16 (2^log2s_out), aux = h frag16 (2^log2s_aux);
+ *   GRU: out = new h frag16 (2^log2s_out), aux = h frag16 (2^log2s_aux; may alias out), aux2 = z f32x8;
+ *   DELTA (Cout % 128 == 0): out = tap planes T [Cout/128, 9, h*w] (plain) as for cer_conv3x3_f16x3, aux = projection weights
+ *   packed by cer_delta_proj_s16_pack, log2s_aux = their scale.
+ * tile_mt: 0 = choose the tile height from (h, w) and the CU count; else force it (tests: 4 | 5 for Cout % 128 == 0,
+ * 3 | 4 for Cout = 64). */
+long cer_conv3x3_s16_packed_size(int Cout, const int* ch, const int* kind, int nsrc, int collapsed);
+int cer_conv3x3_s16_scale(const float* w_oihw, int Cout, int Cin, const int* ch, const int* kind, const int* log2sx, int nsrc);
+int cer_conv3x3_s16_pack(const float* w_oihw, void* packed, int Cout, int Cin, const int* ch, const int* kind, const int* log2sx,
+                         int nsrc, int collapsed, int log2S);
+int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, const void* packed_w, const void* packed_collapsed, int log2S,
+                    const float* bias, const float* init, float* out, float* out2, const float* aux, const float* aux2,
+                    int h, int w, int Cout, int epi, int log2s_out, int log2s_aux, int tile_mt, void* stream);
+long cer_delta_proj_s16_packed_size(int C);
+int cer_delta_proj_s16_pack(const float* w2_oihw, void* packed, int C, int* log2s_out);
+long cer_s16_padded_pixels(int h, int w);
+int cer_s16_layout_f32(const float* src, float* dst, int h, int w, int C, int layout, int log2s, int inverse, void* stream);
+/* Image rows [y0, y0 + nrows) of a frag16 tensor (h x w image, C channels) -> rows [nrows * w, C] (to_tensor = 0) or back
+ * (to_tensor = 1), as bit-exact copies of the 16-byte hi | lo pieces (the row-slab halo exchange). */
+int cer_s16_rows_f32(float* tensor, float* rows, int h, int w, int C, int y0, int nrows, int to_tensor, void* stream);
 
 /* fp32 [P, C] -> split32 (inverse = 0) or back (inverse = 1); C % 32 == 0. */
 int cer_split32_f32(const float* src, float* dst, long P, int C, int inverse, void* stream);

@@ -1,0 +1,250 @@
+"""GPU parity of the round-2 update-block convolutions (csrc/conv_s16.hip, through the C ABI) against torch / fp64 restatements
+of core/update.py:13-25,61-71,80-85.  Run on the GPU box: pytest -m gpu."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l1
+from test_oracle_golden import hashed
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def nhwc(x):
+    """[1,C,h,w] -> [h*w, C]"""
+    return x[0].permute(1, 2, 0).reshape(-1, x.shape[1]).contiguous()
+
+
+@pytest.fixture
+def tile_mt():
+    from cer_mvs_amd import ops
+    yield ops
+    ops.TILE_MT = 0
+
+
+def frag(x, h, w, log2s):
+    """[1,C,h,w] cpu -> frag16 device tensor"""
+    from cer_mvs_amd import ops
+    return ops.to_frag16(nhwc(x).cuda(), h, w, log2s)
+
+
+def unfrag(t, h, w, log2s):
+    from cer_mvs_amd import ops
+    return ops.from_frag16(t, h, w, log2s).cpu().double()
+
+
+def unacc(t, h, w, layout=None):
+    from cer_mvs_amd import _lib as L, ops
+    return ops.s16_layout(t, h, w, L.S16_ACC32 if layout is None else layout, inverse=True).cpu().double()
+
+
+@pytest.mark.parametrize("h,w", [(8, 16), (13, 37), (30, 64)])
+def test_s16_layouts_roundtrip(dev, h, w):
+    """Plain [h*w, C] <-> the three m-tile-major layouts (cer_mvs.h): exact for the fp32 layouts, 2^-22-class for frag16; the
+    frag16 row mover copies bits."""
+    from cer_mvs_amd import _lib as L, ops
+    x = hashed((h * w, 64), 901, -1, 1).to(dev)
+    for layout in (L.S16_ACC32, L.S16_F32X8):
+        t = ops.s16_layout(x, h, w, layout)
+        assert t.shape == (ops.s16_pixels(h, w), 64)
+        assert torch.equal(ops.s16_layout(t, h, w, layout, inverse=True), x)
+    for log2s in (L.S16_UNIT, L.S16_RELU, 0):
+        rt = ops.from_frag16(ops.to_frag16(x, h, w, log2s), h, w, log2s)
+        assert (rt - x).abs().max() <= max(2.0 ** -21, 2.0 ** (-24 - log2s))
+    big = torch.full((h * w, 32), 1e9, device=dev)
+    assert torch.isfinite(ops.from_frag16(ops.to_frag16(big, h, w, 4), h, w, 4)).all()       # saturates at 65504 / 2^4
+    # the two fp32 layouts really differ from each other and from the plain order
+    assert not torch.equal(ops.s16_layout(x, h, w, L.S16_ACC32)[:h * w], x)
+    # row mover: rows [y0, y0+n) out and back in
+    t = ops.to_frag16(x, h, w, L.S16_UNIT)
+    y0, n = 3, 4
+    rows = torch.empty(n * w * 64, device=dev)
+    ops.s16_rows(t, rows, h, w, y0, n, False)
+    t2 = torch.zeros_like(t)
+    ops.s16_rows(t2, rows, h, w, y0, n, True)
+    back = ops.from_frag16(t2, h, w, L.S16_UNIT)
+    ref = ops.from_frag16(t, h, w, L.S16_UNIT)
+    assert torch.equal(back[y0 * w:(y0 + n) * w], ref[y0 * w:(y0 + n) * w]) and back[:y0 * w].abs().sum() == 0
+
+
+@pytest.mark.parametrize("mt", [0, 3, 4, 5])
+@pytest.mark.parametrize("h,w,cout", [(8, 16, 64), (11, 21, 64), (9, 17, 128), (24, 40, 256), (5, 70, 128), (37, 33, 64)])
+def test_conv_s16_matches_torch(dev, tile_mt, h, w, cout, mt):
+    from cer_mvs_amd import _lib as L, ops
+    ops.TILE_MT = mt
+    cin = 64
+    x = hashed((1, cin, h, w), 101)
+    wt = hashed((cout, cin, 3, 3), 102, -0.1, 0.1)
+    b = hashed((cout,), 103)
+    ref = nhwc(F.conv2d(x.double(), wt.double(), b.double(), padding=1))
+    pc = ops.PackedConvS16(wt, b, [(cin, 2, L.S16_UNIT)], dev)
+    xs = frag(x, h, w, L.S16_UNIT)
+    out = ops.conv3x3_s16(pc, [xs], h, w, L.EPI_LINEAR)
+    assert rel_l1(unacc(out, h, w), ref) < 1e-6
+    out = ops.conv3x3_s16(pc, [xs], h, w, L.EPI_LINEAR, out_split=True, log2s_out=L.S16_RELU)
+    assert rel_l1(unfrag(out, h, w, L.S16_RELU), ref) < 1e-6
+    out = ops.conv3x3_s16(pc, [xs], h, w, L.EPI_RELU, log2s_out=L.S16_RELU)
+    assert rel_l1(unfrag(out, h, w, L.S16_RELU), F.relu(ref)) < 1e-6
+    init = hashed((h * w, cout), 104, -0.3, 0.3)
+    out = ops.conv3x3_s16(pc, [xs], h, w, L.EPI_LINEAR, init=ops.s16_layout(init.to(dev), h, w, L.S16_ACC32))
+    assert rel_l1(unacc(out, h, w), ref - b.double() + init.double()) < 1e-6
+
+
+def test_conv_s16_two_sources_and_error_bound(dev):
+    """Two tensor sources with different scale classes; error per output relative to sum |x||w| stays fp32-class."""
+    from cer_mvs_amd import _lib as L, ops
+    h, w, cout = 19, 45, 128
+    a = torch.tanh(hashed((1, 64, h, w), 111, -2, 2))
+    c = torch.relu(hashed((1, 32, h, w), 112, -1, 3))
+    wt = hashed((cout, 96, 3, 3), 113, -0.07, 0.07)
+    x = torch.cat([a, c], 1)
+    ref = nhwc(F.conv2d(x.double(), wt.double(), None, padding=1))
+    mag = nhwc(F.conv2d(x.abs().double(), wt.abs().double(), None, padding=1))
+    pc = ops.PackedConvS16(wt, None, [(64, 2, L.S16_UNIT), (32, 2, L.S16_RELU)], dev)
+    out = ops.conv3x3_s16(pc, [frag(a, h, w, L.S16_UNIT), frag(c, h, w, L.S16_RELU)], h, w, L.EPI_LINEAR)
+    assert float(((unacc(out, h, w) - ref).abs() / mag).max()) < 1e-6
+
+
+@pytest.mark.parametrize("mt", [4, 5])
+@pytest.mark.parametrize("h,w,cout", [(30, 70, 128), (13, 101, 64), (41, 50, 64)])
+def test_conv_s16_disparity_source(dev, tile_mt, h, w, cout, mt):
+    """Kind-1 source: 100 * (unfold7x7(disp) - disp) (core/update.py:80-85,97) generated in the kernel - collapsed 81-tap form
+    on interior tiles, literal form on border tiles; both must match the literal convolution, also where the 9x9 window
+    leaves the image."""
+    from cer_mvs_amd import _lib as L, ops
+    from oracle import cer_oracle as O
+    ops.TILE_MT = mt if cout == 128 else mt - 1
+    disp = hashed((1, 1, h, w), 211, 0.0005, 0.0025)
+    a = hashed((1, 32, h, w), 212)
+    feat = 100 * O.disp_features(disp)
+    wt = hashed((cout, 32 + 49, 3, 3), 213, -0.1, 0.1)
+    ref = nhwc(F.conv2d(torch.cat([a, feat], 1).double(), wt.double(), None, padding=1))
+    pc = ops.PackedConvS16(wt, None, [(32, 2, L.S16_UNIT), (49, 1, L.S16_DISP)], dev)
+    assert pc.packed_c is not None
+    srcs = [frag(a, h, w, L.S16_UNIT), disp.reshape(-1).to(dev)]
+    outs = {}
+    for flag in (True, False):
+        ops.COLLAPSE_DISP = flag
+        try:
+            outs[flag] = unacc(ops.conv3x3_s16(pc, srcs, h, w, L.EPI_LINEAR), h, w)
+        finally:
+            ops.COLLAPSE_DISP = True
+        assert rel_l1(outs[flag], ref) < 2e-6, flag
+        assert (outs[flag] - ref).abs().max() < 5e-6 * ref.abs().max()
+    th = 2 * ops.TILE_MT * (1 if cout == 128 else 2)
+    if h >= 2 * th + 2:                                          # at least one interior tile row
+        assert not torch.equal(outs[True], outs[False])          # some tiles really took the collapsed path
+
+
+def test_conv_s16_disparity_only_source(dev):
+    from cer_mvs_amd import _lib as L, ops
+    from oracle import cer_oracle as O
+    h, w, cout = 33, 37, 64
+    disp = hashed((1, 1, h, w), 221, 0.0, 0.0025)
+    wt = hashed((cout, 49, 3, 3), 223, -0.1, 0.1)
+    ref = nhwc(F.conv2d((100 * O.disp_features(disp)).double(), wt.double(), None, padding=1))
+    pc = ops.PackedConvS16(wt, None, [(49, 1, L.S16_DISP)], dev)
+    out = ops.conv3x3_s16(pc, [disp.reshape(-1).to(dev)], h, w, L.EPI_LINEAR)
+    assert rel_l1(unacc(out, h, w), ref) < 2e-6
+
+
+def test_conv_s16_gates_and_gru_epilogues(dev):
+    """z|r gates (sigmoid, r*h) and the GRU blend (core/update.py:17-25) on frag16 tensors vs an fp64 restatement."""
+    from cer_mvs_amd import _lib as L, ops
+    from oracle import cer_oracle as O
+    h, w = 23, 50
+    P = h * w
+    U, R, Dp = L.S16_UNIT, L.S16_RELU, L.S16_DISP
+    net = torch.tanh(hashed((1, 64, h, w), 501, -2, 2))
+    c2 = torch.relu(hashed((1, 64, h, w), 502, -1, 2))
+    disp = hashed((1, 1, h, w), 503, 0.0005, 0.0025)
+    feat = 100 * O.disp_features(disp)
+    wzr = hashed((128, 177, 3, 3), 505, -0.05, 0.05)
+    wq = hashed((64, 177, 3, 3), 506, -0.05, 0.05)
+    init = hashed((P, 128), 504, -0.3, 0.3)
+    initq = hashed((P, 64), 507, -0.3, 0.3)
+    x = torch.cat([net, feat, c2], 1).double()
+    pre = nhwc(F.conv2d(x, wzr.double(), None, padding=1)) + init.double()
+    z_ref = torch.sigmoid(pre[:, :64])
+    r_ref = torch.sigmoid(pre[:, 64:])
+    rh_ref = r_ref * nhwc(net).double()
+    src = [(64, 2, U), (49, 1, Dp), (64, 2, R)]
+    pzr = ops.PackedConvS16(wzr, None, src, dev)
+    pq = ops.PackedConvS16(wq, None, src, dev)
+    net_s, c2_s = frag(net, h, w, U), frag(c2, h, w, R)
+    d = disp.reshape(-1).to(dev)
+    acc = lambda t: ops.s16_layout(t.to(dev), h, w, L.S16_ACC32)
+    z, rh = ops.conv3x3_s16(pzr, [net_s, d, c2_s], h, w, L.EPI_GATES, aux=net_s, init=acc(init), log2s_out=U, log2s_aux=U)
+    assert rel_l1(unacc(z, h, w, L.S16_F32X8), z_ref) < 1e-6
+    assert rel_l1(unfrag(rh, h, w, U), rh_ref) < 1e-6
+    rh4 = rh_ref.t().reshape(1, 64, h, w)
+    xq = torch.cat([rh4, feat.double(), c2.double()], 1)
+    q_ref = torch.tanh(nhwc(F.conv2d(xq, wq.double(), None, padding=1)) + initq.double())
+    new_ref = (1 - z_ref) * nhwc(net).double() + z_ref * q_ref
+    new = ops.conv3x3_s16(pq, [rh, d, c2_s], h, w, L.EPI_GRU, out=net_s, aux=net_s, aux2=z, init=acc(initq), log2s_out=U, log2s_aux=U)
+    assert new.data_ptr() == net_s.data_ptr()                    # in place, as the loop runs it
+    assert rel_l1(unfrag(new, h, w, U), new_ref) < 1e-6
+
+
+@pytest.mark.parametrize("mt", [4, 5])
+def test_conv_s16_fused_delta_head(dev, tile_mt, mt):
+    """EPI_DELTA: hid = relu(conv3x3(net, 64 -> 256)) projected onto the nine taps of the 256 -> 1 conv (core/update.py:68-71);
+    cer_delta_sum_f32 then gives delta = 0.01 * conv3x3(hid, w2) (core/update.py:114)."""
+    from cer_mvs_amd import _lib as L, ops
+    ops.TILE_MT = mt
+    h, w = 27, 38
+    P = h * w
+    net = torch.tanh(hashed((1, 64, h, w), 601, -2, 2))
+    w1 = hashed((256, 64, 3, 3), 602, -0.08, 0.08)
+    b1 = hashed((256,), 603, -0.1, 0.1)
+    w2 = hashed((1, 256, 3, 3), 604, -0.05, 0.05)
+    hid = F.relu(F.conv2d(net.double(), w1.double(), b1.double(), padding=1))
+    delta_ref = 0.01 * (F.conv2d(hid, w2.double(), None, padding=1) + 0.25).reshape(-1)
+    pc = ops.PackedConvS16(w1, b1, [(64, 2, L.S16_UNIT)], dev)
+    proj = ops.delta_proj_pack_s16(w2, dev)
+    T = ops.conv3x3_s16(pc, [frag(net, h, w, L.S16_UNIT)], h, w, L.EPI_DELTA, aux=proj)
+    assert T.shape == (2, 9, P)
+    disp0 = hashed((P,), 605, 0.0005, 0.002).to(dev)
+    disp1, delta = ops.delta_sum(T, 0.25, disp0, h, w)
+    assert rel_l1(delta.cpu().double(), delta_ref) < 1e-6
+    assert torch.equal(disp1, disp0 + delta)
+
+
+def test_lookup_encode_frag16_output(dev):
+    """cer_lookup_encode_f32 with out_split = 2 writes exactly frag16(relu(conv1x1(lookup)))."""
+    from cer_mvs_amd import _lib as L, ops
+    h, w, D = 25, 40, 64
+    P = h * w
+    _, _, rs = ops.row_layout(D, 3)
+    vol = hashed((P, rs), 701, -1, 1).to(dev)
+    origin = hashed((P,), 702, 0.001, 0.0015).to(dev)
+    disp = hashed((P,), 703, 0.0005, 0.002).to(dev)
+    w0t = hashed((33, 64), 704, -0.2, 0.2).to(dev)
+    b0 = hashed((64,), 705, -0.1, 0.1).to(dev)
+    incre = 0.0025 / 64
+    a = ops.lookup_encode(vol, origin, disp, w0t, b0, D, incre, 3, 5)
+    b = ops.lookup_encode(vol, origin, disp, w0t, b0, D, incre, 3, 5, out_split=2, log2s=L.S16_RELU, img_w=w)
+    assert torch.equal(b, ops.to_frag16(a, h, w, L.S16_RELU))
+
+
+def test_conv_s16_dynamic_range(dev):
+    """Small and large activations keep fp32-class accuracy relative to sum |x||w|; values beyond 65504 / scale saturate."""
+    from cer_mvs_amd import _lib as L, ops
+    h, w, cin, cout = 16, 32, 32, 64
+    x = hashed((1, cin, h, w), 121) * torch.logspace(-3, 2, h * w).view(1, 1, h, w)       # 1e-3 .. 1e2 per pixel
+    wt = hashed((cout, cin, 3, 3), 122, -0.2, 0.2)
+    ref = nhwc(F.conv2d(x.double(), wt.double(), None, padding=1))
+    mag = nhwc(F.conv2d(x.abs().double(), wt.abs().double(), None, padding=1))
+    wsum = nhwc(F.conv2d(torch.ones(1, cin, h, w).double(), wt.abs().double(), None, padding=1))
+    pc = ops.PackedConvS16(wt, None, [(cin, 2, L.S16_RELU)], dev)
+    got = unacc(ops.conv3x3_s16(pc, [frag(x, h, w, L.S16_RELU)], h, w, L.EPI_LINEAR), h, w)
+    # per operand: relative 2^-22 or absolute 2^-25 / 2^log2s, whichever is larger
+    assert bool(((got - ref).abs() <= 2e-6 * mag + 2.0 ** (-24 - L.S16_RELU) * wsum).all())
+    big = ops.to_frag16(torch.full((h * w, cin), 1e6, device=dev), h, w, L.S16_RELU)
+    assert torch.isfinite(ops.conv3x3_s16(pc, [big], h, w, L.EPI_LINEAR)).all()

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Cycle-stamp trace of the s16 z|r conv (variant build -DSX_TRACE=1: make -C cer-mvs_amd/csrc variants/libcermvs_sxtrace.so;
+run with CER_MVS_LIB=.../variants/libcermvs_sxtrace.so).  Per wave: entry, prologue end, every 18-step body, loop end, exit,
+HW_ID.  Prints residency (waves per SIMD over time), lifetimes and phase lengths."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cer_mvs_amd import _lib as L, ops                                     # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", default="296x400")
+    ap.add_argument("--mt", type=int, default=4)
+    ap.add_argument("--conv", default="zr", choices=["zr", "q"])
+    args = ap.parse_args()
+    h, w = (int(x) for x in args.size.split("x"))
+    P = h * w
+    dev = torch.device("cuda")
+    ops.TILE_MT = args.mt
+    g = torch.Generator().manual_seed(0)
+    rnd = lambda *s, lo=-1.0, hi=1.0: (lo + (hi - lo) * torch.rand(*s, generator=g))
+    U, R, Dp = L.S16_UNIT, L.S16_RELU, L.S16_DISP
+    net = ops.to_frag16(torch.tanh(rnd(P, 64, lo=-2, hi=2)).to(dev), h, w, U)
+    c2 = ops.to_frag16(torch.relu(rnd(P, 64, lo=-1, hi=2)).to(dev), h, w, R)
+    disp = rnd(P, lo=0.0005, hi=0.0025).to(dev)
+    pc = ops.PackedConvS16(rnd(128, 177, 3, 3, lo=-0.05, hi=0.05), None, [(64, 2, U), (49, 1, Dp), (64, 2, R)], dev)
+    init = ops.s16_layout(rnd(P, 128, lo=-0.3, hi=0.3).to(dev), h, w, L.S16_ACC32)
+    PP = ops.s16_pixels(h, w)
+    th = 2 * args.mt * (1 if args.conv == "zr" else 2)
+    nblk = ((h + th - 1) // th) * ((w + 15) // 16)
+    trace = torch.zeros(ops.s16_pixels(h, w), 64, device=dev, dtype=torch.float32)  # 32 x u64 per wave, in a tensor-shaped buffer
+    assert trace.numel() >= nblk * 4 * 32 * 2
+    z, rn = torch.rand(PP, 64, device=dev), torch.empty(PP, 64, device=dev)
+    if args.conv == "zr":
+        run = lambda: ops.conv3x3_s16(pc, [net, disp, c2], h, w, L.EPI_GATES, out=z, out2=rn, aux=net, aux2=trace, init=init, log2s_out=U, log2s_aux=U)
+    else:
+        pq = ops.PackedConvS16(rnd(64, 177, 3, 3, lo=-0.05, hi=0.05), None, [(64, 2, U), (49, 1, Dp), (64, 2, R)], dev)
+        initq = ops.s16_layout(rnd(P, 64, lo=-0.3, hi=0.3).to(dev), h, w, L.S16_ACC32)
+        net2 = torch.empty(PP, 64, device=dev)
+        run = lambda: ops.conv3x3_s16(pq, [net, disp, c2], h, w, L.EPI_GRU, out=net2, out2=trace, aux=net, aux2=z, init=initq, log2s_out=U, log2s_aux=U)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    t = trace.cpu().numpy().reshape(-1)[:nblk * 4 * 32 * 2].view(np.uint64).reshape(nblk, 4, 32).astype(np.int64)
+    n = t[:, :, 0]
+    hw = t[:, :, 1]
+    xcc = t[:, :, 2] & 0xF
+    t_exit = t[:, :, 3]
+    stamps = t[:, :, 8:]
+    t0 = stamps[:, :, 0]
+    # every XCD has its own cycle counter: rebase per XCD
+    for x in np.unique(xcc):
+        m = xcc == x
+        b = t0[m].min()
+        t_exit[m] -= b
+        stamps[m] -= b
+    t0 = stamps[:, :, 0]
+    base = 0
+    cu = ((hw >> 8) & 0xF) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (xcc << 8)
+    simd = (hw >> 4) & 3
+    print(f"blocks {nblk}, kernel span {(t_exit.max() - base)} cycles; distinct CUs {len(np.unique(cu))}")
+    life = t_exit - t0
+    pro = stamps[:, :, 1] - t0
+    nn = int(n.max())
+    loop_end = np.take_along_axis(stamps, (n - 1)[:, :, None], axis=2)[:, :, 0]
+    main_loop = loop_end - stamps[:, :, 1]
+    epi = t_exit - loop_end
+    nsteps = t[:, :, 4]
+    q = lambda a: "p10 %d  p50 %d  p90 %d  max %d" % tuple(np.percentile(a, [10, 50, 90, 100]))
+    print("wave lifetime      ", q(life))
+    print("prologue           ", q(pro))
+    print("main loop          ", q(main_loop))
+    print("main loop / step   ", q(main_loop / nsteps))
+    print("epilogue           ", q(epi))
+    body = np.diff(stamps[:, :, 1:1 + 5], axis=2)          # first four 9-tap groups
+    print("9-tap group        ", q(body[body > 0]))
+    # residency: for every (cu, simd) the number of co-resident waves, sampled at wave starts
+    ev = []
+    for b in range(nblk):
+        for wv in range(4):
+            ev.append((int(cu[b, wv]), int(simd[b, wv]), int(t0[b, wv] - base), int(t_exit[b, wv] - base)))
+    by = {}
+    for c, s_, a, e in ev:
+        by.setdefault((c, s_), []).append((a, e))
+    tot, busy2, busy1 = 0, 0, 0
+    span = int(t_exit.max() - base)
+    for k, iv in by.items():
+        pts = sorted([(a, 1) for a, _ in iv] + [(e, -1) for _, e in iv])
+        cur, last = 0, 0
+        for x, d in pts:
+            if cur >= 2:
+                busy2 += x - last
+            elif cur == 1:
+                busy1 += x - last
+            cur += d
+            last = x
+        tot += span
+    print(f"SIMD-time with >= 2 waves resident {100 * busy2 / tot:.1f} %, exactly 1 wave {100 * busy1 / tot:.1f} %, idle {100 * (tot - busy1 - busy2) / tot:.1f} %  "
+          f"({len(by)} SIMDs seen)")
+    print("waves per CU (whole launch): ", q(np.bincount(np.unique(cu, return_inverse=True)[1].reshape(-1))))
+
+
+if __name__ == "__main__":
+    main()
