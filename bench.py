@@ -57,8 +57,9 @@ def parse():
                          "of the multi-rank code path on a box with fewer GPUs than ranks: ranks share devices)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "amp"])
     ap.add_argument("--encoder", default="hip", choices=["hip", "miopen"], help="encoder backend: channels-last HIP engine or PyTorch-ROCm (MIOpen)")
-    ap.add_argument("--gru-precision", default="f16x3", choices=["f16x3", "fp32"],
-                    help="arithmetic of the update block's 3x3 convs: split-f16 MFMA with fp32-equivalent accuracy, or exact fp32 MFMA")
+    ap.add_argument("--gru-precision", default="s16", choices=["s16", "f16x3", "fp32"],
+                    help="arithmetic of the update block's 3x3 convs: split-f16 MFMA with fp32-class accuracy (s16: round-2 kernels, one "
+                         "accumulator; f16x3: round-1 kernels), or exact fp32 MFMA")
     return ap.parse_args()
 
 
@@ -91,6 +92,8 @@ def kernel_timing(model, inputs, scale):
         setattr(ops, name, wrap(name, originals[name]))
     originals["conv3x3"] = ops.conv3x3
     ops.conv3x3 = wrap("conv3x3", originals["conv3x3"], conv_label)
+    originals["conv3x3_s16"] = ops.conv3x3_s16
+    ops.conv3x3_s16 = wrap("conv3x3_s16", originals["conv3x3_s16"], conv_label)
     try:
         with torch.no_grad():
             model(*inputs, scale=scale)
@@ -263,7 +266,7 @@ def main():
         n_zr, t_zr = rec["conv3x3_gates_zr"]
         flops_zr = 2.0 * 9 * (64 + 49 + 64) * 128 * P            # algorithmic (unpadded K = net|disp49|corr), DESIGN.md
         achieved = flops_zr / (t_zr / n_zr * 1e-3) / 1e12
-        if args.gru_precision == "f16x3":
+        if args.gru_precision in ("s16", "f16x3"):
             # every fp32 product costs 3 f16 MFMA products -> ceiling = f16 dense peak / 3 in fp32-equivalent flops
             peak, kname = F16_MFMA_PEAK_TFLOPS / 3, "conv3x3_f16x3_kernel<4,2,1,2,3,4,GATES> (z|r gates, 3x3, K=177, N=128; 3 f16 MFMAs per fp32 product)"
         else:
@@ -271,14 +274,14 @@ def main():
         traffic = None                                            # HBM bytes per launch from the committed PMC passes
         try:
             with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f)["conv3x3_gates_zr"]["traffic_bytes"] if args.gru_precision == "f16x3" else None
+                traffic = json.load(f)["conv3x3_gates_zr"]["traffic_bytes"] if args.gru_precision in ("s16", "f16x3") else None
         except Exception:
             traffic = None
         roofline = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                     "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2x FETCH correction)", "avg_launch_us": 1e3 * t_zr / n_zr, "launches": n_zr, "flops_per_launch": flops_zr,
-                    "peak_note": ("fp32-equivalent ceiling = 2500 TF dense f16 MFMA / 3" if args.gru_precision == "f16x3"
+                    "peak_note": ("fp32-equivalent ceiling = 2500 TF dense f16 MFMA / 3" if args.gru_precision in ("s16", "f16x3")
                                   else "fp32 MFMA dense peak"),
-                    "frac_of_raw_f16_peak": (3 * achieved / F16_MFMA_PEAK_TFLOPS) if args.gru_precision == "f16x3" else None}
+                    "frac_of_raw_f16_peak": (3 * achieved / F16_MFMA_PEAK_TFLOPS) if args.gru_precision in ("s16", "f16x3") else None}
         hbm = None
         if "lookup_encode" in rec:
             n_lk, t_lk = rec["lookup_encode"]

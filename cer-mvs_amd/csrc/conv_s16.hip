@@ -89,7 +89,10 @@ __device__ __forceinline__ void sx_join8(const half8 hi, const half8 lo, float i
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = ((float)hi[e] + (float)lo[e]) * inv;
 }
-__device__ __forceinline__ float sx_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// gate non-linearities on the hardware exp2 / rcp (1 ulp each; ~5 instructions instead of ~25 for expf + IEEE division: the
+// epilogue was VALU-bound).  Absolute error <= 3e-7 - the class of the fp32 accumulation that feeds them.
+__device__ __forceinline__ float sx_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float sx_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
 
 struct SxStage {                           // what to put into the NEXT activation buffer
     int kind;                              // 0 nothing, 2 tensor half-chunk, 1 literal disparity group, 3 collapsed disparity group
@@ -289,14 +292,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
         return st;
     };
 
-    // ---- prologue
-    if (dsrc) {
-        for (int idx = tid; idx < DROWS * SX_DTW; idx += 256) {
-            const int r = idx / SX_DTW, c = idx - r * SX_DTW;
-            const int gy = ty0 + r - 4, gx = tx0 + c - 4;
-            ldsD[idx] = (gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) ? dsrc[(long)gy * a.w + gx] : 0.f;
+    // ---- prologue: every global load is issued before anything waits (one memory latency instead of four): activation tile of
+    // group 0, disparity tile, the first two weight slices, the accumulators' initial value
+    struct XFrag { half8 h[MT], l[MT]; };
+    struct WFrag { half8 h, l; };
+    XFrag fx;                                              // activation fragments of the CURRENT step; each m-tile's pair is re-loaded
+    WFrag fw[3];                                           // for the next step as soon as its last MFMA of this step has issued
+    auto load_w = [&](WFrag& f, int step) {
+        const char* p = wlane + ((SX_ABL & 2) ? 0L : (long)min(step, nsteps - 1) * wstep);
+        f.h = *reinterpret_cast<const half8*>(p);
+        f.l = *reinterpret_cast<const half8*>(p + 1024);
+    };
+    const SxStage st0 = describe(0);
+    uint4 raw0[ITEMS];
+    if (st0.kind == 2 && !(SX_ABL & 1)) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int pk = st_pk[i];
+            raw0[i] = *reinterpret_cast<const uint4*>(st0.base + (long)(pk & 0xFFFFF) * st0.mtb + (((pk >> 25) & 3) * 512 + ((pk >> 20) & 31) * 16));
         }
     }
+    constexpr int DITEMS = (DROWS * SX_DTW + 255) / 256;
+    float dval[DITEMS];
+    if (dsrc) {
+#pragma unroll
+        for (int i = 0; i < DITEMS; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx / SX_DTW, c = idx - r * SX_DTW;
+            const int gy = ty0 + r - 4, gx = tx0 + c - 4;
+            dval[i] = (idx < DROWS * SX_DTW && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) ? dsrc[(long)gy * a.w + gx] : 0.f;
+        }
+    }
+    load_w(fw[0], 0);
+    load_w(fw[1], 1);
     // m-tile m of this wave: m-tile row (ty0 >> 1) + wm*MT + m, column tile_x (tiles are whole m-tiles; rows past the image's
     // last m-tile row do not exist in the tensors)
     const int mrow0 = (ty0 >> 1) + wm * MT;
@@ -314,22 +342,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
             } else if (a.bias) {
                 v = cer_ld4(a.bias + nb0 + wn * 32 + 8 * j + 4 * kg);
             }
-            acc[m][4 * j + 0] = v.x * a.S; acc[m][4 * j + 1] = v.y * a.S; acc[m][4 * j + 2] = v.z * a.S; acc[m][4 * j + 3] = v.w * a.S;
+            acc[m][4 * j + 0] = v.x; acc[m][4 * j + 1] = v.y; acc[m][4 * j + 2] = v.z; acc[m][4 * j + 3] = v.w;
         }
     }
-    {
-        const SxStage st0 = describe(0);
-        if (dsrc && st0.kind != 2) barrier();              // the disparity tile feeds the generators
-        stage_tap(st0, 0, 0);
-        stage_tap(st0, 0, 3);
-        stage_tap(st0, 0, 6);
-        barrier();
+    if (dsrc) {
+#pragma unroll
+        for (int i = 0; i < DITEMS; ++i)
+            if (tid + 256 * i < DROWS * SX_DTW) ldsD[tid + 256 * i] = dval[i];
     }
+    if (st0.kind == 2) {
+        if (!(SX_ABL & 1)) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const int pk = st_pk[i];
+                const unsigned m = (pk & (1 << 27)) ? 0xFFFFFFFFu : 0u;
+                uint4 v = raw0[i];
+                v.x &= m; v.y &= m; v.z &= m; v.w &= m;
+                const int it = tid + 256 * i;
+                const int n = it >> 2, r = n / SX_HW, c = n - r * SX_HW;
+                if (pk & (1 << 28)) *reinterpret_cast<uint4*>(sx_smem + (r * SX_PITCH + c) * 64 + (it & 3) * 16) = v;
+            }
+        }
+    } else {
+        barrier();                                         // the disparity tile feeds the generators
+        stage_tap(st0, 0, 6);
+    }
+    barrier();
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] *= a.S;
 
-    struct XFrag { half8 h[MT], l[MT]; };
-    struct WFrag { half8 h, l; };
-    XFrag fx;                                              // activation fragments of the CURRENT step; each m-tile's pair is re-loaded
-    WFrag fw[3];                                           // for the next step as soon as its last MFMA of this step has issued
     auto load_x = [&](XFrag& f, int ph, int pl, int rowoff) {      // rowoff: compile-time (dy rows)
         if (SX_ABL & 32) return;
 #pragma unroll
@@ -337,11 +380,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
             f.h[m] = *reinterpret_cast<const half8*>(sx_smem + ph + (2 * m) * SX_ROWB + rowoff);
             f.l[m] = *reinterpret_cast<const half8*>(sx_smem + pl + (2 * m) * SX_ROWB + rowoff);
         }
-    };
-    auto load_w = [&](WFrag& f, int step) {
-        const char* p = wlane + ((SX_ABL & 2) ? 0L : (long)min(step, nsteps - 1) * wstep);
-        f.h = *reinterpret_cast<const half8*>(p);
-        f.l = *reinterpret_cast<const half8*>(p + 1024);
     };
     // one step: 3 * MT MFMAs (consecutive MFMAs hit different accumulators), and the next step's fragments rolled in behind them
     auto mma_roll = [&](const WFrag& w, int ph, int pl, int rowoff) {
@@ -370,9 +408,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
     };
 
     // first tap of group gi inside its buffer: tap 0 (dy = dx = 0), or the centre tap for a collapsed disparity group
-    const bool first_is_centre0 = describe(0).kind == 3;
-    load_w(fw[0], 0);
-    load_w(fw[1], 1);
+    const bool first_is_centre0 = st0.kind == 3;
     if (first_is_centre0) load_x(fx, xh[1], xl[1], SX_ROWB);
     else load_x(fx, xh[0], xl[0], 0);
 
@@ -482,71 +518,88 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
         return;
     } else {
         const int nt = (nb0 >> 5) + wn;                    // this wave's 32-channel tile of the output
+        // frag16 / f32x8 byte offset of the lane's piece of (m-tile, 16-channel group g) in a tensor of G groups: both planes
+        // (hi | lo, or the two float4) are 1 KiB apart
+        auto piece = [&](int m, int G, int g) { return (((mt0 + (long)m * a.mtx) * G + g) * 2) * 1024 + lane * 16; };
+        if (EPI == CER_EPI_LINEAR && !a.out_split) {       // acc32 layout: the accumulators as they are (a later conv's `init`)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            if (mrow0 + m >= a.mty) continue;              // wave-uniform: the m-tile row is past the image
-            const long mt = mt0 + (long)m * a.mtx;
-            if (EPI == CER_EPI_LINEAR && !a.out_split) {   // acc32 layout: the accumulators as they are (a later conv's `init`)
+            for (int m = 0; m < MT; ++m) {
+                if (mrow0 + m >= a.mty) continue;          // wave-uniform: the m-tile row is past the image
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.out) + ((mt * NT + nt) * 4 + j) * 1024 + lane * 16) =
+                    *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.out) + (((mt0 + (long)m * a.mtx) * NT + nt) * 4 + j) * 1024 + lane * 16) =
                         make_float4(acc[m][4 * j] * a.invS, acc[m][4 * j + 1] * a.invS, acc[m][4 * j + 2] * a.invS, acc[m][4 * j + 3] * a.invS);
-                continue;
             }
+        } else {
+            const bool is_r = EPI == CER_EPI_GATES && nt * 32 >= half;          // wave-uniform: this wave holds reset-gate channels
+            const int G = (EPI == CER_EPI_GATES ? half : a.cout) >> 4;         // 16-channel groups of the destination / aux tensors
+            const int g0 = (EPI == CER_EPI_GATES ? ((nt * 32) % half) >> 4 : nt * 2);
+            // (1) every operand of the gate math is requested before anything is computed or stored: the stores below may alias
+            // the loads as far as the compiler knows, so it would otherwise run load -> math -> store once per (m, jp)
+            half8 ph[MT][2], pl[MT][2];
+            float4 z0[MT][2], z1[MT][2];
+            if ((EPI == CER_EPI_GATES && is_r) || EPI == CER_EPI_GRU) {
 #pragma unroll
-            for (int jp = 0; jp < 2; ++jp) {
-                float v[8];
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[m][8 * jp + e]), __float_as_uint(acc[m][8 * jp + 4 + e]), false, false);
-                    v[e] = __uint_as_float(sw[0]) * a.invS;
-                    v[4 + e] = __uint_as_float(sw[1]) * a.invS;
-                }
-                // frag16 planes of channel group g of a C-channel tensor: ((mt * C/16 + g) * 2 + hl) * 1024 + lane * 16
-                auto st_split = [&](float* base, int G, int g, const float (&o)[8]) {
-                    half8 hi, lo;
-                    sx_split8(o, a.out_scale, hi, lo);
-                    char* p = reinterpret_cast<char*>(base) + ((mt * G + g) * 2) * 1024 + lane * 16;
-                    *reinterpret_cast<half8*>(p) = hi;
-                    *reinterpret_cast<half8*>(p + 1024) = lo;
-                };
-                auto ld_split = [&](const float* base, int G, int g, float (&o)[8]) {
-                    const char* p = reinterpret_cast<const char*>(base) + ((mt * G + g) * 2) * 1024 + lane * 16;
-                    sx_join8(*reinterpret_cast<const half8*>(p), *reinterpret_cast<const half8*>(p + 1024), a.aux_inv, o);
-                };
-                // fp32 "swapped" layout (z): ((mt * C/16 + g) * 2 + q) * 1024 + lane * 16, q = first / second float4 of the 8 channels
-                auto st_f32 = [&](float* base, int G, int g, const float (&o)[8]) {
-                    char* p = reinterpret_cast<char*>(base) + ((mt * G + g) * 2) * 1024 + lane * 16;
-                    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
-                    *reinterpret_cast<float4*>(p + 1024) = make_float4(o[4], o[5], o[6], o[7]);
-                };
-                const int gl = (((nt * 32) % half) >> 4) + jp;                   // GATES: 16-channel group inside z / r*h
-                if (EPI == CER_EPI_LINEAR || EPI == CER_EPI_RELU) {
-                    if (EPI == CER_EPI_RELU)
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-                    st_split(a.out, a.cout >> 4, nt * 2 + jp, v);
-                } else if (EPI == CER_EPI_GATES) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = sx_sigmoid(v[e]);
-                    if (nt * 32 < half) {
-                        st_f32(a.out, half >> 4, gl, v);                         // z stays fp32 (blend operand of the q conv)
-                    } else {
-                        float hp[8];
-                        ld_split(a.aux, half >> 4, gl, hp);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] *= hp[e];
-                        st_split(a.out2, half >> 4, gl, v);
+                    for (int jp = 0; jp < 2; ++jp) {
+                        if (mrow0 + m >= a.mty) continue;
+                        const char* p = reinterpret_cast<const char*>(a.aux) + piece(m, G, g0 + jp);
+                        ph[m][jp] = *reinterpret_cast<const half8*>(p);
+                        pl[m][jp] = *reinterpret_cast<const half8*>(p + 1024);
+                        if (EPI == CER_EPI_GRU) {
+                            const char* zp = reinterpret_cast<const char*>(a.aux2) + piece(m, G, g0 + jp);
+                            z0[m][jp] = *reinterpret_cast<const float4*>(zp);
+                            z1[m][jp] = *reinterpret_cast<const float4*>(zp + 1024);
+                        }
                     }
-                } else if (EPI == CER_EPI_GRU) {
-                    float hp[8];
-                    ld_split(a.aux, a.cout >> 4, nt * 2 + jp, hp);
-                    const char* zp = reinterpret_cast<const char*>(a.aux2) + ((mt * (a.cout >> 4) + nt * 2 + jp) * 2) * 1024 + lane * 16;
-                    const float4 z0 = *reinterpret_cast<const float4*>(zp), z1 = *reinterpret_cast<const float4*>(zp + 1024);
-                    const float z[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+            }
+            // (2) math + stores
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (1.0f - z[e]) * hp[e] + z[e] * tanhf(v[e]);
-                    st_split(a.out, a.cout >> 4, nt * 2 + jp, v);
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[m][8 * jp + e]), __float_as_uint(acc[m][8 * jp + 4 + e]), false, false);
+                        v[e] = __uint_as_float(sw[0]) * a.invS;
+                        v[4 + e] = __uint_as_float(sw[1]) * a.invS;
+                    }
+                    if (mrow0 + m >= a.mty) continue;      // wave-uniform
+                    const long off = piece(m, G, g0 + jp);
+                    auto st_split = [&](float* base, const float (&o)[8]) {
+                        half8 hi, lo;
+                        sx_split8(o, a.out_scale, hi, lo);
+                        *reinterpret_cast<half8*>(reinterpret_cast<char*>(base) + off) = hi;
+                        *reinterpret_cast<half8*>(reinterpret_cast<char*>(base) + off + 1024) = lo;
+                    };
+                    if (EPI == CER_EPI_LINEAR || EPI == CER_EPI_RELU) {
+                        if (EPI == CER_EPI_RELU)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                        st_split(a.out, v);
+                    } else if (EPI == CER_EPI_GATES) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = sx_sigmoid(v[e]);
+                        if (!is_r) {                       // z stays fp32 (f32x8 layout): blend operand of the q conv's epilogue
+                            *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.out) + off) = make_float4(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.out) + off + 1024) = make_float4(v[4], v[5], v[6], v[7]);
+                        } else {
+                            float hp[8];
+                            sx_join8(ph[m][jp], pl[m][jp], a.aux_inv, hp);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] *= hp[e];
+                            st_split(a.out2, v);
+                        }
+                    } else if (EPI == CER_EPI_GRU) {
+                        float hp[8];
+                        sx_join8(ph[m][jp], pl[m][jp], a.aux_inv, hp);
+                        const float z[8] = {z0[m][jp].x, z0[m][jp].y, z0[m][jp].z, z0[m][jp].w, z1[m][jp].x, z1[m][jp].y, z1[m][jp].z, z1[m][jp].w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (1.0f - z[e]) * hp[e] + z[e] * sx_tanh(v[e]);
+                        st_split(a.out, v);
+                    }
                 }
             }
         }

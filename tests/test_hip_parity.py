@@ -490,7 +490,7 @@ def test_large_configs_run(dev):
 
 
 # ------------------------------------------------------------------------------------ end to end
-def _run_e2e(dev, golden, name, literal=False, gru_precision="f16x3"):
+def _run_e2e(dev, golden, name, literal=False, gru_precision="s16"):
     from cer_mvs_amd import RAFT
     from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene, tensor_checksum
     g = golden(name)
@@ -527,7 +527,7 @@ def test_end_to_end_tiny_literal_api(dev, golden):
     assert e_disp < TOL and e_depth < TOL
 
 
-@pytest.mark.parametrize("gru_precision", ["f16x3", "fp32"])
+@pytest.mark.parametrize("gru_precision", ["s16", "f16x3", "fp32"])
 def test_end_to_end_cfg1(dev, golden, gru_precision):
     """BASELINE.json configs[0] shape: 640x480, 1 ref + 2 src views, 4 GRU iterations."""
     e_disp, e_depth = _run_e2e(dev, golden, "e2e_cfg1", gru_precision=gru_precision)

@@ -38,7 +38,7 @@ def main():
     H, W = (int(x) for x in args.size.split("x"))
     V = args.views
     dev = torch.device("cuda")
-    model = RAFT(cascade=[(64, 64, 16), (-1, 320, 16)], test_mode=True)
+    model = RAFT(cascade=[(64, 64, 16), (-1, 320, 16)], test_mode=True, gru_precision="f16x3")   # (s16 convs: tools/bench_conv_s16.py)
     model.load_state_dict(fill_state_dict(model.state_dict(), seed=5))
     model = model.to(dev).eval()
     images, poses, intr, scale = synthetic_scene(H, W, V, seed=0)
@@ -70,7 +70,7 @@ def main():
         vol, origin = ops.cost_build(f1, f2, Pij, disp0, D0, i0, True, h, w, 3, fold=True)
         run("pyramid", lambda: ops.pyramid(vol, D0, 3, 1.0 / V))
         p = ub.packed(0, dev)
-        ws = ub.workspace(P, dev)
+        ws = ub.workspace(h, w, dev)
         hz, hq = ub.hoist(inp_l, h, w)
         dd = disp1.clone()
         run("lookup_encode", lambda: ops.lookup_encode(vol, origin, dd, p["w0t"], p["b0"], D0, i0, 3, 5, out=ws["c1"]))
