@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CER_MVS_LIB") or os.path.join(_HERE, "csrc", "libcermvs.so")
-ABI_VERSION = 1021
+ABI_VERSION = 1023
 CONV_MAX_SRC = 4
 EPI_LINEAR, EPI_RELU, EPI_GATES, EPI_GRU, EPI_DELTA = 0, 1, 2, 3, 4
 EPI_OUT_SPLIT, EPI_AUX_SPLIT = 0x100, 0x200       # cer_mvs.h: split32 activation layout flags, or-ed into `epi`
@@ -78,7 +78,9 @@ _SIGNATURES = {
     "cer_conv3x3_s16_packed_size": (_L, [_I, _c.POINTER(_I), _c.POINTER(_I), _I, _I]),
     "cer_conv3x3_s16_scale": (_I, [_P, _I, _I, _c.POINTER(_I), _c.POINTER(_I), _c.POINTER(_I), _I]),
     "cer_conv3x3_s16_pack": (_I, [_P, _P, _I, _I, _c.POINTER(_I), _c.POINTER(_I), _c.POINTER(_I), _I, _I, _I]),
-    "cer_conv3x3_s16": (_I, [_c.POINTER(ConvInputs), _c.POINTER(_I), _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "cer_conv3x3_s16_edge_size": (_L, [_I]),
+    "cer_conv3x3_s16_edge_pack": (_I, [_P, _P, _I, _I, _c.POINTER(_I), _c.POINTER(_I), _c.POINTER(_I), _I, _I]),
+    "cer_conv3x3_s16": (_I, [_c.POINTER(ConvInputs), _c.POINTER(_I), _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cer_delta_proj_s16_packed_size": (_L, [_I]),
     "cer_delta_proj_s16_pack": (_I, [_P, _P, _I, _c.POINTER(_I)]),
     "cer_s16_padded_pixels": (_L, [_I, _I]),

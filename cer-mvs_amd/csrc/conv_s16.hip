@@ -63,6 +63,7 @@ struct S16Args {
     float* out2;
     const float* aux;
     const float* aux2;
+    const void* edge;                      // rim-correction filters of the collapsed disparity form (cer_conv3x3_s16_edge_pack) or null
     int h, w, cout, tiles_x, ntiles, ny, mtx, mty;
     float S, invS;                         // accumulator = S * conv
     float out_scale;                       // frag16 outputs
@@ -140,7 +141,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
     int ntens = a.nsrc;
     const float* dsrc = nullptr;
     if (a.kind[a.nsrc - 1] == 1) { ntens = a.nsrc - 1; dsrc = reinterpret_cast<const float*>(a.src[a.nsrc - 1]); }
-    const bool coll = dsrc && a.wpk_c && ty0 >= 1 && ty0 + TH <= a.h - 1 && tx0 >= 1 && tx0 + SX_TW <= a.w - 1;
+    // collapsed disparity form: exact for pixels whose 3x3 neighbourhood lies inside the image - i.e. on interior tiles; with the
+    // rim correction of the epilogue (a.edge) on every tile
+    const bool interior = ty0 >= 1 && ty0 + TH <= a.h - 1 && tx0 >= 1 && tx0 + SX_TW <= a.w - 1;
+    const bool coll = dsrc && a.wpk_c && (interior || a.edge);
     int nsteps = 0;
     for (int s = 0; s < ntens; ++s) nsteps += (a.ch[s] >> 4) * 9;
     if (dsrc) nsteps += coll ? 6 : 36;
@@ -393,16 +397,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h, fx.h[m], acc[m], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h, fx.l[m], acc[m], 0, 0, 0);
-            if (!(SX_ABL & 32)) fx.l[m] = *reinterpret_cast<const half8*>(sx_smem + pl + (2 * m) * SX_ROWB + rowoff);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        // the hi fragments are needed first in the next step: roll them in during the SECOND term (2 * MT - 1 MFMAs of slack for the
+        // LDS latency), the lo fragments during the third (a whole step of slack)
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.l, fx.h[m], acc[m], 0, 0, 0);
             if (!(SX_ABL & 32)) fx.h[m] = *reinterpret_cast<const half8*>(sx_smem + ph + (2 * m) * SX_ROWB + rowoff);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h, fx.l[m], acc[m], 0, 0, 0);
+            if (!(SX_ABL & 32)) fx.l[m] = *reinterpret_cast<const half8*>(sx_smem + pl + (2 * m) * SX_ROWB + rowoff);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -459,6 +465,54 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
     // v_permlane32_swap on register pairs (j = 2jp, 2jp + 1): lanes 0-31 end up with channels 16jp + 0..7, lanes 32-63 with
     // 16jp + 8..15 of their pixel - 8 consecutive channels starting at cb = nb0 + wn*32 + 16jp + 8kg: exactly this lane's
     // 16-byte pieces of the frag16 planes (hi | lo) of group cb >> 4, so every tensor access below is one contiguous KiB per wave.
+    // ---- rim correction of the collapsed disparity form.  The 3x3 conv zero-pads the FEATURE map (core/update.py:80-85: features
+    // of a position q outside the image are 0), while the collapsed filter evaluated 100 * (d~(q + u - 3) - 0) there (d~ = zero
+    // -padded disparity).  For a pixel on the image rim subtract  E = sum_{taps t with q_t outside} sum_u w[t][u] * 100 * d~(q_t+u-3):
+    // per touched edge a 27-tap filter on the disparity, minus the corner tap two edges share.  It is a small matmul
+    // ([32 channels x 27] x [27 x pixels]), so it runs as extra K-steps: the filters arrive packed like weights (negated, same
+    // scale as the disparity source), the "activations" are generated in registers as B fragments (zero for pixels off the edge).
+    if (coll && a.edge && !interior) {
+        const _Float16* ew = reinterpret_cast<const _Float16*>(a.edge) + ((long)(nb0 >> 5) + wn) * 1024 + lane * 8;
+#pragma unroll                                             // (acc[m] must stay statically indexed: registers, not scratch)
+        for (int m = 0; m < MT; ++m) {
+            const int py = 2 * (wm * MT + m) + (li >> 4), px = li & 15;       // pixel inside the tile
+            const int y = ty0 + py, x = tx0 + px;
+            const bool in = y < a.h && x < a.w;
+            const bool top = in && y == 0, bot = in && y == a.h - 1, lef = in && x == 0, rig = in && x == a.w - 1;
+            // disparity at image (r, c) from the tile in LDS: ldsD(i, j) = image (ty0 - 4 + i, tx0 - 4 + j), zero outside the image
+            auto D = [&](int r, int c) { return ldsD[(r - ty0 + 4) * SX_DTW + (c - tx0 + 4)]; };
+            auto apply = [&](int e, int nks, bool on, auto&& pos) {           // pos(k, r, c): image position of filter tap k
+                if (!__any(on)) return;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    if (ks >= nks) break;
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int k = 16 * ks + 8 * kg + q;
+                        int r = 0, c = 0;
+                        const bool ok = pos(k, r, c);
+                        v[q] = (on && ok) ? 100.0f * D(r, c) : 0.f;
+                    }
+                    half8 fh, fl;
+                    sx_split8(v, a.disp_scale, fh, fl);
+                    const _Float16* wp = ew + (long)((e * 2 + ks) * NT) * 1024;
+                    const half8 wh = *reinterpret_cast<const half8*>(wp), wl = *reinterpret_cast<const half8*>(wp + 512);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fh, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fl, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, fh, acc[m], 0, 0, 0);
+                }
+            };
+            apply(0, 2, top, [&](int k, int& r, int& c) { r = k / 9; c = x + k % 9 - 4; return k < 27; });
+            apply(1, 2, bot, [&](int k, int& r, int& c) { r = a.h - 3 + k / 9; c = x + k % 9 - 4; return k < 27; });
+            apply(2, 2, lef, [&](int k, int& r, int& c) { r = y + k / 3 - 4; c = k % 3; return k < 27; });
+            apply(3, 2, rig, [&](int k, int& r, int& c) { r = y + k / 3 - 4; c = a.w - 3 + k % 3; return k < 27; });
+            apply(4, 1, top && lef, [&](int k, int& r, int& c) { r = k / 3; c = k % 3; return k < 9; });
+            apply(5, 1, top && rig, [&](int k, int& r, int& c) { r = k / 3; c = a.w - 3 + k % 3; return k < 9; });
+            apply(6, 1, bot && lef, [&](int k, int& r, int& c) { r = a.h - 3 + k / 3; c = k % 3; return k < 9; });
+            apply(7, 1, bot && rig, [&](int k, int& r, int& c) { r = a.h - 3 + k / 3; c = a.w - 3 + k % 3; return k < 9; });
+        }
+    }
     const int half = a.cout >> 1;
     if (SX_ABL & 4) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -673,8 +727,24 @@ extern "C" int cer_conv3x3_s16_scale(const float* w, int Cout, int Cin, const in
         for (int co = 0; co < Cout; ++co) {
             for (int i = 0; i < ch[s]; ++i)
                 for (int t = 0; t < 9; ++t) m = fmax(m, fabs((double)w[((long)co * Cin + c + i) * 9 + t]));
-            if (kind[s] == 1)
+            if (kind[s] == 1) {
                 for (int sidx = 0; sidx < 81; ++sidx) m = fmax(m, fabs(sx_w9(w, Cin, co, c, sidx)));
+                // the rim-correction filters sum at most 3 taps per entry
+                double m3 = 0.0;
+                for (int u = 0; u < 49; ++u) {
+                    for (int ty = 0; ty < 3; ++ty) {
+                        double sr = 0.0;
+                        for (int tx = 0; tx < 3; ++tx) sr += fabs((double)w[((long)co * Cin + c + u) * 9 + ty * 3 + tx]);
+                        m3 = fmax(m3, sr);
+                    }
+                    for (int tx = 0; tx < 3; ++tx) {
+                        double sc = 0.0;
+                        for (int ty = 0; ty < 3; ++ty) sc += fabs((double)w[((long)co * Cin + c + u) * 9 + ty * 3 + tx]);
+                        m3 = fmax(m3, sc);
+                    }
+                }
+                m = fmax(m, m3);
+            }
         }
         wmax[s] = m;
         c += ch[s];
@@ -688,6 +758,60 @@ extern "C" int cer_conv3x3_s16_scale(const float* w, int Cout, int Cin, const in
     }
     if (best == 1000) best = 14;
     return best;
+}
+
+// Rim-correction filters of the collapsed disparity form (see the kernel's epilogue), packed like weight slices:
+// [edge 8][k16-step 2][ntile][hi|lo][lane][8] halves of  -sign * Wedge[k][co] * 2^(log2S - log2sx(disparity source)):
+// edges 0-3 = top, bottom, left, right (27 taps: top/bottom k = a * 9 + sx, left/right k = sy * 3 + b), 4-7 = the corner taps two
+// edges share (9 taps, k = i * 3 + j; opposite sign): top-left, top-right, bottom-left, bottom-right.
+extern "C" long cer_conv3x3_s16_edge_size(int Cout) { return (Cout > 0 && Cout % 32 == 0) ? 16L * (Cout / 32) * 1024 : CER_ESHAPE; }
+
+static void sx_pack_slice(_Float16* packed, long step, int NT, int nt, const double* col, double scale);
+
+extern "C" int cer_conv3x3_s16_edge_pack(const float* w, void* out_v, int Cout, int Cin, const int* ch, const int* kind, const int* log2sx, int nsrc,
+                                         int log2S) {
+    if (!w || !out_v || !ch || !kind || !log2sx || nsrc <= 0 || nsrc > CER_CONV_MAX_SRC) return CER_EINVAL;
+    if (Cout % 32) return CER_ESHAPE;
+    int c0 = -1, c = 0, sd = -1;
+    for (int s = 0; s < nsrc; ++s) {
+        if (kind[s] == 1) { if (ch[s] != 49 || c0 >= 0) return CER_ESHAPE; c0 = c; sd = s; }
+        c += ch[s];
+    }
+    if (c != Cin || c0 < 0) return CER_ESHAPE;
+    auto W = [&](int co, int uy, int ux, int ty, int tx) -> double {
+        if (uy < 0 || uy > 6 || ux < 0 || ux > 6) return 0.0;
+        return (double)w[((long)co * Cin + c0 + uy * 7 + ux) * 9 + ty * 3 + tx];
+    };
+    // Wedge[edge][k][co]
+    auto edge_w = [&](int e, int k, int co) -> double {
+        if (e < 4) {
+            if (k >= 27) return 0.0;
+            double v = 0;
+            if (e == 0) { const int a = k / 9, sx = k % 9; for (int tx = 0; tx < 3; ++tx) v += W(co, a + 4, sx - tx, 0, tx); }
+            if (e == 1) { const int a = k / 9, sx = k % 9; for (int tx = 0; tx < 3; ++tx) v += W(co, a, sx - tx, 2, tx); }
+            if (e == 2) { const int sy = k / 3, b = k % 3; for (int ty = 0; ty < 3; ++ty) v += W(co, sy - ty, b + 4, ty, 0); }
+            if (e == 3) { const int sy = k / 3, b = k % 3; for (int ty = 0; ty < 3; ++ty) v += W(co, sy - ty, b, ty, 2); }
+            return -v;                                     // the rim terms are SUBTRACTED from the collapsed result
+        }
+        if (k >= 9) return 0.0;
+        const int i = k / 3, j = k % 3;
+        if (e == 4) return W(co, i + 4, j + 4, 0, 0);      // ... and the shared corner tap is added back once
+        if (e == 5) return W(co, i + 4, j, 0, 2);
+        if (e == 6) return W(co, i, j + 4, 2, 0);
+        return W(co, i, j, 2, 2);
+    };
+    _Float16* packed = (_Float16*)out_v;
+    const int NT = Cout / 32;
+    const double scale = ldexp(1.0, log2S - log2sx[sd]);
+    double col[16 * 32];
+    for (int e = 0; e < 8; ++e)
+        for (int ks = 0; ks < 2; ++ks)
+            for (int nt = 0; nt < NT; ++nt) {
+                for (int k = 0; k < 16; ++k)
+                    for (int j = 0; j < 32; ++j) col[k * 32 + j] = edge_w(e, ks * 16 + k, nt * 32 + j);
+                sx_pack_slice(packed, e * 2 + ks, NT, nt, col, scale);
+            }
+    return CER_OK;
 }
 
 static void sx_pack_slice(_Float16* packed, long step, int NT, int nt, const double* col /* [16 k][32 co] */, double scale) {
@@ -821,8 +945,8 @@ static int sx_num_cus() {
     return n;
 }
 
-extern "C" int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, const void* packed_w, const void* packed_collapsed, int log2S,
-                               const float* bias, const float* init, float* out, float* out2, const float* aux, const float* aux2, int h,
+extern "C" int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, const void* packed_w, const void* packed_collapsed,
+                               const void* edge_w, int log2S, const float* bias, const float* init, float* out, float* out2, const float* aux, const float* aux2, int h,
                                int w, int Cout, int epi, int log2s_out, int log2s_aux, int tile_mt, void* stream) {
     if (!in || !log2sx || !packed_w || !out || h <= 0 || w <= 0 || Cout <= 0) return CER_EINVAL;
     if (in->nsrc <= 0 || in->nsrc > CER_CONV_MAX_SRC) return CER_EINVAL;
@@ -833,7 +957,7 @@ extern "C" int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, con
     if (epi == SX_EPI_DELTA && (!aux || Cout % 128 != 0)) return CER_EINVAL;
     if (Cout % 64 != 0) return CER_ESHAPE;
     if ((long)h * w >= (1L << 27)) return CER_ESHAPE;
-    if (!cer_aligned16(packed_w) || !cer_aligned16(packed_collapsed) || !cer_aligned16(init) || !cer_aligned16(bias) || !cer_aligned16(out) ||
+    if (!cer_aligned16(packed_w) || !cer_aligned16(packed_collapsed) || !cer_aligned16(edge_w) || !cer_aligned16(init) || !cer_aligned16(bias) || !cer_aligned16(out) ||
         !cer_aligned16(out2) || !cer_aligned16(aux) || !cer_aligned16(aux2))
         return CER_EALIGN;
     S16Args a;
@@ -855,6 +979,7 @@ extern "C" int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, con
     }
     a.wpk = (const _Float16*)packed_w;
     a.wpk_c = (const _Float16*)packed_collapsed;
+    a.edge = packed_collapsed ? edge_w : nullptr;
     a.bias = bias;
     a.init = init;
     a.out = out;

@@ -370,7 +370,13 @@ class PackedConvS16:
                                              self.log2S), "conv3x3_s16_pack")
             return t.to(device)
         self.packed = pack(0)
-        self.packed_c = pack(1) if any(k == 1 for _, k, _ in sources) else None
+        self.packed_c, self.edge = None, None
+        if any(k == 1 for _, k, _ in sources):
+            self.packed_c = pack(1)
+            edge = torch.empty(lib.cer_conv3x3_s16_edge_size(Cout), dtype=torch.float16)
+            L.check(lib.cer_conv3x3_s16_edge_pack(wp, ctypes.c_void_p(edge.data_ptr()), Cout, Cin, self.ch, self.kind, self.log2sx, n, self.log2S),
+                    "conv3x3_s16_edge_pack")
+            self.edge = edge.to(device)
         self.bias = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
         self.cout = Cout
 
@@ -390,6 +396,7 @@ def delta_proj_pack_s16(w2, device):
 
 
 TILE_MT = 0              # 0: let the library choose the tile height; tests force 3 / 4 / 5
+EDGE_CORRECT = True      # collapsed disparity form on every tile + rim correction (False: border tiles run the literal form)
 
 
 def conv3x3_s16(pc, srcs, h, w, epi, out=None, out2=None, aux=None, aux2=None, init=None, use_bias=True, out_split=False,
@@ -425,8 +432,9 @@ def conv3x3_s16(pc, srcs, h, w, epi, out=None, out2=None, aux=None, aux2=None, i
     bias = pc.bias if (use_bias and init is None) else None
     aux_p = L.dev_ptr(aux, "aux", torch.float16) if epi == L.EPI_DELTA else L.dev_ptr(aux, "aux")
     coll = L.dev_ptr(pc.packed_c, "packed_collapsed", torch.float16) if (COLLAPSE_DISP and pc.packed_c is not None) else None
+    edge = L.dev_ptr(pc.edge, "edge_w", torch.float16) if (EDGE_CORRECT and coll is not None) else None
     flags = L.EPI_OUT_SPLIT if (out_split or epi in (L.EPI_RELU, L.EPI_GATES, L.EPI_GRU)) else 0
-    rc = L.load().cer_conv3x3_s16(ctypes.byref(ci), pc.log2sx, L.dev_ptr(pc.packed, "packed_w", torch.float16), coll, pc.log2S,
+    rc = L.load().cer_conv3x3_s16(ctypes.byref(ci), pc.log2sx, L.dev_ptr(pc.packed, "packed_w", torch.float16), coll, edge, pc.log2S,
                                   L.dev_ptr(bias, "bias"), L.dev_ptr(init, "init"), L.dev_ptr(out, "out"), L.dev_ptr(out2, "out2"), aux_p,
                                   L.dev_ptr(aux2, "aux2"), h, w, pc.cout, epi | flags, int(log2s_out), int(log2s_aux), int(TILE_MT),
                                   L.cur_stream())

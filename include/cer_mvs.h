@@ -230,8 +230,16 @@ long cer_conv3x3_s16_packed_size(int Cout, const int* ch, const int* kind, int n
 int cer_conv3x3_s16_scale(const float* w_oihw, int Cout, int Cin, const int* ch, const int* kind, const int* log2sx, int nsrc);
 int cer_conv3x3_s16_pack(const float* w_oihw, void* packed, int Cout, int Cin, const int* ch, const int* kind, const int* log2sx,
                          int nsrc, int collapsed, int log2S);
-int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, const void* packed_w, const void* packed_collapsed, int log2S,
-                    const float* bias, const float* init, float* out, float* out2, const float* aux, const float* aux2,
+/* edge_w (may be NULL): rim-correction filters packed by cer_conv3x3_s16_edge_pack (size in 2-byte halves from
+ * cer_conv3x3_s16_edge_size; same log2sx / log2S as the weights).  With them EVERY tile evaluates the disparity source in the
+ * collapsed form and pixels on the image's 1-pixel rim subtract, as a few extra MFMA steps after the main loop, what the taps
+ * whose feature position lies outside the image contributed (the 3x3 conv zero-pads the feature map, core/update.py:80-85);
+ * without them border tiles run the literal form (36 steps instead of 6 for that source). */
+long cer_conv3x3_s16_edge_size(int Cout);
+int cer_conv3x3_s16_edge_pack(const float* w_oihw, void* out, int Cout, int Cin, const int* ch, const int* kind, const int* log2sx,
+                              int nsrc, int log2S);
+int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, const void* packed_w, const void* packed_collapsed,
+                    const void* edge_w, int log2S, const float* bias, const float* init, float* out, float* out2, const float* aux, const float* aux2,
                     int h, int w, int Cout, int epi, int log2s_out, int log2s_aux, int tile_mt, void* stream);
 long cer_delta_proj_s16_packed_size(int C);
 int cer_delta_proj_s16_pack(const float* w2_oihw, void* packed, int C, int* log2s_out);

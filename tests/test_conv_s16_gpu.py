@@ -129,17 +129,33 @@ def test_conv_s16_disparity_source(dev, tile_mt, h, w, cout, mt):
     assert pc.packed_c is not None
     srcs = [frag(a, h, w, L.S16_UNIT), disp.reshape(-1).to(dev)]
     outs = {}
-    for flag in (True, False):
-        ops.COLLAPSE_DISP = flag
+    # (collapsed everywhere + rim correction: the default) / (collapsed on interior tiles, literal on border tiles) / (literal)
+    for mode, (coll, edge) in {"rim": (True, True), "mixed": (True, False), "literal": (False, False)}.items():
+        ops.COLLAPSE_DISP, ops.EDGE_CORRECT = coll, edge
         try:
-            outs[flag] = unacc(ops.conv3x3_s16(pc, srcs, h, w, L.EPI_LINEAR), h, w)
+            outs[mode] = unacc(ops.conv3x3_s16(pc, srcs, h, w, L.EPI_LINEAR), h, w)
         finally:
-            ops.COLLAPSE_DISP = True
-        assert rel_l1(outs[flag], ref) < 2e-6, flag
-        assert (outs[flag] - ref).abs().max() < 5e-6 * ref.abs().max()
+            ops.COLLAPSE_DISP, ops.EDGE_CORRECT = True, True
+        assert rel_l1(outs[mode], ref) < 2e-6, mode
+        assert (outs[mode] - ref).abs().max() < 5e-6 * ref.abs().max(), mode
+    assert not torch.equal(outs["rim"], outs["literal"])         # the collapsed path really ran
     th = 2 * ops.TILE_MT * (1 if cout == 128 else 2)
     if h >= 2 * th + 2:                                          # at least one interior tile row
-        assert not torch.equal(outs[True], outs[False])          # some tiles really took the collapsed path
+        assert not torch.equal(outs["mixed"], outs["literal"])
+
+
+@pytest.mark.parametrize("h,w", [(1, 16), (2, 3), (3, 40), (40, 2), (9, 17)])
+def test_conv_s16_rim_correction_degenerate_images(dev, h, w):
+    """Images so small that a pixel lies on several edges at once (all four for 1 x n): the rim correction sums the edges and
+    removes the corner taps they share."""
+    from cer_mvs_amd import _lib as L, ops
+    from oracle import cer_oracle as O
+    disp = hashed((1, 1, h, w), 231, 0.0005, 0.0025)
+    wt = hashed((64, 49, 3, 3), 233, -0.1, 0.1)
+    ref = nhwc(F.conv2d((100 * O.disp_features(disp)).double(), wt.double(), None, padding=1))
+    pc = ops.PackedConvS16(wt, None, [(49, 1, L.S16_DISP)], dev)
+    out = unacc(ops.conv3x3_s16(pc, [disp.reshape(-1).to(dev)], h, w, L.EPI_LINEAR), h, w)
+    assert rel_l1(out, ref) < 2e-6 and (out - ref).abs().max() < 5e-6 * ref.abs().max()
 
 
 def test_conv_s16_disparity_only_source(dev):

@@ -80,29 +80,21 @@ def main():
     print("epilogue           ", q(epi))
     body = np.diff(stamps[:, :, 1:1 + 5], axis=2)          # first four 9-tap groups
     print("9-tap group        ", q(body[body > 0]))
-    # residency: for every (cu, simd) the number of co-resident waves, sampled at wave starts
-    ev = []
-    for b in range(nblk):
-        for wv in range(4):
-            ev.append((int(cu[b, wv]), int(simd[b, wv]), int(t0[b, wv] - base), int(t_exit[b, wv] - base)))
-    by = {}
-    for c, s_, a, e in ev:
-        by.setdefault((c, s_), []).append((a, e))
-    tot, busy2, busy1 = 0, 0, 0
-    span = int(t_exit.max() - base)
-    for k, iv in by.items():
-        pts = sorted([(a, 1) for a, _ in iv] + [(e, -1) for _, e in iv])
-        cur, last = 0, 0
-        for x, d in pts:
-            if cur >= 2:
-                busy2 += x - last
-            elif cur == 1:
-                busy1 += x - last
-            cur += d
-            last = x
-        tot += span
-    print(f"SIMD-time with >= 2 waves resident {100 * busy2 / tot:.1f} %, exactly 1 wave {100 * busy1 / tot:.1f} %, idle {100 * (tot - busy1 - busy2) / tot:.1f} %  "
-          f"({len(by)} SIMDs seen)")
+    # residency per CU (cycle counters are only comparable inside one CU): span of the CU's work, and how many blocks overlap
+    spans, conc, gaps = [], [], []
+    for c in np.unique(cu):
+        m = cu == c
+        a0, e0 = t0[m].min(), t_exit[m].max()
+        spans.append(e0 - a0)
+        conc.append(life[m].sum() / 4.0 / max(e0 - a0, 1))         # average number of resident blocks
+        starts = np.sort(np.unique(t0[m] // 2000))                   # block starts (waves of a block start within ~2k cycles)
+    spans, conc = np.array(spans), np.array(conc)
+    print("per-CU busy span   ", q(spans))
+    print("avg resident blocks per CU  p10 %.2f  p50 %.2f  p90 %.2f" % tuple(np.percentile(conc, [10, 50, 90])))
+    nb = np.array([len(np.unique(np.nonzero(cu == c)[0])) for c in np.unique(cu)])
+    print("blocks per CU      ", q(nb))
+    for k in np.unique(nb):
+        print(f"   CUs with {k} blocks: {np.sum(nb == k)}, busy span p50 {np.percentile(spans[nb == k], 50):.0f} max {spans[nb == k].max()}")
     print("waves per CU (whole launch): ", q(np.bincount(np.unique(cu, return_inverse=True)[1].reshape(-1))))
 
 
