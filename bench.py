@@ -64,65 +64,57 @@ def parse():
 
 
 def kernel_timing(model, inputs, scale):
-    """One extra, instrumented forward: HIP events (on the launch stream = torch's current stream) around every
-    kernel class of the inner loop.  Returns {name: (launches, total_ms)}."""
-    from cer_mvs_amd import ops, update
-    records = {}
-    pending = []
-    originals = {}
+    """One extra, instrumented forward: HIP events (on the launch stream = torch's current stream) around EVERY launch the
+    library makes - encoders, cost volume, lookups, update-block convs (cer-mvs_amd/_lib.timing).  Launch plans are off for
+    this pass, so every iteration goes through the Python wrappers: it is slower than the timed region (stated in the JSON).
+    Returns ({class: (launches, total_ms)}, wall_ms of the pass)."""
+    from cer_mvs_amd import _lib as L, update
     plans = update.USE_PLANS
-    update.USE_PLANS = False             # every iteration through the (wrapped) ops, so that each launch gets its events
-
-    def wrap(name, fn, label=None):
-        def inner(*a, **k):
-            key = label(*a, **k) if label else name
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = fn(*a, **k)
-            e1.record()
-            pending.append((key, e0, e1))
-            return out
-        return inner
-
-    def conv_label(pc, srcs, h, w, epi, **k):
-        return {0: "conv3x3_linear", 1: f"conv3x3_relu_{pc.cout}", 2: "conv3x3_gates_zr", 3: "conv3x3_gru_q", 4: "conv3x3_delta_fused"}[epi]
-
-    for name in ("cost_build", "pyramid", "lookup_encode", "delta_tail", "delta_sum"):
-        originals[name] = getattr(ops, name)
-        setattr(ops, name, wrap(name, originals[name]))
-    originals["conv3x3"] = ops.conv3x3
-    ops.conv3x3 = wrap("conv3x3", originals["conv3x3"], conv_label)
-    originals["conv3x3_s16"] = ops.conv3x3_s16
-    ops.conv3x3_s16 = wrap("conv3x3_s16", originals["conv3x3_s16"], conv_label)
+    update.USE_PLANS = False
+    recs = []
     try:
-        with torch.no_grad():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad(), L.timing(recs):
             model(*inputs, scale=scale)
         torch.cuda.synchronize()
+        wall = 1e3 * (time.perf_counter() - t0)
     finally:
         update.USE_PLANS = plans
-        for name, fn in originals.items():
-            setattr(ops, name, fn)
+    epi_names = {0: "linear", 1: "relu", 2: "gates_zr", 3: "gru_q", 4: "delta_fused"}
     per = {}
-    for key, e0, e1 in pending:
+    nbuild = 0
+    for name, args, e0, e1 in recs:
+        key = name[4:] if name.startswith("cer_") else name
+        if name == "cer_conv3x3_s16":
+            key = "conv3x3_" + epi_names[args[15] & 0xFF] + (f"_{args[14]}" if (args[15] & 0xFF) == 1 else "")
+        elif name == "cer_conv3x3_f16x3":
+            key = "conv3x3_" + epi_names[args[12] & 0xFF] + (f"_{args[11]}" if (args[12] & 0xFF) == 1 else "")
+        elif name == "cer_conv3x3_f32":
+            key = "conv3x3_" + epi_names[args[11] & 0xFF] + (f"_{args[10]}" if (args[11] & 0xFF) == 1 else "")
+        elif name == "cer_cost_build_f32":
+            key = f"cost_build_stage{nbuild}"
+            nbuild += 1
+        elif name == "cer_enc_conv_f16x3":
+            key = f"enc_conv_{args[11]}to{args[12]}_taps{args[13]}_s{args[14]}"
         per.setdefault(key, []).append(e0.elapsed_time(e1))
-    # per class: launches and launches x MEDIAN launch time - a single stalled launch in this one instrumented pass
-    # (observed: one 20 ms outlier among 32 launches) must not move the reported per-launch duration; classes with two
-    # launches of different shapes (cost_build: the two cascade stages) keep their plain sum
+    out = {}
+    # per class: launches and launches x MEDIAN launch time (a single stalled launch in this one pass must not move the reported
+    # per-launch duration); classes with < 4 launches keep their plain sum
     for key, ts in per.items():
         ts_sorted = sorted(ts)
-        total = sum(ts) if len(ts) < 4 else ts_sorted[len(ts) // 2] * len(ts)
-        records[key] = (len(ts), total)
-    return records
+        out[key] = (len(ts), sum(ts) if len(ts) < 4 else ts_sorted[len(ts) // 2] * len(ts))
+    return out, wall
 
 
 def cpu_baseline(H, W, V, cascade, sd):
-    """Oracle (CPU port of the reference's torch op sequence) on a bounded sample, extrapolated to one depth map."""
+    """The oracle (oracle/cer_oracle.py: the reference's torch op sequence on CPU, fp32) on the bench workload itself - one
+    whole depth map, same images / weights, nothing extrapolated - on this box's host cores (thread count calibrated: torch's
+    CPU kernels stop scaling, and the 528 small grid_samples per lookup get slower, with hundreds of threads)."""
     from oracle import cer_oracle as O
     from cer_mvs_amd.synthetic import synthetic_scene
-    cores = os.cpu_count() or 1
-    # torch's CPU kernels stop scaling (and the 528 small grid_samples per lookup get much slower) with hundreds of
-    # threads: calibrate the thread count on one conv + one grid_sample and keep the fastest.
     import torch.nn.functional as F
+    cores = os.cpu_count() or 1
     cand = sorted({c for c in (8, 16, 32, 64, cores) if c <= cores})
     xcal = torch.randn(1, 64, H // 4, W // 4)
     wcal = torch.randn(64, 64, 3, 3)
@@ -141,47 +133,23 @@ def cpu_baseline(H, W, V, cascade, sd):
             best, best_t = c, dt
     threads = best
     torch.set_num_threads(threads)
-    h, w = H // 4, W // 4
-    P = h * w
-    images, poses, intr, _ = synthetic_scene(H, W, 1, seed=0)
-    imgs = images[0].float() * (2 / 255.0) - 1
-    intr_f = intr[0].clone()
-    intr_f[:, :2] /= 4
-    stages = O.resolve_cascade(cascade)
-    t = {}
+    runs = max(1, int(os.environ.get("CER_BENCH_CPU_RUNS", "1")))
+    images, poses, intr, scale = synthetic_scene(H, W, V, seed=0)
     with torch.no_grad():
-        O.encoder(imgs[0:1, :, :64, :64], sd, "fnet.", "instance")            # warm the thread pool
-        t0 = time.perf_counter()
-        fm = torch.cat([O.encoder(imgs[i:i + 1], sd, "fnet.", "instance") for i in range(2)], 0)
-        t["enc_per_image"] = (time.perf_counter() - t0) / 2
-        disp = torch.full((h, w), 0.0015)
-        t["build_per_view"] = []
-        for s, (D, incre, T) in enumerate(stages):
+        wi, wp, wk, ws = synthetic_scene(64, 96, 2, seed=1)              # warm-up: a tiny forward (thread pool, allocator)
+        O.raft_forward(sd, wi, wp, wk, ws, cascade=[(64, 64, 1), (-1, 320, 1)])
+        times = []
+        for _ in range(runs):
             t0 = time.perf_counter()
-            vol, origin = O.cost_volume(fm, poses[0], intr_f, D, incre, disp, shift=(s == 0))
-            levels = O.pyramid(vol, 3)
-            t["build_per_view"].append(time.perf_counter() - t0)
-        # one lookup (all V views: cost is value-independent, so tile the 1-view pyramid) + one update iteration
-        D, incre, _ = stages[-1]
-        lv = [l.expand(V, -1, -1).contiguous() for l in levels]
-        net = torch.zeros(1, 64, h, w)
-        inp = torch.zeros(1, 64, h, w)
-        d4 = disp.view(1, 1, h, w)
-        t0 = time.perf_counter()
-        feats = O.lookup(lv, origin, disp, D, incre, 5)
-        t["lookup_per_iter"] = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        O.update_block(sd, net, inp, d4, feats, 1)
-        t["update_per_iter"] = time.perf_counter() - t0
-    iters = sum(T for _, _, T in stages)
-    total = (V + 2) * t["enc_per_image"] + V * sum(t["build_per_view"]) + iters * (t["lookup_per_iter"] + t["update_per_iter"])
-    sample_s = 2 * t["enc_per_image"] + sum(t["build_per_view"]) + t["lookup_per_iter"] + t["update_per_iter"]
+            O.raft_forward(sd, images, poses, intr, scale, cascade=cascade)
+            times.append(time.perf_counter() - t0)
+    total = sorted(times)[len(times) // 2]
     return {
         "value": 1.0 / total, "unit": "depth-maps/s", "cores": threads, "host_cores": cores, "kind": "port",
-        "sample": (f"oracle/cer_oracle.py at {W}x{H}: 2 fnet passes, 1-view cost volume + pyramid for both stages, "
-                   f"1 lookup over {V} views + 1 update-block iteration ({sample_s:.1f} s measured); extrapolated to "
-                   f"{V + 2} encoder passes, {V} views x 2 stages, {iters} iterations = {total:.1f} s per depth map"),
-        "seconds_per_depth_map": total,
+        "sample": (f"oracle/cer_oracle.py, ONE WHOLE depth map of the bench workload ({W}x{H}, {V} source views, "
+                   f"{sum(c[2] for c in cascade)} GRU iterations): 1 tiny warm-up forward + {runs} timed run(s), median {total:.1f} s "
+                   f"(CER_BENCH_CPU_RUNS sets the number of runs)"),
+        "seconds_per_depth_map": total, "runs_s": times,
     }
 
 
@@ -252,61 +220,123 @@ def main():
     result = None
     rec = None
     if rank == 0 or shard:               # a sharded forward is collective: every rank runs the instrumented pass
-        rec = kernel_timing(model, inputs, scale)
+        rec, inst_wall_ms = kernel_timing(model, inputs, scale)
     if rank == 0:
-        P = (H // 4) * (W // 4)
+        h4, w4 = H // 4, W // 4
+        P = h4 * w4
         if shard and args.mode == "shard":
             # row-slab sharding: rank 0's kernels process its owned rows plus the halo, not the whole image - the per-launch
             # roofline figures below are per rank and must use that pixel count
             from cer_mvs_amd import slab as _slab
-            if _slab.can_shard(H // 4, world):
-                _, _, e0, e1 = _slab.slab_bounds(H // 4, world, 0)
-                P = (e1 - e0) * (W // 4)
-        kern = {k: {"launches": n, "avg_us": 1e3 * t / n, "total_ms": t} for k, (n, t) in sorted(rec.items())}
+            if _slab.can_shard(h4, world):
+                _, _, e0, e1 = _slab.slab_bounds(h4, world, 0)
+                P = (e1 - e0) * w4
+        Vloc = V if not (shard and args.mode == "views") else (V + world - 1) // world
+        C, L_, r_ = 64, 3, 5
+        stages = model.stages()
+        split = args.gru_precision in ("s16", "f16x3")
+        mfma_peak = F16_MFMA_PEAK_TFLOPS / 3 if split else FP32_MFMA_PEAK_TFLOPS
+        # ---- algorithmic work per launch, SURVEY.md 8(d) (fp32, view-mean folded):
+        #   build(s): bytes 4[P C (V+1) + P] + 4 P 1.75 D_s, flops 512 V P D_s;  lookup: 284 P bytes per iteration;
+        #   GRU convs: 2 * 9 * K * N * P flops with the hoisted `inp` slice and the collapsed encoder NOT credited (K = the
+        #   reference's channel counts: 64 + 49 + 64);  encoders: 71 GFLOP per image.
+        alg = {}
+        for si, (D, _, _) in enumerate(stages):
+            alg[f"cost_build_stage{si}"] = dict(bytes=4.0 * (P * C * (Vloc + 1) + P) + 4.0 * P * 1.75 * D, flops=512.0 * Vloc * P * D,
+                                                bound="hbm (gather-dot, ~100 FLOP/B: also shown against the fp32 vector peak)")
+        alg["lookup_encode_f32"] = dict(bytes=284.0 * P, bound="hbm",
+                                    note="8(d) bytes: 3 windows of 12 taps + origin + disp in, 33 floats out; the kernel writes the fused "
+                                         "1x1 conv's 64 floats instead (bytes_fused = 408 P)", bytes_fused=408.0 * P)
+        alg["conv3x3_gates_zr"] = dict(flops=2.0 * 9 * 177 * 128 * P, bound="mfma")
+        alg["conv3x3_gru_q"] = dict(flops=2.0 * 9 * 177 * 64 * P, bound="mfma")
+        alg["conv3x3_relu_64"] = dict(flops=2.0 * 9 * 64 * 64 * P, bound="mfma")
+        alg["conv3x3_delta_fused"] = dict(flops=2.0 * 9 * 64 * 256 * P + 2.0 * 9 * 256 * P, bound="mfma")
+        alg["conv3x3_linear"] = dict(flops=2.0 * 9 * 64 * 96 * P, bound="mfma", note="hoisted inp slice: z|r (128) and q (64) launches, mean")
+        kern = {}
+        for k, (n, t) in sorted(rec.items()):
+            e = {"launches": n, "avg_us": 1e3 * t / n, "total_ms": t}
+            if k in alg:
+                a_ = alg[k]
+                sec = t / n * 1e-3
+                if "bytes" in a_:
+                    e.update(alg_bytes=a_["bytes"], GBps=a_["bytes"] / sec / 1e9, frac_hbm=a_["bytes"] / sec / 1e9 / HBM_PEAK_GBS)
+                    if "bytes_fused" in a_:
+                        e.update(GBps_fused=a_["bytes_fused"] / sec / 1e9, frac_hbm_fused=a_["bytes_fused"] / sec / 1e9 / HBM_PEAK_GBS)
+                if "flops" in a_:
+                    pk = mfma_peak if a_["bound"] == "mfma" else FP32_MFMA_PEAK_TFLOPS
+                    e.update(alg_flops=a_["flops"], TFLOPs=a_["flops"] / sec / 1e12, frac_flops=a_["flops"] / sec / 1e12 / pk, flops_peak=pk)
+                e["bound"] = a_["bound"]
+                if "note" in a_:
+                    e["note"] = a_["note"]
+            kern[k] = e
+        enc = [(k, v) for k, v in rec.items() if k.startswith("enc_")]
+        enc_ms = sum(t for _, (_, t) in enc)
+        if enc_ms > 0:
+            nimg = (Vloc + 1) + 1                              # fnet on the reference + source views, cnet on the reference
+            enc_flops = 71.0e9 * nimg
+            kern["encoders_total"] = {"launches": sum(n for _, (n, _) in enc), "total_ms": enc_ms, "alg_flops": enc_flops,
+                                      "TFLOPs": enc_flops / (enc_ms * 1e-3) / 1e12, "frac_flops": enc_flops / (enc_ms * 1e-3) / 1e12 / mfma_peak,
+                                      "flops_peak": mfma_peak, "bound": "mfma",
+                                      "note": f"{nimg} encoder passes x 71 GFLOP (SURVEY.md 8(a) row 2).  The encoder launches are short and "
+                                              "host-paced in this instrumented pass, so their event times include launch gaps: kernel "
+                                              "durations are in the rocprofv3 summary under profiles/ (6.2 ms per depth map)"}
         n_zr, t_zr = rec["conv3x3_gates_zr"]
-        flops_zr = 2.0 * 9 * (64 + 49 + 64) * 128 * P            # algorithmic (unpadded K = net|disp49|corr), DESIGN.md
+        flops_zr = alg["conv3x3_gates_zr"]["flops"]
         achieved = flops_zr / (t_zr / n_zr * 1e-3) / 1e12
-        if args.gru_precision in ("s16", "f16x3"):
-            # every fp32 product costs 3 f16 MFMA products -> ceiling = f16 dense peak / 3 in fp32-equivalent flops
-            peak, kname = F16_MFMA_PEAK_TFLOPS / 3, "conv3x3_f16x3_kernel<4,2,1,2,3,4,GATES> (z|r gates, 3x3, K=177, N=128; 3 f16 MFMAs per fp32 product)"
+        if args.gru_precision == "s16":
+            kname = "conv3x3_s16_kernel<1,4,4,GATES> (z|r gates, 3x3, K=177, N=128; 3 f16 MFMAs per fp32 product, one accumulator)"
+        elif args.gru_precision == "f16x3":
+            kname = "conv3x3_f16x3_kernel<4,2,1,2,3,4,GATES> (z|r gates, 3x3, K=177, N=128; 3 f16 MFMAs per fp32 product)"
         else:
-            peak, kname = FP32_MFMA_PEAK_TFLOPS, "conv3x3_kernel<2,2,4,4,GATES> (z|r gates, 3x3, K=177, N=128; exact fp32 MFMA)"
-        traffic = None                                            # HBM bytes per launch from the committed PMC passes
-        try:
-            with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f)["conv3x3_gates_zr"]["traffic_bytes"] if args.gru_precision in ("s16", "f16x3") else None
-        except Exception:
-            traffic = None
-        roofline = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                    "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2x FETCH correction)", "avg_launch_us": 1e3 * t_zr / n_zr, "launches": n_zr, "flops_per_launch": flops_zr,
-                    "peak_note": ("fp32-equivalent ceiling = 2500 TF dense f16 MFMA / 3" if args.gru_precision in ("s16", "f16x3")
-                                  else "fp32 MFMA dense peak"),
-                    "frac_of_raw_f16_peak": (3 * achieved / F16_MFMA_PEAK_TFLOPS) if args.gru_precision in ("s16", "f16x3") else None}
+            kname = "conv3x3_kernel<2,2,4,4,GATES> (z|r gates, 3x3, K=177, N=128; exact fp32 MFMA)"
+        traffic, traffic_src = None, None                        # HBM bytes per launch from the committed PMC passes
+        for cand in ("r02_pmc_traffic.json",):
+            try:
+                with open(os.path.join(REPO, "profiles", cand)) as f:
+                    traffic = json.load(f)["conv3x3_gates_zr"]["traffic_bytes"] if args.gru_precision == "s16" else None
+                traffic_src = f"profiles/{cand} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2x FETCH correction)"
+            except Exception:
+                pass
+        roofline = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": mfma_peak, "unit": "TFLOP/s", "frac": achieved / mfma_peak,
+                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": 1e3 * t_zr / n_zr, "launches": n_zr,
+                    "flops_per_launch": flops_zr,
+                    "peak_note": ("fp32-equivalent ceiling = 2500 TF dense f16 MFMA / 3" if split else "fp32 MFMA dense peak"),
+                    "frac_of_raw_f16_peak": (3 * achieved / F16_MFMA_PEAK_TFLOPS) if split else None}
         hbm = None
-        if "lookup_encode" in rec:
-            n_lk, t_lk = rec["lookup_encode"]
-            D0 = cascade[0][0]
-            rowf = (D0 + D0 // 2 + D0 // 4 + 3) // 4 * 4
-            bytes_lk = 4.0 * P * (rowf + 2 + 64)                  # stage-0 row + origin + disp read, 64 floats written
-            gbs = bytes_lk / (t_lk / n_lk * 1e-3) / 1e9
-            hbm = {"kernel": "lookup_encode_kernel (multi-level lookup + view mean + 1x1 conv)", "bound": "hbm", "achieved": gbs,
-                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "avg_launch_us": 1e3 * t_lk / n_lk,
-                   "bytes_per_launch": bytes_lk, "note": "stage-0 row length used for all launches (stage-1 rows are 80 floats)"}
+        if "lookup_encode_f32" in kern:
+            lk = kern["lookup_encode_f32"]
+            hbm = {"kernel": "lookup_encode_kernel (multi-level lookup + view mean + 1x1 conv)", "bound": "hbm", "achieved": lk["GBps"],
+                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lk["frac_hbm"], "avg_launch_us": lk["avg_us"],
+                   "bytes_per_launch": lk["alg_bytes"], "bytes_formula": "SURVEY.md 8(d): 284 * P per iteration",
+                   "frac_with_fused_output_bytes": lk["frac_hbm_fused"], "bytes_fused_output": 408.0 * P}
+        loop_keys = ("lookup_encode_f32", "conv3x3_relu_64", "conv3x3_gates_zr", "conv3x3_gru_q", "conv3x3_delta_fused", "delta_sum_f32")
+        loop_ms = sum(rec[k][1] for k in loop_keys if k in rec)
+        iters = sum(c[2] for c in cascade)
+        inner = {"ms_per_depth_map": loop_ms, "us_per_iteration": 1e3 * loop_ms / iters,
+                 "alg_bytes_per_iteration": (284.0 + 908.0) * P, "alg_flops_per_iteration": 1210368.0 * P,
+                 "frac_hbm": (284.0 + 908.0) * P * iters / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "frac_mfma": 1210368.0 * P * iters / (loop_ms * 1e-3) / 1e12 / mfma_peak,
+                 "note": "correlation + GRU inner loop against both rooflines with SURVEY.md 8(d)'s unreduced per-iteration figures "
+                         "(1.21 MFLOP and 1192 B per pixel): the loop is MFMA-bound, not HBM-bound (SURVEY.md 7, hard part 1)"}
         result = {
             "metric": "depth-maps/sec (ref+N src views) at DTU 1600x1184; HBM GB/s vs roofline",
             "value": maps / elapsed, "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong" if (shard or world == 1) else "weak", "vs_baseline": None,
             "dtype": ("f32" if args.precision == "fp32" else "f32 (encoders f16 autocast)")
-                     + (" [GRU convs: f32 operands split into 2 x f16, 3 MFMAs per product, f32 accumulate - fp32-equivalent]"
-                        if args.gru_precision == "f16x3" else ""), "data": "synthetic",
+                     + (" [dense convs: f32 operands split into 2 x f16, 3 MFMAs per product, f32 accumulate - fp32-class]" if split else ""),
+            "data": "synthetic",
             "config": {"workload": args.workload, "image": f"{W}x{H}", "src_views": V, "cascade": cascade,
                        "gru_iters": sum(c[2] for c in cascade),
                        "parallelism": "single" if world == 1 else (
                            (f"row-slab x{world}: feature all-gather + 7-row halo all-gather per GRU iteration" if args.mode == "shard"
                             else f"view-shard x{world} + all-reduce/stage") if shard else f"replica x{world}"),
                        **({"backend": "gloo (validation run, ranks may share a GPU)"} if (world > 1 and args.backend == "gloo") else {})},
-            "roofline": roofline, "roofline_hbm_kernel": hbm, "kernels": kern,
+            "roofline": roofline, "roofline_hbm_kernel": hbm, "inner_loop": inner, "kernels": kern,
+            "instrumented_pass": {"wall_ms": inst_wall_ms, "sum_of_kernels_ms": sum(t for _, t in rec.values()),
+                                  "note": "one extra forward after the timed region with HIP events around every library launch and "
+                                          "launch plans disabled; its per-launch times feed `kernels` / `roofline`, its wall time is "
+                                          "NOT ms_per_step"},
             "peak_device_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
         }
         # parity of THIS run's output: the default workload with the default seeds is exactly the configuration the reference

@@ -142,6 +142,49 @@ class recording:
         return False
 
 
+class _Timing:
+    """Wraps the library so that every stream-taking call (the last argument of every launching entry point) is bracketed by
+    HIP events recorded on that stream - bench.py's instrumented pass.  ``records``: list of (name, args, e0, e1)."""
+
+    def __init__(self, lib, records):
+        self._lib, self._records = lib, records
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        sig = _SIGNATURES.get(name)
+        if sig is None or not sig[1] or sig[1][-1] is not _P or name.endswith("_pack"):
+            return fn
+        records = self._records
+
+        def call(*args):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            records.append((name, args, e0, e1))
+            return rc
+        return call
+
+
+class timing:
+    """``with timing(records): ...`` - every launching library call inside the block is timed with HIP events."""
+
+    def __init__(self, records):
+        self.records = records
+
+    def __enter__(self):
+        global _recorder
+        if _recorder is not None:
+            raise RuntimeError("cer-mvs_amd: timing inside a launch recording")
+        _recorder = _Timing(load(), self.records)
+        return self.records
+
+    def __exit__(self, *exc):
+        global _recorder
+        _recorder = None
+        return False
+
+
 def exported_symbols():
     """Names every build of the library must export (mirrors include/cer_mvs.h)."""
     return sorted(_SIGNATURES)
