@@ -84,6 +84,10 @@ int cer_cost_build_f32(const float* fmap1, const float* fmap2, const float* Pij,
                        float* vol, float* origin_out,
                        int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride,
                        double incre, int shift, int mode, int y0, int fuse_levels, float fuse_scale, void* stream);
+/* Implementation choice of the fold modes (1, 2) of cer_cost_build_f32: 0 / 1 = the wave-per-pixel walk (default), 2 = the
+ * round-2 experiment "band GEMM + 4-tap gather" (csrc/cost_gemm.hip) wherever it applies (C == 64): same results, tested against
+ * the walk, not faster yet.  Returns the previous setting. */
+int cer_cost_build_algo(int algo);
 
 /* Correlation pyramid (reference: core/corr.py:94-97, F.avg_pool2d([1,2]) x (L-1)), in place on
  * rows laid out [level0 (D) | level1 (D/2) | level2 (D/4) | ... | pad]: first level0 *= scale

@@ -241,6 +241,58 @@ def test_conv3x3_disp_encoder_source(dev):
         assert rel_l1(out.cpu(), ref) < 2e-6, mode
 
 
+@pytest.mark.parametrize("geom", ["horizontal", "diagonal", "vertical", "wild"])
+@pytest.mark.parametrize("D,stage0", [(64, True), (44, False), (20, False)])
+def test_cost_build_band_gemm_matches_walk(dev, D, stage0, geom):
+    """The round-2 fold kernel (band GEMM + 4-tap gather, csrc/cost_gemm.hip) against the round-1 wave-per-pixel walk on the
+    same inputs: epipolar lines of every direction, a view whose projection blows up (Z crosses 0 inside the hypothesis range:
+    the bounding box never fits and the direct per-sample path runs), odd image sizes (partial tiles), a row-slab offset,
+    accumulate mode and the fused pyramid."""
+    from cer_mvs_amd import _lib as L, ops
+    from cer_mvs_amd.corr import fmaps_to_nhwc
+    h1, w1, V, C = 19, 45, 3, 64
+    fm = hashed((1, V + 1, C, h1, w1), 311, -2, 2).to(dev)
+    f1 = fmaps_to_nhwc(fm[0, 0:1])[0]
+    f2 = fmaps_to_nhwc(fm[0, 1:], border=2)
+    Pij = torch.eye(4).repeat(V, 1, 1)
+    for v in range(V):
+        if geom == "horizontal":
+            Pij[v, 0, 3] = (900.0 if stage0 else 9000.0) * (v + 1)
+        elif geom == "vertical":
+            Pij[v, 1, 3] = -(700.0 if stage0 else 7000.0) * (v + 1)
+        elif geom == "diagonal":
+            Pij[v, 0, 3], Pij[v, 1, 3] = 600.0 * (v + 1), -500.0 * (v + 1)
+            Pij[v, 0, 1] = 0.05 * v
+        else:   # wild: Z = 1 + m[11] * hyp crosses zero inside the range; one view entirely behind the camera
+            Pij[v, 0, 3], Pij[v, 2, 3] = 4000.0, (-700.0, -1500.0, 0.0)[v]
+            if v == 2:
+                Pij[v, 2, 2] = -1.0
+    Pij = Pij.to(dev)
+    d0 = hashed((h1 * w1,), 312, 0.0005, 0.002).to(dev) if not stage0 else torch.zeros(h1 * w1, device=dev)
+    incre = 0.0025 / (64 if stage0 else 320)
+    lib = L.load()
+    res = {}
+    for algo in (1, 2):
+        prev = lib.cer_cost_build_algo(algo)
+        try:
+            a, oa = ops.cost_build(f1, f2, Pij, d0, D, incre, stage0, h1, w1, 3, fold=True)
+            b, ob = ops.cost_build(f1, f2, Pij, d0, D, incre, stage0, h1, w1, 3, fold=True, pyramid_scale=1.0 / V if D <= 64 else None)
+            c, _ = ops.cost_build(f1, f2, Pij, d0, D, incre, stage0, h1, w1, 3, fold=True, vol=a.clone(), accumulate=True)
+            s_, _ = ops.cost_build(f1[5 * w1:], f2, Pij, d0[5 * w1:], D, incre, stage0, h1 - 5, w1, 3, fold=True, src_hw=(h1, w1), y0=5)
+            res[algo] = (a, oa, b, ob, c, s_)
+        finally:
+            lib.cer_cost_build_algo(prev)
+    ref, new = res[1], res[2]
+    n = D + D // 2 + D // 4
+    assert torch.equal(ref[1], new[1]) and torch.equal(ref[3], new[3])                    # origins
+    mag = ref[0][:, :D].abs().max().clamp_min(1e-6)
+    for i, cols in ((0, D), (2, n), (4, D), (5, D)):
+        err = (ref[i][:, :cols] - new[i][:, :cols]).abs().max()
+        assert err <= 2e-6 * max(float(mag), 1.0) * (2 if i == 4 else 1), (i, float(err), float(mag))
+    assert torch.equal(new[5], new[0][5 * w1:])                                              # the slab sees the same samples
+    assert new[0][:, :D].abs().sum() > 0
+
+
 @pytest.mark.parametrize("D", [64, 44, 20])
 def test_cost_build_fused_pyramid_equals_two_pass(dev, D):
     """cer_cost_build_f32 with fuse_levels: level 0 * 1/V and the avg-pooled levels written by the build's epilogue are
