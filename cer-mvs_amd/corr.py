@@ -91,16 +91,6 @@ class CorrBlock:
         out = ops.corr_lookup(self.volume, self.origin, z, self.nIncre, self.incre, self.num_levels, self.radius, per_view_disp=True)
         return out.view(1, num, -1, h1, w1)
 
-    @staticmethod
-    def corr(fmaps, ii, jj):
-        """All-pairs correlation (dead code in the reference, core/corr.py:148-158); kept for API parity."""
-        fmap1 = fmaps[:, ii]
-        fmap2 = fmaps[:, jj]
-        batch, num, dim, ht, wd = fmap1.shape
-        fmap1 = fmap1.reshape(batch * num, dim, ht * wd) / 8.0
-        fmap2 = fmap2.reshape(batch * num, dim, ht * wd) / 8.0
-        return torch.matmul(fmap1.transpose(1, 2), fmap2).view(batch, num, ht, wd, 1, ht, wd)
-
 
 def report():
     """Peak-memory print (reference: utils/memory.py:5-11 shells out to nvidia-smi)."""

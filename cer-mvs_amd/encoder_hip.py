@@ -77,8 +77,9 @@ class HipEncoder:
         return out
 
     # ---- trunk: images -> last residual activation (channels-last) + geometry
-    def trunk(self, x):
-        """x [N,3,H,W] float32 (already normalised to [-1,1]) -> (a [N, h*w, 64], h, w)."""
+    def trunk(self, x, raw=False):
+        """x [N,3,H,W] float32, normalised to [-1,1] - or, with ``raw``, 0..255 pixel values that the stem kernel normalises while
+        it loads them (x * 2/255 - 1, core/raft.py:40-41: no separate pass over the image stack) -> (a [N, h*w, 64], h, w)."""
         lib = L.load()
         N, _, H, W = x.shape
         x = x.contiguous()
@@ -88,7 +89,7 @@ class HipEncoder:
         if self.inorm:
             part = torch.empty(N, lib.cer_enc_stem_tiles(ho, wo), 32, 2, device=self.device, dtype=torch.float32)
         L.check(lib.cer_enc_stem_f32(L.dev_ptr(x, "images"), L.dev_ptr(self.stem_w, "w"), L.dev_ptr(self.stem_b, "b"), L.dev_ptr(raw0, "out"),
-                                     L.dev_ptr(part, "part"), N, H, W, 0, L.cur_stream()), "enc_stem")
+                                     L.dev_ptr(part, "part"), N, H, W, int(bool(raw)), L.cur_stream()), "enc_stem")
         st0 = self._stats(part, N, part.shape[1], 32, ho * wo) if part is not None else None
         # `cur` = (tensor, stats, relu): the block input is relu(norm(tensor)) when stats/relu are set, else the tensor itself
         cur, cur_st, cur_relu, h, w, C = raw0, st0, True, ho, wo, 32
@@ -103,10 +104,10 @@ class HipEncoder:
             cur, cur_st, cur_relu, h, w, C = nxt, None, False, h1, w1, c2.cout
         return cur, h, w
 
-    def features(self, x, n_ref=1, border=2, scale=0.125, src_out=None):
+    def features(self, x, n_ref=1, border=2, scale=0.125, src_out=None, raw=False):
         """fnet head: (ref [n_ref*h*w... ] plain, src bordered).  x [N,3,H,W]; the first ``n_ref`` images go to a plain
         [n_ref, h*w, C] map, the rest to a [N-n_ref, (h+2b)*(w+2b), C] map with a zero border; both scaled."""
-        a, h, w = self.trunk(x)
+        a, h, w = self.trunk(x, raw)
         N, C = x.shape[0], self.head.cout
         ref = torch.empty(n_ref, h * w, C, device=self.device, dtype=torch.float32)
         self._conv(self.head, a[:n_ref], n_ref, h, w, None, False, epi=1, out=ref, border=0, scale=scale)
@@ -117,9 +118,9 @@ class HipEncoder:
             self._conv(self.head, a[n_ref:], N - n_ref, h, w, None, False, epi=1, out=src, border=border, scale=scale)
         return ref, src, h, w
 
-    def context(self, x):
+    def context(self, x, raw=False):
         """cnet head: x [1,3,H,W] -> (net = tanh(first half) [P,64], inp = relu(second half) [P,64])."""
-        a, h, w = self.trunk(x)
+        a, h, w = self.trunk(x, raw)
         half = self.head.cout // 2
         net = torch.empty(h * w, half, device=self.device, dtype=torch.float32)
         inp = torch.empty(h * w, half, device=self.device, dtype=torch.float32)

@@ -36,7 +36,8 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, 1, stride=stride), self.norm3)
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.float32 and self.kind in ("instance", "none"):
+        # (the fused kernels have no autograd and overwrite the conv output in place: inference only)
+        if x.is_cuda and x.dtype == torch.float32 and self.kind in ("instance", "none") and not torch.is_grad_enabled():
             return self._forward_fused(x)
         y = F.relu(self.norm1(self.conv1(x)))
         y = F.relu(self.norm2(self.conv2(y)))
@@ -84,7 +85,7 @@ class BasicEncoder(nn.Module):
     def forward(self, x):
         lead = x.shape[:-3]
         x = x.reshape((-1,) + tuple(x.shape[-3:]))
-        if x.is_cuda and x.dtype == torch.float32 and self.norm_fn in ("instance", "none"):
+        if x.is_cuda and x.dtype == torch.float32 and self.norm_fn in ("instance", "none") and not torch.is_grad_enabled():
             from . import ops
             x = self.conv1(x).contiguous()
             x = ops.norm_act(x, ops.plane_stats(x) if self.norm_fn == "instance" else None, relu_a=True, out=x)

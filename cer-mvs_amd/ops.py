@@ -30,10 +30,38 @@ def alt_corr_forward(fmap1, fmap2, coords, radius):
     return corr
 
 
-def alt_corr_backward(fmap1, fmap2, coords, corr_grad, radius):
+DETERMINISTIC_BACKWARD = True      # fmap2 gradient by a sorted segmented reduction (False: float atomics, like the reference)
+
+
+def alt_corr_backward(fmap1, fmap2, coords, corr_grad, radius, deterministic=None):
+    """-> (fmap1_grad, fmap2_grad, coords_grad = 0) (correlation.cpp:36-48).  ``deterministic`` (default
+    ``DETERMINISTIC_BACKWARD``): fmap2_grad without atomics - tuples kernel, stable sort of the texel keys (torch), segmented
+    reduction kernel: bit-identical from run to run."""
     B, H1, W1, C = fmap1.shape
     _, H2, W2, _ = fmap2.shape
     N = coords.shape[1]
+    if DETERMINISTIC_BACKWARD if deterministic is None else deterministic:
+        lib, dev = L.load(), fmap1.device
+        g1 = torch.empty_like(fmap1)
+        gc = torch.zeros_like(coords)
+        L.check(lib.cer_alt_corr_backward_f32(L.dev_ptr(fmap1, "fmap1"), L.dev_ptr(fmap2, "fmap2"), L.dev_ptr(coords, "coords"),
+                                              L.dev_ptr(corr_grad, "corr_grad"), L.dev_ptr(g1, "g1"), None, None, B, N, H1, W1, H2, W2, C,
+                                              radius, L.cur_stream()), "alt_corr_backward[f1]")
+        n = B * N * H1 * W1 * (2 * radius + 2) ** 2
+        keys = torch.empty(n, device=dev, dtype=torch.int64)
+        coef = torch.empty(n, device=dev, dtype=torch.float32)
+        src = torch.empty(n, device=dev, dtype=torch.int32)
+        L.check(lib.cer_alt_corr_bwd_tuples_f32(L.dev_ptr(coords, "coords"), L.dev_ptr(corr_grad, "corr_grad"), L.dev_ptr(keys, "keys", torch.int64),
+                                                L.dev_ptr(coef, "coef"), L.dev_ptr(src, "src", torch.int32), B, N, H1, W1, H2, W2, radius,
+                                                L.cur_stream()), "alt_corr_bwd_tuples")
+        skeys, order = torch.sort(keys, stable=True)
+        T = B * H2 * W2
+        seg = torch.searchsorted(skeys, torch.arange(T + 1, device=dev, dtype=torch.int64)).contiguous()
+        g2 = torch.empty_like(fmap2)
+        L.check(lib.cer_alt_corr_bwd_reduce_f32(L.dev_ptr(fmap1, "fmap1"), L.dev_ptr(order.contiguous(), "order", torch.int64), L.dev_ptr(coef, "coef"),
+                                                L.dev_ptr(src, "src", torch.int32), L.dev_ptr(seg, "seg", torch.int64), L.dev_ptr(g2, "g2"), T, C,
+                                                L.cur_stream()), "alt_corr_bwd_reduce")
+        return g1, g2, gc
     g1 = torch.empty_like(fmap1)
     g2 = torch.empty_like(fmap2)
     gc = torch.empty_like(coords)
@@ -58,7 +86,15 @@ def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, 
     _, _, rs = row_layout(D, num_levels)
     if vol is None:
         shape = (P, rs) if fold else (V, P, rs)
-        vol = torch.zeros(shape, device=fmap1.device, dtype=torch.float32)
+        if pyramid_scale is not None:
+            # fused pyramid (the forward's hot path): the kernel writes every level of every row - no 50 MB zero fill; only the
+            # alignment pad of a row (rs - used, <= 3 floats) is cleared
+            vol = torch.empty(shape, device=fmap1.device, dtype=torch.float32)
+            offs, lens, _ = row_layout(D, num_levels)
+            if offs[-1] + lens[-1] < rs:
+                vol[..., offs[-1] + lens[-1]:] = 0
+        else:
+            vol = torch.zeros(shape, device=fmap1.device, dtype=torch.float32)     # pooled levels stay 0 until ``pyramid`` runs
     origin = torch.empty(P, device=fmap1.device, dtype=torch.float32)
     mode = (2 if accumulate else 1) if fold else 0
     fuse = pyramid_scale is not None

@@ -47,6 +47,18 @@ class RAFT(nn.Module):
         self._engines = None
         self._src_buf = {}
         self.last_timings = None
+        # packed encoder weights are a cache of the parameters: drop them whenever parameters are (re)loaded - through this
+        # module, a wrapper (nn.DataParallel(model).load_state_dict, as the reference's inference.py does) or a submodule
+        for m in (self, self.fnet, self.cnet):
+            m.register_load_state_dict_post_hook(lambda module, incompatible, me=self: me._drop_engines())
+
+    def _drop_engines(self):
+        self._engines = None
+
+    def refresh_weights(self):
+        """Call after mutating parameters in place: drops every packed copy (encoder engines, update-block packs)."""
+        self._engines = None
+        self.update_block.refresh_weights()
 
     def stages(self):
         """(D, incre, T) per cascade stage (reference: core/raft.py:76-81)."""
@@ -69,29 +81,33 @@ class RAFT(nn.Module):
         self._engines = None
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
-    def encode(self, images, views):
-        """images [1,N,3,H,W] in [-1,1]; ``views`` = source-view indices this rank owns
-        -> (net [P,64], inp [P,64], reference features [P,C], source features [len(views),(h+4)*(w+4),C]);
+    def encode(self, images, views, raw=False):
+        """images [1,N,3,H,W] in [-1,1] (``raw``: 0..255, normalised on the fly, core/raft.py:40-41); ``views`` = source-view
+        indices this rank owns -> (net [P,64], inp [P,64], reference features [P,C], source features [len(views),(h+4)*(w+4),C]);
         features are channels-last, scaled by 1/8, source maps with a 2-texel zero border."""
         idx = [0] + list(views)
+        stack = images[0] if idx == list(range(images.shape[1])) else images[0, idx]      # (no gather copy when every view is local)
         if self.encoder_backend == "hip" and self.precision == "fp32" and self.encoder_type == "HR":
             from .encoder_hip import HipEncoder
             dev = images.device
             if self._engines is None or self._engines[0] != dev:
                 self._engines = (dev, HipEncoder(self.fnet, dev), HipEncoder(self.cnet, dev))
             _, eng_f, eng_c = self._engines
-            net, inp, h, w = eng_c.context(images[0, :1])
+            net, inp, h, w = eng_c.context(images[0, :1], raw=raw)
             key = (len(views), h, w, str(dev))
             buf = self._src_buf.get(key)
             if views and buf is None:      # border texels are written once (zeros) and never touched again
                 buf = torch.zeros(len(views), (h + 4) * (w + 4), self.dim_fmap, device=dev, dtype=torch.float32)
                 self._src_buf = {key: buf}
-            ref, src, _, _ = eng_f.features(images[0, idx], n_ref=1, border=2, scale=0.125, src_out=buf if views else None)
+            ref, src, _, _ = eng_f.features(stack, n_ref=1, border=2, scale=0.125, src_out=buf if views else None, raw=raw)
             return net, inp, ref[0], src
+        if raw:
+            images = images.float() * (2 / 255.0) - 1
+            stack = images[0] if idx == list(range(images.shape[1])) else images[0, idx]
         amp = self.precision == "amp"
         with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
             ctx = self.cnet(images[:, [0]])[0, 0].float()                       # [128,h,w]
-            fm = self.fnet(images[0, idx]).float()                             # [n,C,h,w] (instance norm is per image)
+            fm = self.fnet(stack).float()                                      # [n,C,h,w] (instance norm is per image)
         net = torch.tanh(ctx[: self.dim_net])
         inp = torch.relu(ctx[self.dim_net:])
         f2 = fmaps_to_nhwc(fm[1:], border=2) if views else None
@@ -102,7 +118,9 @@ class RAFT(nn.Module):
         if not images.is_cuda:
             raise RuntimeError("RAFT.forward: images must be a CUDA tensor (there is no CPU path)")
         if not self.test_mode:
-            raise NotImplementedError("RAFT.forward: only test_mode=True (inference) is built; training is SURVEY.md §8(f) 'next'")
+            # training mode: the list of per-iteration predictions (core/raft.py:103,109), differentiable (train.py)
+            from .train import forward_train
+            return forward_train(self, images, poses, intrinsics, scale)
         if "mean" not in self.update_block.aggregation or len(self.update_block.aggregation) != 1:
             return self._forward_literal(images, poses, intrinsics, scale, do_report)
         dev = images.device
@@ -122,7 +140,10 @@ class RAFT(nn.Module):
         factor = 8 if self.encoder_type == "LR" else 4
         intrinsics = intrinsics.clone().float()
         intrinsics[:, :, :2] /= factor
-        images = images.float() * (2 / 255.0) - 1
+        if ht % factor or wd % factor:
+            raise RuntimeError(f"RAFT.forward: image size {wd}x{ht} must be a multiple of {factor} (the cost volume lives at 1/{factor} "
+                               "resolution; the reference crops / rescales to such sizes, utils/data_utils.py:58-78)")
+        images = images.float()                           # (normalised to [-1,1] inside the encoders' stem kernel)
         h, w = ht // factor, wd // factor
         P = h * w
         ub = self.update_block
@@ -133,14 +154,15 @@ class RAFT(nn.Module):
         # (uploaded BEFORE the encoders are enqueued: a pageable H2D copy is stream-ordered and would block the host
         # until everything enqueued so far has finished)
         Pij = pij_matrices(poses[0], intrinsics[0], [0] * len(views), views).to(dev) if views else None
-        net_l, inp_l, f1, f2 = self.encode(images, views)
+        net_l, inp_l, f1, f2 = self.encode(images, views, raw=True)
         net_l = ub.prepare_net(net_l, h, w)
         del images
 
         disp = torch.zeros(P, device=dev, dtype=torch.float32)
-        hoisted = ub.hoist(inp_l, h, w)
+        hoisted_all = ub.hoist_all(inp_l, h, w, len(self.cascade))
         ws = ub.workspace(h, w, dev)
         for stage, (D, incre, T) in enumerate(self.stages()):
+            hoisted = hoisted_all[stage]
             single = self.view_group is None   # no cross-rank sum between the build and the pooling: fuse them
             if views:
                 vol, origin = ops.cost_build(f1, f2, Pij, disp, D, incre, stage == 0, h, w, ub.num_levels, fold=True,

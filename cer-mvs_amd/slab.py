@@ -158,7 +158,9 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
     intr = intrinsics.clone().float()
     intr[:, :, :2] /= factor
     _, num, _, ht, wd = images.shape
-    images = images.float() * (2 / 255.0) - 1
+    if ht % factor or wd % factor:
+        raise RuntimeError(f"sharded_forward: image size {wd}x{ht} must be a multiple of {factor}")
+    images = images.float()                               # (normalised inside the encoders' stem kernel)
     h, w = ht // factor, wd // factor
     V = num - 1
     ub = model.update_block
@@ -174,7 +176,7 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
     send = []
     for g in ex.ranks:
         views = local_views_for(V, G, g)
-        net_l, inp_l, f1, f2 = model.encode(images, views)
+        net_l, inp_l, f1, f2 = model.encode(images, views, raw=True)
         st[g] = dict(net=net_l, inp=inp_l, f1=f1)
         pad = torch.zeros(vmax, Pb, C, device=dev, dtype=torch.float32)
         if views:
@@ -198,7 +200,7 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
         d["inp"] = d["inp"][e0 * w:e1 * w].contiguous()
         d["f1s"] = d["f1"][e0 * w:e1 * w].contiguous()
         d["disp"] = torch.zeros((e1 - e0) * w, device=dev, dtype=torch.float32)
-        d["hoist"] = ub.hoist(d["inp"], e1 - e0, w)
+        d["hoist"] = ub.hoist_all(d["inp"], e1 - e0, w, len(model.cascade))
         d["ws"] = ub.workspace(e1 - e0, w, dev)
         d["strips"] = torch.empty(2 * HALO * w * (d["net"].shape[1] + 1), device=dev, dtype=torch.float32)
         # s16 path: the hidden state lives in the m-tile-major frag16 layout - image rows move through cer_s16_rows_f32
@@ -222,7 +224,7 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
                     # iteration + pack of the 2 x HALO border rows of (net, disp): recorded once per stage, then replayed
                     d["plan_step"] = L.LaunchPlan(keep=(d["vol"], d["origin"]))
                     with L.recording(d["plan_step"]):
-                        ub.step(d["vol"], d["origin"], d["net"], d["disp"], d["hoist"], stage, d["hs"], w, D, incre, d["ws"])
+                        ub.step(d["vol"], d["origin"], d["net"], d["disp"], d["hoist"][stage], stage, d["hs"], w, D, incre, d["ws"])
                         pack_strips(d["net"], d["disp"], d["strips"], w, d["r0"], d["r1"], d["e0"], rows=d["rows"])
                 else:
                     d["plan_step"].replay()

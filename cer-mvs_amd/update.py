@@ -70,6 +70,7 @@ class _Strided:
 
     def __init__(self, pc, sources):
         self.packed, self.packed_x, self.bias, self.cout, self.sources = pc.packed, pc.packed_x, pc.bias, pc.cout, sources
+        self.packed_c = None              # (no kind-1 disparity source in the literal ConvGRU: nothing to collapse)
 
 
 def _with_stride(pc, sources):
@@ -177,6 +178,13 @@ class UpdateBlock(nn.Module):
             inp_s = ops.to_frag16(inp_l, h, w, L.S16_RELU)
             return (ops.conv3x3_s16(p["s_zr_inp"], [inp_s], h, w, L.EPI_LINEAR), ops.conv3x3_s16(p["s_q_inp"], [inp_s], h, w, L.EPI_LINEAR))
         return (ops.conv3x3(p["zr_inp"], [inp_l], h, w, L.EPI_LINEAR, mode=self.conv_mode), ops.conv3x3(p["q_inp"], [inp_l], h, w, L.EPI_LINEAR, mode=self.conv_mode))
+
+    def hoist_all(self, inp_l, h, w, n_stages):
+        """``hoist`` for every cascade stage: one result shared by all stages when the GRU weights are shared (the reference's
+        default, core/update.py:47), one per stage otherwise (gru{stage} has its own `inp` weights and biases)."""
+        if self.share_gru:
+            return [self.hoist(inp_l, h, w, 0)] * n_stages
+        return [self.hoist(inp_l, h, w, s) for s in range(n_stages)]
 
     # f16x3 path: the loop's activations (hidden state, corr features, r*h) live in HBM in the "split32" layout - hi|lo f16
     # pairs in the fp32 slots (cer_mvs.h) - written by the producers' epilogues, so that every conv stages its tensor sources

@@ -51,6 +51,17 @@ int cer_alt_corr_forward_f32(const float* fmap1, const float* fmap2, const float
 int cer_alt_corr_backward_f32(const float* fmap1, const float* fmap2, const float* coords, const float* corr_grad,
                               float* fmap1_grad, float* fmap2_grad, float* coords_grad,
                               int B, int N, int H1, int W1, int H2, int W2, int C, int radius, void* stream);
+/* Deterministic fmap2 gradient (no float atomics).  cer_alt_corr_backward_f32 with fmap2_grad = NULL
+ * gives fmap1_grad only; then
+ *   cer_alt_corr_bwd_tuples_f32: per (sample, footprint texel) a key (b*H2*W2 + texel, or the sentinel B*H2*W2 for texels
+ *     outside the map), a coefficient and the source pixel (b*H1*W1 + p): arrays of B*N*H1*W1*(2r+2)^2 entries;
+ *   the caller sorts the keys stably (`order` = the permutation) and computes seg[t] = first sorted position with key >= t,
+ *     t = 0 .. B*H2*W2 (T + 1 entries);
+ *   cer_alt_corr_bwd_reduce_f32: fmap2_grad[t, :] = sum of coef * fmap1[src, :] over segment t, in sorted order. */
+int cer_alt_corr_bwd_tuples_f32(const float* coords, const float* corr_grad, long* keys, float* coef, int* src,
+                                int B, int N, int H1, int W1, int H2, int W2, int radius, void* stream);
+int cer_alt_corr_bwd_reduce_f32(const float* fmap1, const long* order, const float* coef, const int* src, const long* seg,
+                                float* fmap2_grad, long T, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Epipolar cost-volume build, one cascade stage (reference: CorrBlock.__init__

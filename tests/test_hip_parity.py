@@ -153,7 +153,8 @@ def test_cost_build_edge_cases(dev):
     bad = Pij.clone()
     bad[0, 2] = 0.0                                    # Z == 0 everywhere
     vol2, _ = ops.cost_build(f1, f2, bad.to(dev), disp_in.reshape(-1).to(dev), D, incre, True, h1, w1, 3, fold=False)
-    assert torch.isfinite(vol2).all() and float(vol2[0].abs().max()) == 0.0
+    # (level 0 only: the pooled levels of a row are undefined until cer_pyramid_f32 has run)
+    assert torch.isfinite(vol2[..., :D]).all() and float(vol2[0, :, :D].abs().max()) == 0.0
 
 
 def test_lookup_edge_cases(dev):
@@ -289,7 +290,7 @@ def test_cost_build_band_gemm_matches_walk(dev, D, stage0, geom):
     for i, cols in ((0, D), (2, n), (4, D), (5, D)):
         err = (ref[i][:, :cols] - new[i][:, :cols]).abs().max()
         assert err <= 2e-6 * max(float(mag), 1.0) * (2 if i == 4 else 1), (i, float(err), float(mag))
-    assert torch.equal(new[5], new[0][5 * w1:])                                              # the slab sees the same samples
+    assert torch.equal(new[5][:, :D], new[0][5 * w1:, :D])                                    # the slab sees the same samples
     assert new[0][:, :D].abs().sum() > 0
 
 
