@@ -39,3 +39,41 @@ def stage_origin(disp, D, incre, shift):
         return disp.clone()
     lim = torch.tensor((D // 2) * incre, device=disp.device, dtype=torch.float32)
     return torch.where(disp < lim, lim, disp)
+
+
+def aggregate_views(frames, num_views, aggregation, group):
+    """View aggregation of the looked-up correlation features across ranks (core/update.py:101-107) - the literal multi-GPU form of
+    SURVEY.md 8(e): ``frames`` [V_local, K, ...] holds this rank's views (V_local may be 0), every rank gets the list of
+    aggregated [K, ...] tensors in the order mean, max, std.  mean: one SUM all-reduce of the local sum; max: one MAX all-reduce;
+    std (torch.std: unbiased): a second SUM all-reduce of the squared deviations from the global mean."""
+    G, _ = group_info(group)
+    if frames.shape[0]:
+        local_sum = frames.sum(0)
+        shape, dev, dt = frames.shape[1:], frames.device, frames.dtype
+    else:
+        shape, dev, dt = frames.shape[1:], frames.device, frames.dtype
+        local_sum = torch.zeros(shape, device=dev, dtype=dt)
+    out = []
+    need_mean = "mean" in aggregation or "std" in aggregation
+    mean = None
+    if need_mean:
+        mean = local_sum.clone()
+        if G > 1:
+            import torch.distributed as dist
+            dist.all_reduce(mean, op=dist.ReduceOp.SUM, group=group)
+        mean = mean / num_views
+    if "mean" in aggregation:
+        out.append(mean)
+    if "max" in aggregation:
+        mx = frames.max(0).values if frames.shape[0] else torch.full(shape, float("-inf"), device=dev, dtype=dt)
+        if G > 1:
+            import torch.distributed as dist
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+        out.append(mx)
+    if "std" in aggregation:
+        ss = ((frames - mean) ** 2).sum(0) if frames.shape[0] else torch.zeros(shape, device=dev, dtype=dt)
+        if G > 1:
+            import torch.distributed as dist
+            dist.all_reduce(ss, op=dist.ReduceOp.SUM, group=group)
+        out.append(torch.sqrt(ss / (num_views - 1)))
+    return out

@@ -110,7 +110,8 @@ class HipEncoder:
         a, h, w = self.trunk(x, raw)
         N, C = x.shape[0], self.head.cout
         ref = torch.empty(n_ref, h * w, C, device=self.device, dtype=torch.float32)
-        self._conv(self.head, a[:n_ref], n_ref, h, w, None, False, epi=1, out=ref, border=0, scale=scale)
+        if n_ref > 0:
+            self._conv(self.head, a[:n_ref], n_ref, h, w, None, False, epi=1, out=ref, border=0, scale=scale)
         src = None
         if N > n_ref:
             src = src_out if src_out is not None else torch.zeros(N - n_ref, (h + 2 * border) * (w + 2 * border), C, device=self.device,

@@ -81,10 +81,38 @@ class RAFT(nn.Module):
         self._engines = None
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
-    def encode(self, images, views, raw=False):
+    def encode(self, images, views, raw=False, parts="all"):
         """images [1,N,3,H,W] in [-1,1] (``raw``: 0..255, normalised on the fly, core/raft.py:40-41); ``views`` = source-view
         indices this rank owns -> (net [P,64], inp [P,64], reference features [P,C], source features [len(views),(h+4)*(w+4),C]);
-        features are channels-last, scaled by 1/8, source maps with a 2-texel zero border."""
+        features are channels-last, scaled by 1/8, source maps with a 2-texel zero border.
+        ``parts``: "all", or "src" (source features only: (None, None, None, f2)) / "ref" (context + reference features:
+        (net, inp, f1, None)) - the sharded forward encodes its source views first, starts their all-gather, and encodes the
+        reference view while the collective is in flight."""
+        if parts == "src":
+            if not views:
+                return None, None, None, None
+            if self.encoder_backend == "hip" and self.precision == "fp32" and self.encoder_type == "HR":
+                from .encoder_hip import HipEncoder
+                dev = images.device
+                if self._engines is None or self._engines[0] != dev:
+                    self._engines = (dev, HipEncoder(self.fnet, dev), HipEncoder(self.cnet, dev))
+                factor = 4
+                h, w = images.shape[-2] // factor, images.shape[-1] // factor
+                key = (len(views), h, w, str(dev))
+                buf = self._src_buf.get(key)
+                if buf is None:
+                    buf = torch.zeros(len(views), (h + 4) * (w + 4), self.dim_fmap, device=dev, dtype=torch.float32)
+                    self._src_buf = {key: buf}
+                _, src, _, _ = self._engines[1].features(images[0, list(views)], n_ref=0, border=2, scale=0.125, src_out=buf, raw=raw)
+                return None, None, None, src
+            x = images[0, list(views)]
+            if raw:
+                x = x.float() * (2 / 255.0) - 1
+            with torch.autocast("cuda", dtype=torch.float16, enabled=self.precision == "amp"):
+                fm = self.fnet(x).float()
+            return None, None, None, fmaps_to_nhwc(fm, border=2)
+        if parts == "ref":
+            views = []
         idx = [0] + list(views)
         stack = images[0] if idx == list(range(images.shape[1])) else images[0, idx]      # (no gather copy when every view is local)
         if self.encoder_backend == "hip" and self.precision == "fp32" and self.encoder_type == "HR":
@@ -193,21 +221,37 @@ class RAFT(nn.Module):
         intrinsics[:, :, :2] /= factor
         batch, num, ch, ht, wd = images.shape
         images = images.float() * (2 / 255.0) - 1
-        ii = torch.zeros(num - 1, dtype=torch.long)
-        jj = torch.arange(1, num)
         h, w = ht // factor, wd // factor
         disp = torch.zeros(batch, 1, h, w, device=dev)
         ctx = self.cnet(images[:, [0]]).float()
         net, inp = ctx.split([self.dim_net, self.dim_inp], dim=2)
         net, inp = torch.tanh(net), torch.relu(inp)
-        fmaps = self.fnet(images).float()
         ub = self.update_block
+        V = num - 1
+        sharded = self.view_group is not None and cdist.group_info(self.view_group)[0] > 1
+        if sharded:
+            # view sharding of the literal path (fallback for max / std aggregation): this rank encodes and
+            # correlates ITS views; the looked-up [33, h, w] features are aggregated across ranks every GRU step
+            views = cdist.local_views(V, self.view_group)
+            sel = [0] + views
+            images, poses, intrinsics = images[:, sel], poses[:, sel], intrinsics[:, sel]
+        nloc = images.shape[1] - 1
+        ii = torch.zeros(nloc, dtype=torch.long)
+        jj = torch.arange(1, nloc + 1)
+        fmaps = self.fnet(images).float()
         for stage, (D, incre, T) in enumerate(self.stages()):
-            corr_fn = CorrBlock(fmaps, poses, intrinsics, ii, jj, nIncre=D, incre=incre, disps_input=disp.detach(),
-                                shift=(stage == 0), num_levels=ub.num_levels, radius=ub.radius, test_mode=True, do_report=do_report)
+            corr_fn = None
+            if nloc:
+                corr_fn = CorrBlock(fmaps, poses, intrinsics, ii, jj, nIncre=D, incre=incre, disps_input=disp.detach(),
+                                    shift=(stage == 0), num_levels=ub.num_levels, radius=ub.radius, test_mode=True, do_report=do_report)
             for _ in range(T):
-                corr_frames = corr_fn(disp[:, ii.to(dev)])
-                net, delta = ub(net, inp, disp, corr_frames, stage)
+                if sharded:
+                    K = ub.num_levels * (2 * ub.radius + 1)
+                    frames = corr_fn(disp[:, ii.to(dev)])[0] if nloc else torch.zeros(0, K, h, w, device=dev)
+                    net, delta = ub(net, inp, disp, None, stage, parts=cdist.aggregate_views(frames, V, ub.aggregation, self.view_group))
+                else:
+                    corr_frames = corr_fn(disp[:, ii.to(dev)])
+                    net, delta = ub(net, inp, disp, corr_frames, stage)
                 disp = disp + delta.float()
         assert s is not None
         return disp * s

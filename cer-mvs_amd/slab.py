@@ -41,6 +41,31 @@ class LocalExchange:
         assert len(tensors) == self.G
         return [list(tensors) for _ in range(self.G)]
 
+    def all_gather_async(self, tensors):
+        return self.all_gather(tensors)
+
+    def wait(self, handle):
+        return handle
+
+    def neighbor_exchange(self, bufs):
+        """Simulated point-to-point halo refresh: rank g sees the bottom half of g-1's buffer and the top half of g+1's
+        (copies, like the real receive buffers)."""
+        half = bufs[0].numel() // 2
+        key = (bufs[0].numel(), bufs[0].device, bufs[0].dtype)
+        if getattr(self, "_nb_key", None) != key:      # persistent receive buffers, like DistExchange: recorded launches point into them
+            self._nb_key = key
+            self._nb = [(torch.empty(half, device=bufs[0].device, dtype=bufs[0].dtype), torch.empty(half, device=bufs[0].device, dtype=bufs[0].dtype))
+                        for _ in range(self.G)]
+        out = []
+        for g in range(self.G):
+            rp, rn = self._nb[g]
+            if g > 0:
+                rp.copy_(bufs[g - 1][half:])
+            if g < self.G - 1:
+                rn.copy_(bufs[g + 1][:half])
+            out.append((rp if g > 0 else None, rn if g < self.G - 1 else None))
+        return out
+
     def all_gather_flat(self, tensors):
         """list of G equal-sized tensors -> per simulated rank the stacked [G, ...] tensor."""
         assert len(tensors) == self.G
@@ -61,12 +86,57 @@ class DistExchange:
         self.G = dist.get_world_size(group)
         self.ranks = [dist.get_rank(group)]
 
+    def neighbor_exchange(self, bufs):
+        """Halo refresh as point-to-point traffic: this rank's buffer is [top half | bottom half]; the top half goes to rank g-1,
+        the bottom half to rank g+1, and their facing halves come back - 2 sends + 2 receives of one strip each
+        (``batch_isend_irecv``: one RCCL group call, neighbour links of the xGMI mesh only) instead of an all-gather in which every
+        rank receives all G buffers.  Returns [(prev_half or None, next_half or None)] (persistent receive buffers)."""
+        import torch.distributed as dist
+        buf = bufs[0]
+        g, G = self.ranks[0], self.G
+        half = buf.numel() // 2
+        key = (buf.numel(), buf.device, buf.dtype)
+        if getattr(self, "_nb_key", None) != key:
+            self._nb_key = key
+            self._nb = (torch.empty(half, device=buf.device, dtype=buf.dtype), torch.empty(half, device=buf.device, dtype=buf.dtype))
+        rprev, rnext = self._nb
+        ranks = dist.get_process_group_ranks(self.group) if self.group is not None else list(range(G))
+        # RCCL orders the transfers after the launch stream's kernels by itself.  gloo (the transport of the multi-process tests)
+        # has no stream semantics for point-to-point device buffers: there the strips are staged through host tensors.
+        staged = buf.is_cuda and dist.get_backend(self.group) != "nccl"
+        src = buf.cpu() if staged else buf
+        dprev, dnext = (torch.empty(half, dtype=buf.dtype), torch.empty(half, dtype=buf.dtype)) if staged else (rprev, rnext)
+        ops_ = []
+        if g > 0:
+            ops_ += [dist.P2POp(dist.isend, src[:half], ranks[g - 1], self.group), dist.P2POp(dist.irecv, dprev, ranks[g - 1], self.group)]
+        if g < G - 1:
+            ops_ += [dist.P2POp(dist.isend, src[half:], ranks[g + 1], self.group), dist.P2POp(dist.irecv, dnext, ranks[g + 1], self.group)]
+        for w_ in (dist.batch_isend_irecv(ops_) if ops_ else []):
+            w_.wait()
+        if staged:
+            if g > 0:
+                rprev.copy_(dprev)
+            if g < G - 1:
+                rnext.copy_(dnext)
+        return [(rprev if g > 0 else None, rnext if g < G - 1 else None)]
+
     def all_gather(self, tensors):
         import torch.distributed as dist
         t = tensors[0].contiguous()
         out = [torch.empty_like(t) for _ in range(self.G)]
         dist.all_gather(out, t, group=self.group)
         return [out]
+
+    def all_gather_async(self, tensors):
+        """Start an all-gather; ``wait`` returns what ``all_gather`` would (the collective runs on RCCL's own stream meanwhile)."""
+        import torch.distributed as dist
+        t = tensors[0].contiguous()
+        out = [torch.empty_like(t) for _ in range(self.G)]
+        return dist.all_gather(out, t, group=self.group, async_op=True), out, t
+
+    def wait(self, handle):
+        handle[0].wait()
+        return [handle[1]]
 
     def all_gather_flat(self, tensors):
         """One collective into one preallocated [G, ...] buffer (no per-rank output tensors, no copies after it)."""
@@ -105,42 +175,55 @@ def _device_copy(pairs):
 
 
 def pack_strips(net, disp, buf, w, r0, r1, e0, halo=HALO, copy=_device_copy, rows=None):
-    """The first / last ``halo`` OWNED rows of net [rows_ext*w, C] and disp [rows_ext*w] -> buf (flat:
-    net top | net bottom | disp top | disp bottom).  All four ranges are contiguous: one cer_copy_segments_f32 launch.
+    """The first / last ``halo`` OWNED rows of net [rows_ext*w, C] and disp [rows_ext*w] -> buf, laid out as two halves
+    [net top | disp top] [net bottom | disp bottom] (the top half is what rank g-1 needs, the bottom half what g+1 needs).
+    All four ranges are contiguous: one cer_copy_segments_f32 launch.
     ``rows(net, flat, y0, nrows, to_tensor)``: row mover for a hidden state kept in an m-tile-major layout (s16 path)."""
     C = net.shape[1]
     n, t0, b0 = halo * w, (r0 - e0) * w, (r1 - halo - e0) * w
+    hb = n * (C + 1)
     if rows is not None:
         rows(net, buf[:n * C], r0 - e0, halo, False)
-        rows(net, buf[n * C:2 * n * C], r1 - halo - e0, halo, False)
-        copy([(disp[t0:t0 + n], buf[2 * n * C:2 * n * C + n]), (disp[b0:b0 + n], buf[2 * n * C + n:])])
+        rows(net, buf[hb:hb + n * C], r1 - halo - e0, halo, False)
+        copy([(disp[t0:t0 + n], buf[n * C:hb]), (disp[b0:b0 + n], buf[hb + n * C:])])
         return
-    copy([(net[t0:t0 + n], buf[:n * C]), (net[b0:b0 + n], buf[n * C:2 * n * C]),
-          (disp[t0:t0 + n], buf[2 * n * C:2 * n * C + n]), (disp[b0:b0 + n], buf[2 * n * C + n:])])
+    copy([(net[t0:t0 + n], buf[:n * C]), (disp[t0:t0 + n], buf[n * C:hb]),
+          (net[b0:b0 + n], buf[hb:hb + n * C]), (disp[b0:b0 + n], buf[hb + n * C:])])
 
 
-def unpack_halo(net, disp, allbuf, w, g, G, r0, r1, e0, e1, halo=HALO, copy=_device_copy, rows=None):
-    """Refresh the halo rows of (net, disp) from the gathered strips allbuf [G, 2*halo*w*(C+1)] (layout of pack_strips),
-    one launch; same row bookkeeping as refresh_halo.  ``rows``: see pack_strips."""
+def unpack_halves(net, disp, prev_half, next_half, w, g, G, r0, r1, e0, e1, halo=HALO, copy=_device_copy, rows=None):
+    """Refresh the halo rows of (net, disp): rows [e0, r0) from ``prev_half`` = the BOTTOM half of rank g-1's strips buffer (its
+    last ``halo`` owned rows), rows [r1, e1) from ``next_half`` = the TOP half of rank g+1's; layout of pack_strips.  One launch
+    (plus the row mover's, s16 path)."""
     C = net.shape[1]
     n = halo * w
     pairs = []
     if g > 0 and r0 > e0:          # rows [e0, r0) = the last (r0-e0) rows of rank g-1's bottom strip
-        k, src = (r0 - e0) * w, allbuf[g - 1]
+        k = (r0 - e0) * w
         if rows is not None:
-            rows(net, src[n * C + (n - k) * C:2 * n * C], 0, r0 - e0, True)
+            rows(net, prev_half[(n - k) * C:n * C], 0, r0 - e0, True)
         else:
-            pairs += [(src[n * C + (n - k) * C:2 * n * C], net[:k])]
-        pairs += [(src[2 * n * C + n + (n - k):], disp[:k])]
+            pairs += [(prev_half[(n - k) * C:n * C], net[:k])]
+        pairs += [(prev_half[n * C + (n - k):], disp[:k])]
     if g < G - 1 and e1 > r1:      # rows [r1, e1) = the first (e1-r1) rows of rank g+1's top strip
-        k, src, o = (e1 - r1) * w, allbuf[g + 1], (r1 - e0) * w
+        k, o = (e1 - r1) * w, (r1 - e0) * w
         if rows is not None:
-            rows(net, src[:k * C], r1 - e0, e1 - r1, True)
+            rows(net, next_half[:k * C], r1 - e0, e1 - r1, True)
         else:
-            pairs += [(src[:k * C], net[o:o + k])]
-        pairs += [(src[2 * n * C:2 * n * C + k], disp[o:o + k])]
+            pairs += [(next_half[:k * C], net[o:o + k])]
+        pairs += [(next_half[n * C:n * C + k], disp[o:o + k])]
     if pairs:
         copy(pairs)
+
+
+def unpack_halo(net, disp, allbuf, w, g, G, r0, r1, e0, e1, halo=HALO, copy=_device_copy, rows=None):
+    """``unpack_halves`` on the gathered strips allbuf [G, 2*halo*w*(C+1)] of the all-gather form of the exchange."""
+    hb = halo * w * (net.shape[1] + 1)
+    unpack_halves(net, disp, allbuf[g - 1][hb:] if g > 0 else None, allbuf[g + 1][:hb] if g < G - 1 else None, w, g, G, r0, r1, e0, e1,
+                  halo, copy, rows)
+
+
+P2P_HALO = True           # halo refresh by neighbour point-to-point exchange (False: one all-gather of every rank's strips)
 
 
 def sharded_forward(model, images, poses, intrinsics, scale, ex):
@@ -171,18 +254,22 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
     # (uploaded before anything is enqueued: a pageable H2D copy blocks the host until the stream has drained)
     Pij = pij_matrices(poses[0], intr[0], [0] * V, list(range(1, V + 1))).to(dev)
 
-    # ---- encoders: every rank the reference + context, each rank its own source views; all-gather the source maps
+    # ---- encoders: each rank its own source views first, so that their all-gather (333 MB at 1600x1184 x 10 views: the exchange
+    # step of the cost volume) is in flight while the rank encodes the reference view and the context map
     st = {}
     send = []
     for g in ex.ranks:
         views = local_views_for(V, G, g)
-        net_l, inp_l, f1, f2 = model.encode(images, views, raw=True)
-        st[g] = dict(net=net_l, inp=inp_l, f1=f1)
+        _, _, _, f2 = model.encode(images, views, raw=True, parts="src")
         pad = torch.zeros(vmax, Pb, C, device=dev, dtype=torch.float32)
         if views:
             pad[:len(views)] = f2
         send.append(pad)
-    gathered = ex.all_gather(send)
+    pending = ex.all_gather_async(send)
+    for g in ex.ranks:
+        net_l, inp_l, f1, _ = model.encode(images, [], raw=True, parts="ref")
+        st[g] = dict(net=net_l, inp=inp_l, f1=f1)
+    gathered = ex.wait(pending)
     for i, g in enumerate(ex.ranks):
         f2_all = torch.empty(V, Pb, C, device=dev, dtype=torch.float32)
         for r in range(G):
@@ -229,13 +316,20 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
                 else:
                     d["plan_step"].replay()
                 send.append(d["strips"])
-            gathered = ex.all_gather_flat(send)   # one collective per iteration
+            if P2P_HALO:                          # neighbours only: 2 sends + 2 receives of one strip per rank
+                halves = ex.neighbor_exchange(send)
+            else:                                 # one collective: every rank receives all G strip buffers
+                gathered = ex.all_gather_flat(send)
+                hb = send[0].numel() // 2
+                halves = [(gathered[i][g - 1][hb:] if g > 0 else None, gathered[i][g + 1][:hb] if g < G - 1 else None)
+                          for i, g in enumerate(ex.ranks)]
             for i, g in enumerate(ex.ranks):
                 d = st[g]
                 if record:
-                    d["plan_halo"] = L.LaunchPlan(keep=(gathered[i],))
+                    d["plan_halo"] = L.LaunchPlan(keep=(halves[i],))
                     with L.recording(d["plan_halo"]):
-                        unpack_halo(d["net"], d["disp"], gathered[i], w, g, G, d["r0"], d["r1"], d["e0"], d["e1"], rows=d["rows"])
+                        unpack_halves(d["net"], d["disp"], halves[i][0], halves[i][1], w, g, G, d["r0"], d["r1"], d["e0"], d["e1"],
+                                      rows=d["rows"])
                 else:
                     d["plan_halo"].replay()
 

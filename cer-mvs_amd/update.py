@@ -282,8 +282,10 @@ class UpdateBlock(nn.Module):
         u = torch.nn.functional.unfold(disp, [k, k], padding=k // 2).view(batch, k * k, ht, wd)
         return u - disp.view(batch, 1, ht, wd)
 
-    def forward(self, net, inp, disp, corr_frames, stage):
-        """net, inp [B,num,64,h,w]; disp [B,1,h,w]; corr_frames [B,V,33,h,w] -> (net [B,num,64,h,w], delta [B,num,h,w])."""
+    def forward(self, net, inp, disp, corr_frames, stage, parts=None):
+        """net, inp [B,num,64,h,w]; disp [B,1,h,w]; corr_frames [B,V,33,h,w] -> (net [B,num,64,h,w], delta [B,num,h,w]).
+        ``parts`` (extension): the view aggregates [33,h,w] in the order mean, max, std, already reduced over all views - the
+        view-sharded literal forward passes them (dist.aggregate_views) instead of ``corr_frames``."""
         if not net.is_cuda:
             raise RuntimeError("net must be a CUDA tensor")
         batch, num, ch, ht, wd = net.shape
@@ -295,9 +297,16 @@ class UpdateBlock(nn.Module):
         net_l = ops.nchw_to_nhwc(net.reshape(ch, P).float().contiguous())
         inp_l = ops.nchw_to_nhwc(inp.reshape(-1, P).float().contiguous())
         disp_l = disp.reshape(P).float().contiguous()
-        feats = corr_frames[0].float()
-        parts = []
-        if "mean" in self.aggregation and len(self.aggregation) == 1:
+        if parts is not None:
+            agg = torch.stack([t.float() for t in parts], dim=1).reshape(1, -1, P).contiguous()
+            c1 = ops.corr_encode(agg, p["w0t"], p["b0"])
+            feats = None
+        else:
+            feats = corr_frames[0].float()
+            parts = []
+        if feats is None:
+            pass
+        elif "mean" in self.aggregation and len(self.aggregation) == 1:
             c1 = ops.corr_encode(feats.reshape(feats.shape[0], -1, P).contiguous(), p["w0t"], p["b0"])
         else:
             if "mean" in self.aggregation:

@@ -75,6 +75,43 @@ def test_more_ranks_than_views():
         assert out[r][1] < 1e-6 and out[r][2]
 
 
+def _agg_worker(rank, world, port, V, ret):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    from cer_mvs_amd import dist as cdist
+    from test_oracle_golden import hashed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = hashed((V, 33, 5, 7), 91, -1.5, 3.0)
+    views = cdist.local_views(V, dist.group.WORLD)
+    local = frames[[v - 1 for v in views]] if views else frames[:0]
+    got = cdist.aggregate_views(local, V, ["mean", "max", "std"], dist.group.WORLD)
+    want = [frames.mean(0), frames.max(0).values, frames.std(0)]
+    ret[rank] = [float((a - b).abs().max()) for a, b in zip(got, want)]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_view_aggregation_across_ranks_matches_torch():
+    """The literal multi-GPU exchange: mean / max / std of the looked-up features over ALL views from per-rank
+    partial views (core/update.py:101-107), incl. a rank without views."""
+    for V in (5, 2, 1):
+        if V == 1:
+            continue                                   # torch.std of one view is NaN in the reference too
+        ret = mp.Manager().dict()
+        mp.spawn(_agg_worker, args=(2, _free_port(), V, ret), nprocs=2, join=True)
+        for r in (0, 1):
+            assert max(ret[r]) < 1e-5, (V, dict(ret))
+    from cer_mvs_amd import dist as cdist
+    from test_oracle_golden import hashed
+    frames = hashed((4, 33, 3, 3), 92)
+    one = cdist.aggregate_views(frames, 4, ["max", "mean"], None)           # single rank: plain torch, order mean, max
+    assert torch.equal(one[0], frames.sum(0) / 4) and torch.equal(one[1], frames.max(0).values)
+
+
 def test_partition_covers_every_view_once():
     from cer_mvs_amd import dist as cdist
 
@@ -132,10 +169,15 @@ def _slab_worker(rank, world, port, ret):
         ref = _fake_step(ref, h, w)
         xd = _fake_step(xd[:, None], e1 - e0, w)[:, 0].contiguous()
         refd = _fake_step(refd[:, None], h, w)[:, 0].contiguous()
-        # the product's per-iteration exchange: pack -> one flat all-gather -> refresh (slab.sharded_forward)
+        # the product's per-iteration exchange (slab.sharded_forward): pack -> neighbour point-to-point exchange -> refresh ...
         slab.pack_strips(x, xd, buf, w, r0, r1, e0, copy=_torch_copy)
+        x2, xd2 = x.clone(), xd.clone()
+        prev_half, next_half = ex.neighbor_exchange([buf])[0]
+        slab.unpack_halves(x, xd, prev_half, next_half, w, rank, world, r0, r1, e0, e1, copy=_torch_copy)
+        # ... and its all-gather form
         allbuf = ex.all_gather_flat([buf])[0]
-        slab.unpack_halo(x, xd, allbuf, w, rank, world, r0, r1, e0, e1, copy=_torch_copy)
+        slab.unpack_halo(x2, xd2, allbuf, w, rank, world, r0, r1, e0, e1, copy=_torch_copy)
+        assert torch.equal(x, x2) and torch.equal(xd, xd2)
         # and the list form (features / final gather use it)
         y = x.clone()
         strips = ex.all_gather([slab.border_strips(y, w, r0, r1, e0)])[0]
@@ -192,8 +234,12 @@ def test_local_exchange_simulation_matches_full_image():
         for g, (r0, r1, e0, e1) in enumerate(b):
             slab.pack_strips(ys[g], ds[g], bufs[g], w, r0, r1, e0, copy=_torch_copy)
         flat = ex.all_gather_flat(bufs)
+        nb = ex.neighbor_exchange(bufs)
         for g in range(G):
+            y2, d2 = ys[g].clone(), ds[g].clone()
             slab.unpack_halo(ys[g], ds[g], flat[g], w, g, G, *b[g], copy=_torch_copy)
+            slab.unpack_halves(y2, d2, nb[g][0], nb[g][1], w, g, G, *b[g], copy=_torch_copy)
             assert torch.equal(ys[g], xs[g]) and torch.equal(ds[g], xs[g][:, 0])
+            assert torch.equal(y2, xs[g]) and torch.equal(d2, xs[g][:, 0])
     for g, (r0, r1, e0, e1) in enumerate(b):
         assert float((xs[g] - ref[e0 * w:e1 * w]).abs().max()) < 1e-6

@@ -607,7 +607,8 @@ def test_end_to_end_other_baseline_configs(dev, golden, name):
     assert e_disp < TOL and e_depth < TOL
 
 
-@pytest.mark.parametrize("name,G", [("e2e_tiny", 2), ("e2e_cfg1", 2), ("e2e_cfg1", 3), ("e2e_cfg1", 8), ("e2e_cfg2", 8), ("e2e_cfg2", 4)])
+@pytest.mark.parametrize("name,G", [("e2e_tiny", 2), ("e2e_cfg1", 2), ("e2e_cfg1", 3), ("e2e_cfg1", 8), ("e2e_cfg2", 8), ("e2e_cfg2", 4),
+                                    ("e2e_blended", 8), ("e2e_tnt", 8)])
 def test_slab_sharded_forward_matches_reference_capture(dev, golden, name, G):
     """The multi-GPU row-slab algorithm (slab.py) with G ranks simulated in one process: same kernels, same halo
     bookkeeping, only the collective is replaced by list passing.  Must equal the captures like the 1-GPU path."""

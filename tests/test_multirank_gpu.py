@@ -30,7 +30,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, shard, name, out_path):
+def _worker(rank, world, port, shard, name, out_path, aggregation=None):
     import sys
     sys.path.insert(0, REPO)
     import torch.distributed as dist
@@ -46,6 +46,9 @@ def _worker(rank, world, port, shard, name, out_path):
     cascade = [tuple(int(x) for x in c) for c in g["cascade"]]
     images, poses, intr, scale = synthetic_scene(H, W, V, seed=int(g["scene_seed"]))
     model = RAFT(cascade=cascade, test_mode=True, view_group=dist.group.WORLD, shard=shard)
+    if aggregation is not None:
+        from cer_mvs_amd.update import UpdateBlock
+        model.update_block = UpdateBlock(cascade=model.cascade, dim_net=64, dim_inp=64, aggregation=aggregation)
     model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(g["weight_seed"])))
     model = model.to(dev).eval()
     with torch.no_grad():
@@ -56,7 +59,7 @@ def _worker(rank, world, port, shard, name, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shard,name", [("slab", "e2e_cfg1"), ("views", "e2e_cfg1"), ("slab", "e2e_tiny")])
+@pytest.mark.parametrize("shard,name", [("slab", "e2e_cfg1"), ("views", "e2e_cfg1"), ("slab", "e2e_tiny"), ("views", "e2e_cfg2")])
 def test_two_process_sharded_forward(dev, golden, tmp_path, shard, name):
     world = 2
     out_path = str(tmp_path / "disp")
@@ -66,3 +69,28 @@ def test_two_process_sharded_forward(dev, golden, tmp_path, shard, name):
     assert torch.equal(outs[0], outs[1])                       # every rank returns the full disparity map
     assert outs[0].shape == ref.shape
     assert rel_l1(outs[0], ref) < TOL
+
+
+def test_two_process_literal_forward_with_max_aggregation(dev, golden, tmp_path):
+    """aggregation = [mean, max] has no view-mean fold: the literal forward shards the views and aggregates the looked-up
+    features across ranks every GRU step (dist.aggregate_views: SUM and MAX all-reduces of [33, P]); it must equal the
+    single-process literal forward."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.update import UpdateBlock
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+    name, agg = "e2e_tiny", ("mean", "max")
+    world = 2
+    out_path = str(tmp_path / "disp")
+    mp.spawn(_worker, args=(world, _free_port(), "views", name, out_path, agg), nprocs=world, join=True)
+    g = golden(name)
+    cascade = [tuple(int(x) for x in c) for c in g["cascade"]]
+    images, poses, intr, scale = synthetic_scene(int(g["H"]), int(g["W"]), int(g["V"]), seed=int(g["scene_seed"]))
+    model = RAFT(cascade=cascade, test_mode=True)
+    model.update_block = UpdateBlock(cascade=model.cascade, dim_net=64, dim_inp=64, aggregation=agg)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(g["weight_seed"])))
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        ref = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale).cpu()
+    outs = [torch.from_numpy(np.load(f"{out_path}.{r}.npy")) for r in range(world)]
+    assert rel_l1(outs[0], outs[1]) < 1e-6 and rel_l1(outs[0], ref) < 1e-5 and rel_l1(outs[1], ref) < 1e-5, \
+        (rel_l1(outs[0], outs[1]), rel_l1(outs[0], ref), rel_l1(outs[1], ref))
