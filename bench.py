@@ -8,11 +8,13 @@ HBM -> disparity in HBM) at BASELINE.json configs[1]: DTU 1600x1184, 10 source v
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1 (configs[3]): ONE reference frame is sharded over the ranks (`--mode shard`, default): rank g encodes the
-source views v with (v-1) % N == g and the feature maps are all-gathered (RCCL over xGMI); image rows are sharded for
-the cost volume and the GRU loop with a 7-row halo all-gather of (net, disp) per iteration (cer-mvs_amd/slab.py).
-Total work is fixed as N grows => "scaling": "strong".  `--mode views` is the simpler scheme (views sharded, view-sum
-volume all-reduced once per stage, GRU replicated); `--mode replica` runs N independent depth maps (weak scaling).
+N > 1 (configs[3]): ONE reference frame is sharded over the ranks.  The default `--mode both` times the two schemes one
+after the other and reports both under "modes"; the headline (`value`, `ms_per_step`) is a fresh timed run of the faster one:
+  shard   rank g encodes the source views v with (v-1) % N == g; their feature maps are all-gathered (RCCL over xGMI) while
+          the rank encodes the reference view; image rows are sharded for the cost volume and the GRU loop, with the 7-row
+          halo of (net, disp) exchanged point-to-point with the two neighbours per iteration (cer-mvs_amd/slab.py);
+  views   north_star's scheme: views sharded, the view-sum volume all-reduced once per stage, GRU replicated.
+Total work is fixed as N grows => "scaling": "strong".  `--mode replica` runs N independent depth maps (weak scaling).
 
 Rank 0 prints ONE JSON line (see the README of this file's contract in DESIGN.md §Measurement): besides
 the driver's keys it carries
@@ -50,7 +52,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="dtu_1600x1184_v10_it32", choices=sorted(WORKLOADS))
-    ap.add_argument("--mode", default="shard", choices=["shard", "views", "replica"])
+    ap.add_argument("--mode", default="both", choices=["both", "shard", "views", "replica"],
+                    help="N > 1: both = time the view-shard scheme (north_star's) AND the row-slab scheme, headline = row-slab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1: nccl (= RCCL over xGMI, the product path) or gloo (validation "
@@ -184,15 +187,8 @@ def main():
     from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
 
     H, W, V, cascade = WORKLOADS[args.workload]
-    shard = world > 1 and args.mode in ("shard", "views")
-    model = RAFT(cascade=cascade, test_mode=True, precision=args.precision, view_group=group if shard else None,
-                 gru_precision=args.gru_precision, encoder_backend=args.encoder, shard="slab" if args.mode == "shard" else "views")
-    sd = fill_state_dict(model.state_dict(), seed=5)
-    model.load_state_dict(sd)
-    model = model.to(dev).eval()
-    seed = 0 if (shard or world == 1) else rank          # replicas: a different reference frame per rank
-    images, poses, intr, scale = synthetic_scene(H, W, V, seed=seed)
-    inputs = (images.to(dev), poses.to(dev), intr.to(dev))
+    if world == 1:
+        args.mode = "shard"                               # (single GPU: the modes coincide)
 
     def sync():
         if world > 1:
@@ -200,21 +196,50 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            out = model(*inputs, scale=scale)
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = model(*inputs, scale=scale)
-        sync()
-        elapsed = time.perf_counter() - t0
-    assert torch.isfinite(out).all()
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt[0])
+    def timed_run(mode):
+        """W warm-up + K timed forwards in one sharding mode -> (seconds: max over ranks, output, model, inputs, weights)."""
+        shard = world > 1 and mode in ("shard", "views")
+        model = RAFT(cascade=cascade, test_mode=True, precision=args.precision, view_group=group if shard else None,
+                     gru_precision=args.gru_precision, encoder_backend=args.encoder, shard="slab" if mode == "shard" else "views")
+        sd = fill_state_dict(model.state_dict(), seed=5)
+        model.load_state_dict(sd)
+        model = model.to(dev).eval()
+        seed = 0 if (shard or world == 1) else rank          # replicas: a different reference frame per rank
+        images, poses, intr, scale = synthetic_scene(H, W, V, seed=seed)
+        inputs = (images.to(dev), poses.to(dev), intr.to(dev))
+        with torch.no_grad():
+            for _ in range(args.warmup):
+                out = model(*inputs, scale=scale)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out = model(*inputs, scale=scale)
+            sync()
+            elapsed = time.perf_counter() - t0
+        assert torch.isfinite(out).all()
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt[0])
+        return elapsed, out, model, inputs, scale, sd
+
+    modes = None
+    if args.mode == "both":
+        # north_star's scheme (views sharded, view-sum volume all-reduced once per stage, GRU replicated) and the row-slab scheme,
+        # one after the other; the headline is the faster one (decided on the max-over-ranks times, so every rank agrees) and the
+        # rest of the line - kernels, roofline - describes that mode
+        modes = {}
+        for m, label in (("views", f"view-shard x{world} + all-reduce/stage"), ("shard", f"row-slab x{world}")):
+            e_m, out_m, model_m, _, _, _ = timed_run(m)
+            modes[m] = {"value": args.steps / e_m, "ms_per_step": 1e3 * e_m / args.steps, "parallelism": label}
+            del model_m, out_m
+            torch.cuda.empty_cache()
+        args.mode = "shard" if modes["shard"]["ms_per_step"] <= modes["views"]["ms_per_step"] else "views"
+    shard = world > 1 and args.mode in ("shard", "views")
+    elapsed, out, model, inputs, scale, sd = timed_run(args.mode)
+    if modes is not None:
+        modes[args.mode].update(value=args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps, headline=True)
     maps = args.steps * (world if (world > 1 and not shard) else 1)
 
     result = None
@@ -329,9 +354,11 @@ def main():
             "config": {"workload": args.workload, "image": f"{W}x{H}", "src_views": V, "cascade": cascade,
                        "gru_iters": sum(c[2] for c in cascade),
                        "parallelism": "single" if world == 1 else (
-                           (f"row-slab x{world}: feature all-gather + 7-row halo all-gather per GRU iteration" if args.mode == "shard"
+                           (f"row-slab x{world}: source-feature all-gather (overlapped with the reference encode) + 7-row halo exchanged "
+                            f"point-to-point with the 2 neighbours per GRU iteration" if args.mode == "shard"
                             else f"view-shard x{world} + all-reduce/stage") if shard else f"replica x{world}"),
                        **({"backend": "gloo (validation run, ranks may share a GPU)"} if (world > 1 and args.backend == "gloo") else {})},
+            **({"modes": modes} if modes is not None else {}),
             "roofline": roofline, "roofline_hbm_kernel": hbm, "inner_loop": inner, "kernels": kern,
             "instrumented_pass": {"wall_ms": inst_wall_ms, "sum_of_kernels_ms": sum(t for _, t in rec.values()),
                                   "note": "one extra forward after the timed region with HIP events around every library launch and "

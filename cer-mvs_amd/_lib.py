@@ -134,14 +134,15 @@ class recording:
 
     def __enter__(self):
         global _recorder
-        if _recorder is not None:
+        if isinstance(_recorder, _Recording):
             raise RuntimeError("cer-mvs_amd: nested launch recording")
+        self._outer = _recorder                    # (a ``timing`` context stays active underneath: its wrappers get recorded)
         _recorder = _Recording(load(), self.plan)
         return self.plan
 
     def __exit__(self, *exc):
         global _recorder
-        _recorder = None
+        _recorder = self._outer
         return False
 
 

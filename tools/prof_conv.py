@@ -68,9 +68,9 @@ def main():
     elif args.what == "lookup":
         vol = r(P, 112)
         w0t, b0 = r(33, 64), r(64)
-        out = torch.empty(P, 64, device=dev)
+        out = torch.empty(ops.s16_pixels(h, w), 64, device=dev)       # the shipped form: frag16 output for the s16 convolutions
         org, dd = disp.clone(), disp + 0.0002 * torch.rand(P, device=dev)
-        run(lambda: ops.lookup_encode(vol, org, dd, w0t, b0, 64, 0.0025 / 64, 3, 5, out=out))
+        run(lambda: ops.lookup_encode(vol, org, dd, w0t, b0, 64, 0.0025 / 64, 3, 5, out=out, out_split=2, log2s=L.S16_RELU, img_w=w))
     elif args.what in ("build0", "build1"):
         V = 10
         f1 = r(P, 64) * 0.25
