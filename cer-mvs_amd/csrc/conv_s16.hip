@@ -997,22 +997,31 @@ extern "C" int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, con
     a.out_split = out_split;
     hipStream_t st = (hipStream_t)stream;
     const int ncu = sx_num_cus();
+    // Tile height: blocks are 4 waves, two of them fit a CU.  A launch costs rounds x (tile rows + a fixed prologue / epilogue
+    // share worth ~1.1 m-tile rows per wave); images too small to fill the CUs with full-height tiles (the row slabs of the
+    // multi-GPU forward: 51 x 400 at 8 ranks) take the half-height tiles.  tile_mt forces a height (experiments, tests).
+    // (tile_mt = 5 - 10-row tiles, fewer idle CU-rounds at 296 x 400 - is kept for experiments: it still spills registers)
+    const long slots = 2L * ncu;
+    const int tx = (w + SX_TW - 1) / SX_TW;
+    auto pick = [&](int rows_per_mt, int lo, int hi, int ny) {
+        int best_mt = hi;
+        double best = -1.0;
+        for (int c = hi; c >= lo; --c) {
+            const long nblk = (long)((h + rows_per_mt * c - 1) / (rows_per_mt * c)) * tx * ny;
+            const double cost = (double)((nblk + slots - 1) / slots) * (c + 1.1);
+            if (best < 0 || cost < best - 1e-9) { best = cost; best_mt = c; }
+        }
+        return best_mt;
+    };
     if (Cout % 128 == 0) {
-        // 1 x 4 waves, tile 2*MT x 16: pick the tile height that leaves the fewest idle CU-rounds (tile_mt forces it)
-        // (tile_mt = 5 - 10-row tiles, fewer idle CU-rounds at 296 x 400 - is kept for experiments: it still spills registers)
-        return tile_mt == 5 ? sx_launch<1, 4, 5>(a, epi, st) : sx_launch<1, 4, 4>(a, epi, st);
+        int mt = tile_mt;
+        if (mt != 2 && mt != 4 && mt != 5) mt = pick(2, 2, 4, Cout / 128) == 2 ? 2 : 4;
+        return mt == 5 ? sx_launch<1, 4, 5>(a, epi, st) : mt == 2 ? sx_launch<1, 4, 2>(a, epi, st) : sx_launch<1, 4, 4>(a, epi, st);
     }
     if (epi == SX_EPI_DELTA || epi == CER_EPI_GATES) return CER_ESHAPE;
     int mt = tile_mt;
-    if (mt != 3 && mt != 4) {
-        long best = -1;
-        for (int c = 3; c <= 4; ++c) {
-            const long nblk = (long)((h + 4 * c - 1) / (4 * c)) * ((w + SX_TW - 1) / SX_TW) * (Cout / 64);
-            const long cost = ((nblk + ncu - 1) / ncu) * c;
-            if (best < 0 || cost < best) { best = cost; mt = c; }
-        }
-    }
-    return mt == 3 ? sx_launch<2, 2, 3>(a, epi, st) : sx_launch<2, 2, 4>(a, epi, st);
+    if (mt < 2 || mt > 4) mt = pick(4, 2, 4, Cout / 64);
+    return mt == 2 ? sx_launch<2, 2, 2>(a, epi, st) : mt == 3 ? sx_launch<2, 2, 3>(a, epi, st) : sx_launch<2, 2, 4>(a, epi, st);
 }
 
 // ---- layout conversion (model load / API boundaries / tests): plain fp32 [h*w, C] <-> the m-tile-major layouts of the s16 convs.

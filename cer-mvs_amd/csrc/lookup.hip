@@ -43,6 +43,23 @@ __device__ __forceinline__ void lk_window(const float* __restrict__ row, int off
     }
 }
 
+// the same with a compile-time radius: the 2r + 2 row reads are issued back to back, o has stride 1
+template <int R_>
+__device__ __forceinline__ void lk_window_ct(const float* __restrict__ row, int off, int len, float x, float* __restrict__ o) {
+    const float fx = floorf(x);
+    const float w = x - fx;
+    const bool in_range = fx < (float)(len + R_ + 1);
+    const int i0 = in_range ? (int)fx - R_ : 0;
+    float v[2 * R_ + 2];
+#pragma unroll
+    for (int j = 0; j < 2 * R_ + 2; ++j) {
+        const int i = i0 + j;
+        v[j] = (in_range && i >= 0 && i < len) ? row[off + i] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 2 * R_ + 1; ++j) o[j] = v[j] * (1.0f - w) + v[j + 1] * w;
+}
+
 // out [nv, L*(2r+1), P] planar
 __global__ __launch_bounds__(256) void lookup_kernel(const float* __restrict__ vol, const float* __restrict__ origin,
                                                      const float* __restrict__ disp, long dvs, float* __restrict__ out, long P, int D,
@@ -77,93 +94,151 @@ __global__ __launch_bounds__(256) void lookup_kernel(const float* __restrict__ v
     }
 }
 
-// fused: lookup on the folded volume + 1x1 conv (taps_total -> 64) + bias + ReLU, out [P,64] NHWC.
-// LDS holds only the 64 staged volume rows (the feature tile overlays them once the windows are read) and the
-// 1x1 weights come through the scalar cache (wave-uniform addresses), so 5 blocks = 20 waves fit a CU and keep
-// enough 16-B loads in flight for an HBM-bound kernel.
+// fused: lookup on the folded volume + 1x1 conv (taps_total -> 64) + bias + ReLU, out [P,64] NHWC (or split32 / frag16).
+// HBM-bound (one 4*rs-byte volume row in, 256 bytes out per pixel; 3.6 us of VALU work for the 1x1 conv at 296 x 400), so the
+// kernel is built around keeping loads in flight: persistent blocks (3 per CU) walk over 64-pixel tiles; the NEXT tile's rows are
+// requested into registers (16-byte loads, <= 16 per thread) right after the current tile's have been written to LDS, and arrive
+// while the block does the windows and the 1x1 conv of the current tile.  Two barriers per tile: rows -> [B1] -> windows (one
+// level per wave) into a double-buffered feature tile -> [B2] -> conv (1x1 weights through the scalar cache: wave-uniform).
+// <L_, R_> = <3, 5> (the model's 3 levels x 11 taps) compiles the windows and the 33-deep 1x1 conv fully unrolled - the feature
+// vector sits in registers and the scalar weight loads are issued ahead of the FMAs that use them; <0, 0> is the generic form.
+#define LK_MAX_PRE 16      // float4 per thread of one 64-row tile: 64 * (LK_MAX_ROW / 4) / 256
+template <int L_, int R_>
 __global__ __launch_bounds__(256) void lookup_encode_kernel(const float* __restrict__ vol, const float* __restrict__ origin,
                                                             const float* __restrict__ disp, const float* __restrict__ wgt,
                                                             const float* __restrict__ bias, float* __restrict__ out, long P, int D, int rs,
-                                                            float incre, int L, int r, LevelInfo li, int out_split, float out_scale, int img_w) {
+                                                            float incre, int L, int r, LevelInfo li, int out_split, float out_scale, int img_w,
+                                                            int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float lk_smem[];
     const int rsp = rs + 4;
-    const int taps = 2 * r + 1, K = L * taps;
+    const int taps = 2 * r + 1, K = L * taps, FS = K | 1, fstride = LK_PIX * FS;     // (odd pixel stride: conflict-free columns)
     float* rows = lk_smem;                                   // [LK_PIX][rs + 4]
-    float* feats = lk_smem;                                  // [LK_PIX][K + 1], overlays `rows` after the second barrier
-    const long p0 = (long)blockIdx.x * LK_PIX;
-    const int npix = (int)min((long)LK_PIX, P - p0);
-    const float* src = vol + p0 * rs;
-    const int n4 = rs / 4;
-    for (int t = threadIdx.x; t < npix * n4; t += 256) {
-        const int pr = t / n4, q = t - pr * n4;
-        *reinterpret_cast<float4*>(&rows[pr * rsp + 4 * q]) = cer_ld4(src + (long)pr * rs + 4 * q);
-    }
-    __syncthreads();
+    float* feats = lk_smem + LK_PIX * rsp;                   // [2][LK_PIX][FS]
+    const int n4 = rs / 4, npre = (LK_PIX * n4 + 255) / 256;
     const int pix = threadIdx.x & 63;
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id: lookup level, then output-channel group
-    float o[32];
-    const bool active = pix < npix;
-    if (active) {
-        const long p = p0 + pix;
-        const float c = lk_index(disp[p], origin[p], incre, D);
-        for (int lv = grp; lv < L; lv += 4) lk_window(&rows[pix * rsp], li.off[lv], li.len[lv], c / (float)(1 << lv), r, o);
-    }
-    __syncthreads();                                         // every window is in registers: the rows may be overwritten
-    if (active)
-        for (int lv = grp; lv < L; lv += 4)                  // (L <= 4: one level per wave, o[] holds it)
-            for (int j = 0; j < taps; ++j) feats[pix * (K + 1) + lv * taps + j] = o[j];
-    __syncthreads();
-    if (!active) return;
-    float acc[16];
+    float4 pre[LK_MAX_PRE];
+    float pre_d = 0.f, pre_o = 0.f;
+    // float4 number t = tid + 256 i of the tile is (row pr, quad q) = (t / n4, t % n4): walked incrementally (no division per item)
+    const int pr0 = threadIdx.x / n4, q0 = threadIdx.x - pr0 * n4, dpr = 256 / n4, dq = 256 - dpr * n4;
+    auto request = [&](int tile) {                           // rows of `tile` -> registers (zeros past the last pixel)
+        const long p0 = (long)tile * LK_PIX;
+        const int npix = (int)min((long)LK_PIX, P - p0);
+        const float* src = vol + p0 * rs;
+        if (pix < npix) { pre_d = disp[p0 + pix]; pre_o = origin[p0 + pix]; }    // ... and this thread's pixel's window position
+        int pr = pr0, q = q0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = bias[grp * 16 + j];
-    for (int k = 0; k < K; ++k) {
-        const float f = feats[pix * (K + 1) + k];
-        const float* wr = wgt + k * 64 + grp * 16;           // wave-uniform: scalar loads
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = fmaf(f, wr[j], acc[j]);
-    }
-    if (out_split == 2) {
-        // frag16 layout (cer_mvs.h, conv_s16.hip): this thread's 16 channels are group `grp` of its pixel's m-tile: four 16-byte
-        // pieces (hi | lo planes x channel octets) of relu(acc) * out_scale
-        const long p = p0 + pix;
-        const int y = (int)(p / img_w), x = (int)(p - (long)y * img_w);
-        const long mt = (long)(y >> 1) * ((img_w + 15) >> 4) + (x >> 4);
-        char* dst = reinterpret_cast<char*>(out) + ((mt * 4 + grp) * 2) * 1024 + (((y & 1) << 4) | (x & 15)) * 16;
-#pragma unroll
-        for (int j = 0; j < 16; j += 8) {
-            cer_h8 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float xs = fminf(fmaxf(acc[j + e], 0.f) * out_scale, 65504.0f);
-                hi[e] = (_Float16)xs;
-                lo[e] = (_Float16)(xs - (float)hi[e]);
+        for (int i = 0; i < LK_MAX_PRE; ++i) {            // (predicated, not `break`: pre[] must stay in registers)
+            if (i < npre) {
+                pre[i] = pr < npix ? cer_ld4(src + (long)(threadIdx.x + 256 * i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                pr += dpr; q += dq;
+                if (q >= n4) { q -= n4; ++pr; }
             }
-            *reinterpret_cast<cer_h8*>(dst + (j >> 3) * 512) = hi;
-            *reinterpret_cast<cer_h8*>(dst + 1024 + (j >> 3) * 512) = lo;
         }
-        return;
-    }
-    if (out_split) {
-        // split32 layout (cer_mvs.h): per pixel and 32-channel chunk 32 hi halves | 32 lo halves - the corr2 conv then stages
-        // this tensor with plain copies
-        char* dst = reinterpret_cast<char*>(out + (p0 + pix) * 64) + (grp >> 1) * 128 + (grp & 1) * 32;
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) request(tile);
+    for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
+        const long p0 = (long)tile * LK_PIX;
+        const int npix = (int)min((long)LK_PIX, P - p0);
+        const bool active = pix < npix;
+        const float c = active ? lk_index(pre_d, pre_o, incre, D) : 0.f;
+        {
+            int pr = pr0, q = q0;
 #pragma unroll
-        for (int j = 0; j < 16; j += 8) {
-            const float v[8] = {fmaxf(acc[j], 0.f), fmaxf(acc[j + 1], 0.f), fmaxf(acc[j + 2], 0.f), fmaxf(acc[j + 3], 0.f),
-                                fmaxf(acc[j + 4], 0.f), fmaxf(acc[j + 5], 0.f), fmaxf(acc[j + 6], 0.f), fmaxf(acc[j + 7], 0.f)};
-            cer_h8 hi, lo;
-            cer_split8(v, hi, lo);
-            *reinterpret_cast<cer_h8*>(dst + j * 2) = hi;
-            *reinterpret_cast<cer_h8*>(dst + 64 + j * 2) = lo;
+            for (int i = 0; i < LK_MAX_PRE; ++i) {
+                if (i < npre) {
+                    if (pr < LK_PIX) *reinterpret_cast<float4*>(&rows[pr * rsp + 4 * q]) = pre[i];
+                    pr += dpr; q += dq;
+                    if (q >= n4) { q -= n4; ++pr; }
+                }
+            }
         }
-        return;
-    }
-    float* dst = out + (p0 + pix) * 64 + grp * 16;
+        __syncthreads();                                     // [B1] rows complete; the previous tile's windows were read before its [B2]
+        if (tile + (int)gridDim.x < ntiles) request(tile + gridDim.x);
+        float* ft = feats + (it & 1) * fstride;
+        if (active) {
+            if constexpr (L_ > 0) {
+                if (grp < L_) lk_window_ct<R_>(&rows[pix * rsp], li.off[grp], li.len[grp], c / (float)(1 << grp), &ft[pix * FS + grp * taps]);
+            } else {
+                for (int lv = grp; lv < L; lv += 4)        // (straight into the feature tile: no per-thread array)
+                    lk_window(&rows[pix * rsp], li.off[lv], li.len[lv], c / (float)(1 << lv), r, &ft[pix * FS + lv * taps]);
+            }
+        }
+        __syncthreads();                                     // [B2] features complete; rows free for the next tile
+        if (!active) continue;
+        float acc[16];
 #pragma unroll
-    for (int j = 0; j < 16; j += 4)
-        *reinterpret_cast<float4*>(dst + j) =
-            make_float4(fmaxf(acc[j], 0.f), fmaxf(acc[j + 1], 0.f), fmaxf(acc[j + 2], 0.f), fmaxf(acc[j + 3], 0.f));
+        for (int j = 0; j < 16; ++j) acc[j] = bias[grp * 16 + j];
+        if constexpr (L_ > 0) {
+            constexpr int KT = L_ * (2 * R_ + 1);
+            // packed fp32 FMAs (v_pk_fma_f32: two channels per instruction, each component an exact fma like fmaf) - a plain
+            // v_fma_f32 takes 4 cycles per wave and the 33 x 16 of them made this phase the longest of the kernel
+            float f[KT];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) f[k] = ft[pix * FS + k];
+            cer_f2 a2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a2[j] = (cer_f2){acc[2 * j], acc[2 * j + 1]};
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const float* wr = wgt + k * 64 + grp * 16;   // wave-uniform: scalar loads
+                const cer_f2 fk = (cer_f2){f[k], f[k]};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a2[j] = __builtin_elementwise_fma(fk, (cer_f2){wr[2 * j], wr[2 * j + 1]}, a2[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { acc[2 * j] = a2[j].x; acc[2 * j + 1] = a2[j].y; }
+        } else {
+#pragma unroll 3
+            for (int k = 0; k < K; ++k) {
+                const float f = ft[pix * FS + k];
+                const float* wr = wgt + k * 64 + grp * 16;   // wave-uniform: scalar loads
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] = fmaf(f, wr[j], acc[j]);
+            }
+        }
+        if (out_split == 2) {
+            // frag16 layout (cer_mvs.h, conv_s16.hip): this thread's 16 channels are group `grp` of its pixel's m-tile: four 16-byte
+            // pieces (hi | lo planes x channel octets) of relu(acc) * out_scale
+            const unsigned p = (unsigned)(p0 + pix);             // (P < 2^31 is checked by the launcher: 32-bit division)
+            const unsigned y = p / (unsigned)img_w, x = p - y * (unsigned)img_w;
+            const long mt = (long)(y >> 1) * ((img_w + 15) >> 4) + (x >> 4);
+            char* dst = reinterpret_cast<char*>(out) + ((mt * 4 + grp) * 2) * 1024 + (((y & 1) << 4) | (x & 15)) * 16;
+#pragma unroll
+            for (int j = 0; j < 16; j += 8) {
+                cer_h2 h[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {                // packed: relu, scale, clamp, hi = f16(xs), lo = f16(xs - hi)
+                    cer_f2 xs = __builtin_elementwise_max((cer_f2){acc[j + 2 * e], acc[j + 2 * e + 1]}, (cer_f2){0.f, 0.f}) * out_scale;
+                    xs = __builtin_elementwise_min(xs, (cer_f2){65504.0f, 65504.0f});
+                    h[e] = __builtin_convertvector(xs, cer_h2);
+                    l[e] = __builtin_convertvector(xs - __builtin_convertvector(h[e], cer_f2), cer_h2);
+                }
+                *reinterpret_cast<cer_h8*>(dst + (j >> 3) * 512) = (cer_h8){h[0].x, h[0].y, h[1].x, h[1].y, h[2].x, h[2].y, h[3].x, h[3].y};
+                *reinterpret_cast<cer_h8*>(dst + 1024 + (j >> 3) * 512) = (cer_h8){l[0].x, l[0].y, l[1].x, l[1].y, l[2].x, l[2].y, l[3].x, l[3].y};
+            }
+        } else if (out_split) {
+            // split32 layout (cer_mvs.h): per pixel and 32-channel chunk 32 hi halves | 32 lo halves - the corr2 conv then stages
+            // this tensor with plain copies
+            char* dst = reinterpret_cast<char*>(out + (p0 + pix) * 64) + (grp >> 1) * 128 + (grp & 1) * 32;
+#pragma unroll
+            for (int j = 0; j < 16; j += 8) {
+                const float v[8] = {fmaxf(acc[j], 0.f), fmaxf(acc[j + 1], 0.f), fmaxf(acc[j + 2], 0.f), fmaxf(acc[j + 3], 0.f),
+                                    fmaxf(acc[j + 4], 0.f), fmaxf(acc[j + 5], 0.f), fmaxf(acc[j + 6], 0.f), fmaxf(acc[j + 7], 0.f)};
+                cer_h8 hi, lo;
+                cer_split8(v, hi, lo);
+                *reinterpret_cast<cer_h8*>(dst + j * 2) = hi;
+                *reinterpret_cast<cer_h8*>(dst + 64 + j * 2) = lo;
+            }
+        } else {
+            float* dst = out + (p0 + pix) * 64 + grp * 16;
+#pragma unroll
+            for (int j = 0; j < 16; j += 4)
+                *reinterpret_cast<float4*>(dst + j) =
+                    make_float4(fmaxf(acc[j], 0.f), fmaxf(acc[j + 1], 0.f), fmaxf(acc[j + 2], 0.f), fmaxf(acc[j + 3], 0.f));
+        }
+    }
 }
 
 static int level_info(int D, int rs, int L, int r, LevelInfo* li) {
@@ -199,15 +274,30 @@ extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, cons
                                      int log2s_out, int img_w, void* stream) {
     if (!vol || !origin || !disp || !w || !b || !out || P <= 0 || D <= 0) return CER_EINVAL;
     if (Cout != 64 || num_levels > 4) return CER_ESHAPE;
-    if (out_split == 2 && (img_w <= 0 || P % img_w != 0)) return CER_ESHAPE;
+    if (out_split == 2 && (img_w <= 0 || P % img_w != 0 || P >= (1L << 31))) return CER_ESHAPE;
     if (!cer_aligned16(vol) || !cer_aligned16(out)) return CER_EALIGN;
     LevelInfo li;
     int rc = level_info(D, row_stride, num_levels, radius, &li);
     if (rc) return rc;
-    hipLaunchKernelGGL(lookup_encode_kernel, dim3((unsigned)((P + LK_PIX - 1) / LK_PIX)), dim3(256),
-                       sizeof(float) * LK_PIX * (row_stride + 4 > num_levels * (2 * radius + 1) + 1 ? row_stride + 4 : num_levels * (2 * radius + 1) + 1),
-                       (hipStream_t)stream, vol, origin, disp, w,
-                       b, out, P, D, row_stride, (float)incre, num_levels, radius, li, out_split, ldexpf(1.0f, log2s_out), img_w);
+    const int K = num_levels * (2 * radius + 1);
+    const long ntiles = (P + LK_PIX - 1) / LK_PIX;
+    if (ntiles >= (1L << 30)) return CER_ESHAPE;
+    const size_t smem = sizeof(float) * LK_PIX * ((size_t)(row_stride + 4) + 2 * (K | 1));
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    const long resident = (long)ncu * (smem <= 50 * 1024 ? 3 : smem <= 76 * 1024 ? 2 : 1);
+    const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);
+    if (num_levels == 3 && radius == 5)
+        hipLaunchKernelGGL((lookup_encode_kernel<3, 5>), dim3(grid), dim3(256), smem, (hipStream_t)stream, vol, origin, disp, w, b, out, P, D, row_stride,
+                           (float)incre, num_levels, radius, li, out_split, ldexpf(1.0f, log2s_out), img_w, (int)ntiles);
+    else
+        hipLaunchKernelGGL((lookup_encode_kernel<0, 0>), dim3(grid), dim3(256), smem, (hipStream_t)stream, vol, origin, disp, w, b, out, P, D, row_stride,
+                           (float)incre, num_levels, radius, li, out_split, ldexpf(1.0f, log2s_out), img_w, (int)ntiles);
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }
