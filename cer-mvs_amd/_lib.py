@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CER_MVS_LIB") or os.path.join(_HERE, "csrc", "libcermvs.so")
-ABI_VERSION = 1025
+ABI_VERSION = 1026
 CONV_MAX_SRC = 4
 EPI_LINEAR, EPI_RELU, EPI_GATES, EPI_GRU, EPI_DELTA = 0, 1, 2, 3, 4
 EPI_OUT_SPLIT, EPI_AUX_SPLIT = 0x100, 0x200       # cer_mvs.h: split32 activation layout flags, or-ed into `epi`
@@ -64,6 +64,10 @@ _SIGNATURES = {
     "cer_delta_sum_f32": (_I, [_P, _I, _F, _P, _P, _P, _I, _I, _P]),
     "cer_delta_tail_f32": (_I, [_P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "cer_enc_stem_tiles": (_I, [_I, _I]),
+    "cer_enc_stem_s16_packed_size": (_L, []),
+    "cer_enc_stem_s16_tiles": (_I, [_I, _I]),
+    "cer_enc_stem_s16_pack": (_I, [_P, _P, _P]),
+    "cer_enc_stem_s16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cer_enc_stem_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cer_enc_conv_packed_size": (_L, [_I, _I, _I]),
     "cer_enc_conv_pack": (_I, [_P, _P, _I, _I, _I]),

@@ -11,6 +11,8 @@ import torch
 
 from . import _lib as L
 
+STEM_MFMA = True          # 7x7 stem on the matrix cores (csrc/enc_stem.hip); False: the direct fp32 kernel (exact fmaf chain)
+
 
 class _Conv:
     def __init__(self, conv, device):
@@ -40,6 +42,12 @@ class HipEncoder:
         w = enc.conv1.weight.detach().to("cpu", torch.float32)
         self.stem_w = w.permute(1, 2, 3, 0).reshape(147, 32).contiguous().to(device)
         self.stem_b = enc.conv1.bias.detach().to(device, torch.float32).contiguous()
+        lib = L.load()
+        wc = w.contiguous()
+        packed = torch.empty(lib.cer_enc_stem_s16_packed_size(), dtype=torch.float16)
+        k = ctypes.c_int(0)
+        L.check(lib.cer_enc_stem_s16_pack(ctypes.c_void_p(wc.data_ptr()), ctypes.c_void_p(packed.data_ptr()), ctypes.byref(k)), "enc_stem_s16_pack")
+        self.stem_packed, self.stem_log2s = packed.to(device), int(k.value)
         self.blocks = []
         for layer in (enc.layer1, enc.layer2):
             for blk in layer:
@@ -86,10 +94,17 @@ class HipEncoder:
         ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         raw0 = torch.empty(N, ho * wo, 32, device=self.device, dtype=torch.float32)
         part = None
-        if self.inorm:
-            part = torch.empty(N, lib.cer_enc_stem_tiles(ho, wo), 32, 2, device=self.device, dtype=torch.float32)
-        L.check(lib.cer_enc_stem_f32(L.dev_ptr(x, "images"), L.dev_ptr(self.stem_w, "w"), L.dev_ptr(self.stem_b, "b"), L.dev_ptr(raw0, "out"),
-                                     L.dev_ptr(part, "part"), N, H, W, int(bool(raw)), L.cur_stream()), "enc_stem")
+        if STEM_MFMA:
+            if self.inorm:
+                part = torch.empty(N, lib.cer_enc_stem_s16_tiles(ho, wo), 32, 2, device=self.device, dtype=torch.float32)
+            L.check(lib.cer_enc_stem_s16(L.dev_ptr(x, "images"), L.dev_ptr(self.stem_packed, "w", torch.float16), L.dev_ptr(self.stem_b, "b"),
+                                         L.dev_ptr(raw0, "out"), L.dev_ptr(part, "part"), N, H, W, int(bool(raw)), self.stem_log2s, L.cur_stream()),
+                    "enc_stem_s16")
+        else:
+            if self.inorm:
+                part = torch.empty(N, lib.cer_enc_stem_tiles(ho, wo), 32, 2, device=self.device, dtype=torch.float32)
+            L.check(lib.cer_enc_stem_f32(L.dev_ptr(x, "images"), L.dev_ptr(self.stem_w, "w"), L.dev_ptr(self.stem_b, "b"), L.dev_ptr(raw0, "out"),
+                                         L.dev_ptr(part, "part"), N, H, W, int(bool(raw)), L.cur_stream()), "enc_stem")
         st0 = self._stats(part, N, part.shape[1], 32, ho * wo) if part is not None else None
         # `cur` = (tensor, stats, relu): the block input is relu(norm(tensor)) when stats/relu are set, else the tensor itself
         cur, cur_st, cur_relu, h, w, C = raw0, st0, True, ho, wo, 32

@@ -317,6 +317,15 @@ int cer_norm_act_f32(const float* x, const float* x_stats, const float* res, con
  *                       2 relu b, 4 relu sum  (core/extractor.py:49-57).
  * Weights: cer_enc_conv_pack (OIHW -> fragment order; size in 2-byte halves from cer_enc_conv_packed_size). */
 int cer_enc_stem_tiles(int ho, int wo);
+/* The stem on the matrix cores (csrc/enc_stem.hip): same operands and outputs as cer_enc_stem_f32, single-accumulator split-f16
+ * MFMA arithmetic (fp32-class).  Weights are packed once on the host from OIHW [32][3][7][7] (cer_enc_stem_s16_pack returns the
+ * power-of-two weight scale it applied in *log2s_w; packed buffer: cer_enc_stem_s16_packed_size() halves); stats_partial is
+ * [N][cer_enc_stem_s16_tiles(ho, wo)][32][2] (8 x 32-pixel output tiles). */
+long cer_enc_stem_s16_packed_size(void);
+int cer_enc_stem_s16_tiles(int ho, int wo);
+int cer_enc_stem_s16_pack(const float* w_oihw, void* packed, int* log2s_w);
+int cer_enc_stem_s16(const float* images, const void* packed_w, const float* bias, float* out, float* stats_partial, int N, int H, int W,
+                     int normalize, int log2s_w, void* stream);
 int cer_enc_stem_f32(const float* images, const float* wgt_k_co, const float* bias, float* out, float* stats_partial,
                      int N, int H, int W, int normalize, void* stream);
 long cer_enc_conv_packed_size(int Cout, int Cin, int taps);

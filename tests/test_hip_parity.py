@@ -445,6 +445,55 @@ def test_hip_encoder_engine_matches_oracle(dev, which, size):
     assert rel_l1(got, ref) < 1e-5
 
 
+@pytest.mark.parametrize("size", [(64, 96), (70, 130), (37, 51)])
+@pytest.mark.parametrize("raw", [False, True])
+def test_stem_on_matrix_cores(dev, size, raw):
+    """7x7 stride-2 stem (core/extractor.py:81,145; raw: with the x * 2/255 - 1 of core/raft.py:40-41 folded in): the MFMA kernel
+    (csrc/enc_stem.hip: K padded to 7 x 32, split-f16 single accumulator) and the direct fp32 kernel against an fp64 conv, incl.
+    ragged sizes (partial tiles, odd widths) and the per-tile (sum, sum of squares) records of the following instance norm."""
+    import ctypes
+    from cer_mvs_amd import _lib as L
+    H, W = size
+    N = 3
+    lib = L.load()
+    w = hashed((32, 3, 7, 7), 401, -0.4, 0.4)
+    b = hashed((32,), 402, -0.2, 0.2)
+    x = hashed((N, 3, H, W), 403, 0.0, 255.0) if raw else hashed((N, 3, H, W), 403, -1.0, 1.0)
+    xn = (x.double() * (2.0 / 255.0) - 1.0) if raw else x.double()
+    ref = torch.nn.functional.conv2d(xn, w.double(), b.double(), stride=2, padding=3)               # [N,32,ho,wo]
+    ho, wo = ref.shape[2], ref.shape[3]
+    ref_cl = ref.permute(0, 2, 3, 1).reshape(N, ho * wo, 32)
+    mag = torch.nn.functional.conv2d(xn.abs(), w.double().abs(), b.double().abs(), stride=2, padding=3).permute(0, 2, 3, 1).reshape(N, ho * wo, 32)
+    packed = torch.empty(lib.cer_enc_stem_s16_packed_size(), dtype=torch.float16)
+    k = ctypes.c_int(0)
+    L.check(lib.cer_enc_stem_s16_pack(ctypes.c_void_p(w.contiguous().data_ptr()), ctypes.c_void_p(packed.data_ptr()), ctypes.byref(k)), "pack")
+    xd, bd = x.to(dev).contiguous(), b.to(dev)
+    outs = {}
+    # MFMA
+    nt = lib.cer_enc_stem_s16_tiles(ho, wo)
+    out = torch.full((N, ho * wo, 32), float("nan"), device=dev)
+    part = torch.full((N, nt, 32, 2), float("nan"), device=dev)
+    L.check(lib.cer_enc_stem_s16(L.dev_ptr(xd, "x"), L.dev_ptr(packed.to(dev), "w", torch.float16), L.dev_ptr(bd, "b"), L.dev_ptr(out, "out"),
+                                 L.dev_ptr(part, "part"), N, H, W, int(raw), int(k.value), L.cur_stream()), "stem_s16")
+    outs["mfma"] = (out.cpu(), part.cpu())
+    # direct fp32
+    nt2 = lib.cer_enc_stem_tiles(ho, wo)
+    out2 = torch.full((N, ho * wo, 32), float("nan"), device=dev)
+    part2 = torch.full((N, nt2, 32, 2), float("nan"), device=dev)
+    wk = w.permute(1, 2, 3, 0).reshape(147, 32).contiguous().to(dev)
+    L.check(lib.cer_enc_stem_f32(L.dev_ptr(xd, "x"), L.dev_ptr(wk, "w"), L.dev_ptr(bd, "b"), L.dev_ptr(out2, "out"), L.dev_ptr(part2, "part"),
+                                 N, H, W, int(raw), L.cur_stream()), "stem_f32")
+    outs["fp32"] = (out2.cpu(), part2.cpu())
+    for name, (o, p_) in outs.items():
+        assert torch.isfinite(o).all() and torch.isfinite(p_).all(), name
+        err = ((o.double() - ref_cl).abs() / mag).max().item()
+        assert err < 2e-6, (name, err)                                       # fp32-class: relative to sum |x||w|
+        tot = p_.double().sum(1)                                             # [N,32,2]
+        assert torch.allclose(tot[..., 0], o.double().sum(1), rtol=1e-5, atol=1e-3), name
+        assert torch.allclose(tot[..., 1], (o.double() ** 2).sum(1), rtol=1e-5, atol=1e-3), name
+    assert rel_l1(outs["mfma"][0], outs["fp32"][0]) < 1e-6
+
+
 def test_encoder_engine_batch_invariance_at_tnt_size(dev):
     """BASELINE.json configs[2] size (3840x2160, 16 images per fnet launch): layer-1 activations are 16 x 1080 x 1920 x 32
     floats = 4.2 GB, i.e. element offsets beyond 2^31 bytes.  Instance norm is per image, so the batched launch must
