@@ -18,5 +18,6 @@ run conv3x3_gru_q       "conv3x3_s16_kernel<2, 2, 4, 3>" python tools/bench_conv
 run conv3x3_delta_fused "conv3x3_s16_kernel<1, 4, 4, 4>" python tools/bench_conv_s16.py --only "delta" --rounds 1 --reps 1
 run conv3x3_relu_64     "conv3x3_s16_kernel<2, 2, 4, 1>" python tools/bench_conv_s16.py --only "corr2" --rounds 1 --reps 1
 run lookup_encode       "lookup_encode"                  python tools/prof_conv.py lookup --reps 1
+run enc_stem_s16        "enc_stem_s16"                   python tools/prof_conv.py stem --reps 1
 run cost_build_stage0   "cost_build"                     python tools/prof_conv.py build0 --reps 1
 run cost_build_stage1   "cost_build"                     python tools/prof_conv.py build1 --reps 1

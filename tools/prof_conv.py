@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Minimal launcher for profiling single kernels at cfg2 shapes on random data (no encoders, no MIOpen):
-usage: python tools/prof_conv.py [zr|q|d1|c2|lookup|tail|build0|build1] [--reps N] [--mode f16x3|fp32]"""
+usage: python tools/prof_conv.py [zr|q|d1|c2|lookup|stem|tail|build0|build1] [--reps N] [--mode f16x3|fp32]"""
 import argparse
 import os
 import sys
@@ -71,6 +71,21 @@ def main():
         out = torch.empty(ops.s16_pixels(h, w), 64, device=dev)       # the shipped form: frag16 output for the s16 convolutions
         org, dd = disp.clone(), disp + 0.0002 * torch.rand(P, device=dev)
         run(lambda: ops.lookup_encode(vol, org, dd, w0t, b0, 64, 0.0025 / 64, 3, 5, out=out, out_split=2, log2s=L.S16_RELU, img_w=w))
+    elif args.what == "stem":
+        import ctypes
+        lib = L.load()
+        N, H, W = 11, 4 * h, 4 * w
+        x = torch.rand(N, 3, H, W, device=dev) * 255.0
+        wt = (torch.rand(32, 3, 7, 7) - 0.5) * 0.4
+        packed = torch.empty(lib.cer_enc_stem_s16_packed_size(), dtype=torch.float16)
+        k = ctypes.c_int(0)
+        L.check(lib.cer_enc_stem_s16_pack(ctypes.c_void_p(wt.data_ptr()), ctypes.c_void_p(packed.data_ptr()), ctypes.byref(k)), "pack")
+        packed, b = packed.to(dev), r(32)
+        ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = torch.empty(N, ho * wo, 32, device=dev)
+        part = torch.empty(N, lib.cer_enc_stem_s16_tiles(ho, wo), 32, 2, device=dev)
+        run(lambda: L.check(lib.cer_enc_stem_s16(L.dev_ptr(x, "x"), L.dev_ptr(packed, "w", torch.float16), L.dev_ptr(b, "b"), L.dev_ptr(out, "out"),
+                                                 L.dev_ptr(part, "part"), N, H, W, 1, int(k.value), L.cur_stream()), "stem"))
     elif args.what in ("build0", "build1"):
         V = 10
         f1 = r(P, 64) * 0.25
