@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CER_MVS_LIB") or os.path.join(_HERE, "csrc", "libcermvs.so")
-ABI_VERSION = 1026
+ABI_VERSION = 1027
 CONV_MAX_SRC = 4
 EPI_LINEAR, EPI_RELU, EPI_GATES, EPI_GRU, EPI_DELTA = 0, 1, 2, 3, 4
 EPI_OUT_SPLIT, EPI_AUX_SPLIT = 0x100, 0x200       # cer_mvs.h: split32 activation layout flags, or-ed into `epi`
@@ -93,6 +93,8 @@ _SIGNATURES = {
     "cer_s16_padded_pixels": (_L, [_I, _I]),
     "cer_s16_layout_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cer_s16_rows_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "cer_multires_merge_f32": (_I, [_P, _I, _I, _P, _I, _I, _D, _P, _P]),
+    "cer_resize_linear_f32": (_I, [_P, _I, _I, _P, _I, _I, _P]),
     "cer_geo_consistency_f32": (_I, [_P, _P, _P, _I, _I, _I, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 

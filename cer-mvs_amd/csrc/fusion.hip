@@ -129,3 +129,60 @@ extern "C" int cer_geo_consistency_f32(const float* depth_ref, const float* dept
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }
+
+// ---- multi-resolution merge (reference: multires.py:16-40): the scale-1 depth map resized to the scale-2 map's size, then
+//   im = where(|im1 - im2| < th * im1, im2, im1)
+// and an optional down-sampling of the result.  Both resizes are cv2.resize(..., INTER_LINEAR) on float32 images, restated here:
+// source coordinate fx = float((dx + 0.5) * (src / dst) - 0.5) (the product in double), sx = floor(fx), fx -= sx; sx < 0 -> (0, 0);
+// sx >= src - 1 -> (src - 1, 0) with both taps on the last pixel; horizontal pass s[sx] * (1 - fx) + s[sx + 1] * fx on the two
+// source rows, then the vertical pass with the row weights - float products and sums in that order (no fma: -ffp-contract=off).
+__device__ __forceinline__ void mr_coord(int d, double scale, int ssize, int& s0, int& s1, float& f) {
+    float fx = (float)(((double)d + 0.5) * scale - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { sx = 0; fx = 0.f; }
+    if (sx >= ssize - 1) { sx = ssize - 1; fx = 0.f; s0 = sx; s1 = sx; f = fx; return; }
+    s0 = sx; s1 = sx + 1; f = fx;
+}
+__device__ __forceinline__ float mr_sample(const float* __restrict__ src, int h, int w, int y, int x, double sy, double sx) {
+    int x0, x1, y0, y1;
+    float fx, fy;
+    mr_coord(x, sx, w, x0, x1, fx);
+    mr_coord(y, sy, h, y0, y1, fy);
+    const float a0 = 1.0f - fx, a1 = fx, b0 = 1.0f - fy, b1 = fy;
+    const float r0 = src[(long)y0 * w + x0] * a0 + src[(long)y0 * w + x1] * a1;
+    const float r1 = src[(long)y1 * w + x0] * a0 + src[(long)y1 * w + x1] * a1;
+    return r0 * b0 + r1 * b1;
+}
+__global__ __launch_bounds__(256) void multires_merge_kernel(const float* __restrict__ im1, int h1, int w1, const float* __restrict__ im2, int h2,
+                                                             int w2, float th, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)h2 * w2) return;
+    const int y = (int)(i / w2), x = (int)(i - (long)y * w2);
+    const float a = (h1 == h2 && w1 == w2) ? im1[i] : mr_sample(im1, h1, w1, y, x, (double)h1 / h2, (double)w1 / w2);
+    const float b = im2[i];
+    out[i] = (fabsf(a - b) < th * a) ? b : a;              // (NaN compares false: keeps the scale-1 value like np.where)
+}
+__global__ __launch_bounds__(256) void resize_linear_kernel(const float* __restrict__ src, int h, int w, float* __restrict__ dst, int ho, int wo) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)ho * wo) return;
+    const int y = (int)(i / wo), x = (int)(i - (long)y * wo);
+    dst[i] = mr_sample(src, h, w, y, x, (double)h / ho, (double)w / wo);
+}
+
+extern "C" int cer_multires_merge_f32(const float* im1, int h1, int w1, const float* im2, int h2, int w2, double th, float* out, void* stream) {
+    if (!im1 || !im2 || !out || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0) return CER_EINVAL;
+    const long P = (long)h2 * w2;
+    hipLaunchKernelGGL(multires_merge_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, im1, h1, w1, im2, h2, w2,
+                       (float)th, out);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}
+
+extern "C" int cer_resize_linear_f32(const float* src, int h, int w, float* dst, int ho, int wo, void* stream) {
+    if (!src || !dst || h <= 0 || w <= 0 || ho <= 0 || wo <= 0) return CER_EINVAL;
+    const long P = (long)ho * wo;
+    hipLaunchKernelGGL(resize_linear_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, h, w, dst, ho, wo);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}

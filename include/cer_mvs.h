@@ -365,6 +365,12 @@ int cer_geo_consistency_f32(const float* depth_ref, const float* depth_src, cons
                             unsigned char* masks9, float* depth_reprojected, float* x_src, float* y_src, float* rel_diff,
                             void* stream);
 
+/* Multi-resolution merge of two depth maps (reference: multires.py:16-40): out [h2, w2] = where(|r - im2| < th * r, im2, r) with
+ * r = im1 [h1, w1] resized to [h2, w2] like cv2.resize(INTER_LINEAR) on float32; cer_resize_linear_f32 is that resize alone (the
+ * reference's optional down_sample step).  Device pointers, fp32, row-major. */
+int cer_multires_merge_f32(const float* im1, int h1, int w1, const float* im2, int h2, int w2, double th, float* out, void* stream);
+int cer_resize_linear_f32(const float* src, int h, int w, float* dst, int ho, int wo, void* stream);
+
 /* Multi-GPU row-slab exchange (cer-mvs_amd/slab.py): up to CER_COPY_MAX_SEG contiguous fp32 ranges copied by ONE launch -
  * the pack of a rank's (net, disp) border strips into its send buffer, and the refresh of its halo rows from the gathered
  * strips.  n[i] floats from src[i] to dst[i]; n[i] == 0 skips a segment.  Device pointers; ranges must not overlap. */
