@@ -95,29 +95,36 @@ class DistExchange:
         buf = bufs[0]
         g, G = self.ranks[0], self.G
         half = buf.numel() // 2
-        key = (buf.numel(), buf.device, buf.dtype)
+        key = (buf.data_ptr(), buf.numel(), buf.device, buf.dtype)
         if getattr(self, "_nb_key", None) != key:
+            # persistent receive buffers and - the send buffer is persistent too - the P2P op list, built once per forward
             self._nb_key = key
             self._nb = (torch.empty(half, device=buf.device, dtype=buf.dtype), torch.empty(half, device=buf.device, dtype=buf.dtype))
-        rprev, rnext = self._nb
-        ranks = dist.get_process_group_ranks(self.group) if self.group is not None else list(range(G))
-        # RCCL orders the transfers after the launch stream's kernels by itself.  gloo (the transport of the multi-process tests)
-        # has no stream semantics for point-to-point device buffers: there the strips are staged through host tensors.
-        staged = buf.is_cuda and dist.get_backend(self.group) != "nccl"
-        src = buf.cpu() if staged else buf
-        dprev, dnext = (torch.empty(half, dtype=buf.dtype), torch.empty(half, dtype=buf.dtype)) if staged else (rprev, rnext)
-        ops_ = []
-        if g > 0:
-            ops_ += [dist.P2POp(dist.isend, src[:half], ranks[g - 1], self.group), dist.P2POp(dist.irecv, dprev, ranks[g - 1], self.group)]
-        if g < G - 1:
-            ops_ += [dist.P2POp(dist.isend, src[half:], ranks[g + 1], self.group), dist.P2POp(dist.irecv, dnext, ranks[g + 1], self.group)]
-        for w_ in (dist.batch_isend_irecv(ops_) if ops_ else []):
-            w_.wait()
-        if staged:
+            ranks = dist.get_process_group_ranks(self.group) if self.group is not None else list(range(G))
+            # RCCL orders the transfers after the launch stream's kernels by itself.  gloo (the transport of the multi-process tests)
+            # has no stream semantics for point-to-point device buffers: there the strips are staged through host tensors.
+            self._nb_staged = buf.is_cuda and dist.get_backend(self.group) != "nccl"
+            if self._nb_staged:
+                self._nb_host = (torch.empty(buf.numel(), dtype=buf.dtype), torch.empty(half, dtype=buf.dtype), torch.empty(half, dtype=buf.dtype))
+                src, dprev, dnext = self._nb_host
+            else:
+                src, (dprev, dnext) = buf, self._nb
+            ops_ = []
             if g > 0:
-                rprev.copy_(dprev)
+                ops_ += [dist.P2POp(dist.isend, src[:half], ranks[g - 1], self.group), dist.P2POp(dist.irecv, dprev, ranks[g - 1], self.group)]
             if g < G - 1:
-                rnext.copy_(dnext)
+                ops_ += [dist.P2POp(dist.isend, src[half:], ranks[g + 1], self.group), dist.P2POp(dist.irecv, dnext, ranks[g + 1], self.group)]
+            self._nb_ops = ops_
+        rprev, rnext = self._nb
+        if self._nb_staged:
+            self._nb_host[0].copy_(buf)
+        for w_ in (dist.batch_isend_irecv(self._nb_ops) if self._nb_ops else []):
+            w_.wait()
+        if self._nb_staged:
+            if g > 0:
+                rprev.copy_(self._nb_host[1])
+            if g < G - 1:
+                rnext.copy_(self._nb_host[2])
         return [(rprev if g > 0 else None, rnext if g < G - 1 else None)]
 
     def all_gather(self, tensors):
