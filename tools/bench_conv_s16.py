@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--mt", type=int, default=0)
     ap.add_argument("--only", default="")
     ap.add_argument("--json", default="")
+    ap.add_argument("--no-init", action="store_true", help="experiment: run the gate / GRU convs without the hoisted init term")
     args = ap.parse_args()
     h, w = (int(x) for x in args.size.split("x"))
     P = h * w
@@ -51,7 +52,7 @@ def main():
     # s16 buffers
     net_s, c1_s = ops.to_frag16(net, h, w, U), ops.to_frag16(c1, h, w, R)
     c2_s, z_s, rn_s, net2_s, T_s = es(64), es(64), es(64), es(64), torch.empty(2, 9, P, device=dev)
-    initzr_s, initq_s = acc32(initzr), acc32(initq)
+    initzr_s, initq_s = (None, None) if args.no_init else (acc32(initzr), acc32(initq))
     # f16x3 buffers (split32)
     net_o, c1_o = ops.split32(net), ops.split32(c1)
     c2_o, z_o, rn_o, net2_o, T_o = e(64), e(64), e(64), e(64), torch.empty(2, 9, P, device=dev)
