@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--mode", default="f16x3")
     ap.add_argument("--hw", default="296x400")
+    ap.add_argument("--baseline-scale", type=float, default=1.0, help="build0/build1: scales the views' translations (0: every hypothesis hits the pixel's own texel)")
     args = ap.parse_args()
     h, w = (int(x) for x in args.hw.split("x"))
     P = h * w
@@ -92,8 +93,8 @@ def main():
         f2 = fmaps_to_nhwc(torch.randn(V, 64, h, w, device=dev), border=2)
         Pij = torch.eye(4).repeat(V, 1, 1)
         for v in range(V):
-            Pij[v, 0, 3] = 30000.0 * (v + 1) * (1 if v % 2 else -1)
-            Pij[v, 1, 3] = 900.0 * (v - 4)
+            Pij[v, 0, 3] = args.baseline_scale * 30000.0 * (v + 1) * (1 if v % 2 else -1)
+            Pij[v, 1, 3] = args.baseline_scale * 900.0 * (v - 4)
         Pij = Pij.to(dev)
         if args.what == "build0":
             run(lambda: ops.cost_build(f1, f2, Pij, torch.zeros(P, device=dev), 64, 0.0025 / 64, True, h, w, 3, fold=True))
