@@ -43,23 +43,6 @@ __device__ __forceinline__ void lk_window(const float* __restrict__ row, int off
     }
 }
 
-// the same with a compile-time radius: the 2r + 2 row reads are issued back to back, o has stride 1
-template <int R_>
-__device__ __forceinline__ void lk_window_ct(const float* __restrict__ row, int off, int len, float x, float* __restrict__ o) {
-    const float fx = floorf(x);
-    const float w = x - fx;
-    const bool in_range = fx < (float)(len + R_ + 1);
-    const int i0 = in_range ? (int)fx - R_ : 0;
-    float v[2 * R_ + 2];
-#pragma unroll
-    for (int j = 0; j < 2 * R_ + 2; ++j) {
-        const int i = i0 + j;
-        v[j] = (in_range && i >= 0 && i < len) ? row[off + i] : 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 2 * R_ + 1; ++j) o[j] = v[j] * (1.0f - w) + v[j + 1] * w;
-}
-
 // out [nv, L*(2r+1), P] planar
 __global__ __launch_bounds__(256) void lookup_kernel(const float* __restrict__ vol, const float* __restrict__ origin,
                                                      const float* __restrict__ disp, long dvs, float* __restrict__ out, long P, int D,
@@ -95,15 +78,15 @@ __global__ __launch_bounds__(256) void lookup_kernel(const float* __restrict__ v
 }
 
 // fused: lookup on the folded volume + 1x1 conv (taps_total -> 64) + bias + ReLU, out [P,64] NHWC (or split32 / frag16).
-// HBM-bound (one 4*rs-byte volume row in, 256 bytes out per pixel; 3.6 us of VALU work for the 1x1 conv at 296 x 400), so the
-// kernel is built around keeping loads in flight: persistent blocks (3 per CU) walk over 64-pixel tiles; the NEXT tile's rows are
-// requested into registers (16-byte loads, <= 16 per thread) right after the current tile's have been written to LDS, and arrive
-// while the block does the windows and the 1x1 conv of the current tile.  Two barriers per tile: rows -> [B1] -> windows (one
-// level per wave) into a double-buffered feature tile -> [B2] -> conv (1x1 weights through the scalar cache: wave-uniform).
-// <L_, R_> = <3, 5> (the model's 3 levels x 11 taps) compiles the windows and the 33-deep 1x1 conv fully unrolled - the feature
-// vector sits in registers and the scalar weight loads are issued ahead of the FMAs that use them; <0, 0> is the generic form.
+// HBM-bound (one 4*rs-byte volume row in, 256 bytes out per pixel), so the kernel is built around keeping loads in flight:
+// persistent blocks (3 per CU) walk over 64-pixel tiles; the NEXT tile's rows are requested into registers (16-byte loads, <= 16
+// per thread) right after the current tile's have been written to LDS, and arrive while the block does the windows and the 1x1
+// conv of the current tile.  Two barriers per tile: rows -> [B1] -> windows (one level per wave) into a double-buffered feature
+// tile -> [B2] -> conv (1x1 weights through the scalar cache: wave-uniform).
+// (A variant with the 3 x 11 windows and the 33-deep conv unrolled at compile time was 1 us faster stand-alone, no faster in the
+// pipeline, and produced intermittently wrong features when a second process shared the GPU - 17 of 70 two-process runs against
+// 0 of 130 for this form; the cause was narrowed to the unrolled window code but not found.  It was removed.)
 #define LK_MAX_PRE 16      // float4 per thread of one 64-row tile: 64 * (LK_MAX_ROW / 4) / 256
-template <int L_, int R_>
 __global__ __launch_bounds__(256) void lookup_encode_kernel(const float* __restrict__ vol, const float* __restrict__ origin,
                                                             const float* __restrict__ disp, const float* __restrict__ wgt,
                                                             const float* __restrict__ bias, float* __restrict__ out, long P, int D, int rs,
@@ -157,46 +140,20 @@ __global__ __launch_bounds__(256) void lookup_encode_kernel(const float* __restr
         __syncthreads();                                     // [B1] rows complete; the previous tile's windows were read before its [B2]
         if (tile + (int)gridDim.x < ntiles) request(tile + gridDim.x);
         float* ft = feats + (it & 1) * fstride;
-        if (active) {
-            if constexpr (L_ > 0) {
-                if (grp < L_) lk_window_ct<R_>(&rows[pix * rsp], li.off[grp], li.len[grp], c / (float)(1 << grp), &ft[pix * FS + grp * taps]);
-            } else {
-                for (int lv = grp; lv < L; lv += 4)        // (straight into the feature tile: no per-thread array)
-                    lk_window(&rows[pix * rsp], li.off[lv], li.len[lv], c / (float)(1 << lv), r, &ft[pix * FS + lv * taps]);
-            }
-        }
+        if (active)
+            for (int lv = grp; lv < L; lv += 4)            // (straight into the feature tile: no per-thread array)
+                lk_window(&rows[pix * rsp], li.off[lv], li.len[lv], c / (float)(1 << lv), r, &ft[pix * FS + lv * taps]);
         __syncthreads();                                     // [B2] features complete; rows free for the next tile
         if (!active) continue;
         float acc[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = bias[grp * 16 + j];
-        if constexpr (L_ > 0) {
-            constexpr int KT = L_ * (2 * R_ + 1);
-            // packed fp32 FMAs (v_pk_fma_f32: two channels per instruction, each component an exact fma like fmaf) - a plain
-            // v_fma_f32 takes 4 cycles per wave and the 33 x 16 of them made this phase the longest of the kernel
-            float f[KT];
-#pragma unroll
-            for (int k = 0; k < KT; ++k) f[k] = ft[pix * FS + k];
-            cer_f2 a2[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a2[j] = (cer_f2){acc[2 * j], acc[2 * j + 1]};
-#pragma unroll
-            for (int k = 0; k < KT; ++k) {
-                const float* wr = wgt + k * 64 + grp * 16;   // wave-uniform: scalar loads
-                const cer_f2 fk = (cer_f2){f[k], f[k]};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) a2[j] = __builtin_elementwise_fma(fk, (cer_f2){wr[2 * j], wr[2 * j + 1]}, a2[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { acc[2 * j] = a2[j].x; acc[2 * j + 1] = a2[j].y; }
-        } else {
 #pragma unroll 3
-            for (int k = 0; k < K; ++k) {
-                const float f = ft[pix * FS + k];
-                const float* wr = wgt + k * 64 + grp * 16;   // wave-uniform: scalar loads
+        for (int k = 0; k < K; ++k) {
+            const float f = ft[pix * FS + k];
+            const float* wr = wgt + k * 64 + grp * 16;       // wave-uniform: scalar loads
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc[j] = fmaf(f, wr[j], acc[j]);
-            }
+            for (int j = 0; j < 16; ++j) acc[j] = fmaf(f, wr[j], acc[j]);
         }
         if (out_split == 2) {
             // frag16 layout (cer_mvs.h, conv_s16.hip): this thread's 16 channels are group `grp` of its pixel's m-tile: four 16-byte
@@ -292,12 +249,8 @@ extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, cons
     }
     const long resident = (long)ncu * (smem <= 50 * 1024 ? 3 : smem <= 76 * 1024 ? 2 : 1);
     const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);
-    if (num_levels == 3 && radius == 5)
-        hipLaunchKernelGGL((lookup_encode_kernel<3, 5>), dim3(grid), dim3(256), smem, (hipStream_t)stream, vol, origin, disp, w, b, out, P, D, row_stride,
-                           (float)incre, num_levels, radius, li, out_split, ldexpf(1.0f, log2s_out), img_w, (int)ntiles);
-    else
-        hipLaunchKernelGGL((lookup_encode_kernel<0, 0>), dim3(grid), dim3(256), smem, (hipStream_t)stream, vol, origin, disp, w, b, out, P, D, row_stride,
-                           (float)incre, num_levels, radius, li, out_split, ldexpf(1.0f, log2s_out), img_w, (int)ntiles);
+    hipLaunchKernelGGL(lookup_encode_kernel, dim3(grid), dim3(256), smem, (hipStream_t)stream, vol, origin, disp, w, b, out, P, D, row_stride,
+                       (float)incre, num_levels, radius, li, out_split, ldexpf(1.0f, log2s_out), img_w, (int)ntiles);
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }
