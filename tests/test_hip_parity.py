@@ -696,7 +696,12 @@ def test_slab_forward_over_rccl_single_rank(dev, golden):
     model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(g["weight_seed"])))
     model = model.to(dev).eval()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))                              # a free port: the suite may run beside other jobs
+    port = sock.getsockname()[1]
+    sock.close()
+    os.environ["MASTER_PORT"] = str(port)
     created = not dist.is_initialized()
     if created:
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
