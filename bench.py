@@ -231,11 +231,17 @@ def main():
         # rest of the line - kernels, roofline - describes that mode
         modes = {}
         for m, label in (("views", f"view-shard x{world} + all-reduce/stage"), ("shard", f"row-slab x{world}")):
-            e_m, out_m, model_m, _, _, _ = timed_run(m)
-            modes[m] = {"value": args.steps / e_m, "ms_per_step": 1e3 * e_m / args.steps, "parallelism": label}
-            del model_m, out_m
+            try:
+                e_m, out_m, model_m, _, _, _ = timed_run(m)
+                modes[m] = {"value": args.steps / e_m, "ms_per_step": 1e3 * e_m / args.steps, "parallelism": label}
+                del model_m, out_m
+            except Exception as exc:                       # (a scheme the transport refuses must not cost the other scheme's line)
+                modes[m] = {"error": f"{type(exc).__name__}: {exc}"[:300], "parallelism": label}
             torch.cuda.empty_cache()
-        args.mode = "shard" if modes["shard"]["ms_per_step"] <= modes["views"]["ms_per_step"] else "views"
+        ok = [m for m in ("shard", "views") if "ms_per_step" in modes[m]]
+        if not ok:
+            raise SystemExit(f"bench.py: both sharding schemes failed: {modes}")
+        args.mode = min(ok, key=lambda m: modes[m]["ms_per_step"])
     shard = world > 1 and args.mode in ("shard", "views")
     elapsed, out, model, inputs, scale, sd = timed_run(args.mode)
     if modes is not None:
