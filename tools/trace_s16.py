@@ -96,6 +96,24 @@ def main():
     for k in np.unique(nb):
         print(f"   CUs with {k} blocks: {np.sum(nb == k)}, busy span p50 {np.percentile(spans[nb == k], 50):.0f} max {spans[nb == k].max()}")
     print("waves per CU (whole launch): ", q(np.bincount(np.unique(cu, return_inverse=True)[1].reshape(-1))))
+    # first-round blocks (start with the launch) against second-round blocks (start when a slot frees), per CU
+    r1, r2, r2lone = [], [], []
+    for c in np.unique(cu):
+        m = np.nonzero((cu == c).any(axis=1))[0]                 # blocks of this CU
+        st = t0[m, 0]
+        order = np.argsort(st)
+        first = st[order[0]]
+        for k, b in enumerate(m[order]):
+            per_step = (main_loop[b, 0] / max(nsteps[b, 0], 1))
+            if t0[b, 0] - first < 20000:
+                r1.append(per_step)
+            else:
+                (r2 if len(m) == 4 else r2lone).append(per_step)
+    print("K-loop cycles/step  round 1      ", q(np.array(r1)))
+    print("K-loop cycles/step  round 2 (CUs with 4 blocks)", q(np.array(r2)))
+    print("K-loop cycles/step  round 2 (CUs with 3 blocks: runs alone)", q(np.array(r2lone)))
+    g = np.diff(stamps[:, 0, 1:1 + 9], axis=1)                   # the 8 tensor groups of wave 0
+    print("cycles per 9-tap group, by group index (p50): ", [int(np.percentile(g[:, k][g[:, k] > 0], 50)) for k in range(g.shape[1])])
 
 
 if __name__ == "__main__":
