@@ -646,6 +646,28 @@ def test_end_to_end_cfg2_bench_workload(dev, golden):
     assert e_disp < TOL and e_depth < TOL
 
 
+@pytest.mark.parametrize("size,V", [((100, 132), 2), ((68, 148), 3), ((52, 76), 1)])
+def test_end_to_end_ragged_sizes_match_oracle(dev, size, V):
+    """Whole forward at image sizes whose feature maps (25 x 33, 17 x 37, 13 x 19) are multiples of none of the kernels' tiles
+    (2 x 16 m-tiles, 8 / 16-row conv tiles, 64-pixel lookup tiles, 8 x 32 stem tiles): every kernel's partial-tile path in one
+    run, against the CPU oracle (which is pinned to the reference captures at the regular sizes)."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+    from oracle import cer_oracle as O
+    H, W = size
+    cascade = [(64, 64, 2), (-1, 320, 2)]
+    images, poses, intr, scale = synthetic_scene(H, W, V, seed=21)
+    model = RAFT(cascade=cascade, test_mode=True)
+    sd = fill_state_dict(model.state_dict(), seed=9)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        got = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale).cpu()
+        ref = O.raft_forward({k: v.cpu() for k, v in sd.items()}, images, poses, intr, scale, cascade=cascade)
+    assert got.shape == ref.shape == (1, 1, H // 4, W // 4)
+    assert rel_l1(got, ref) < TOL
+
+
 @pytest.mark.parametrize("name", ["e2e_blended", "e2e_tnt"])
 def test_end_to_end_other_baseline_configs(dev, golden, name):
     """BASELINE.json configs[4] (BlendedMVS 2048x1536, 7 source views) and configs[2] (Tanks&Temples 3840x2160, 15 source
