@@ -181,6 +181,12 @@ def _device_copy(pairs):
     ops.copy_segments(pairs)
 
 
+def strip_half(w, C, halo=HALO):
+    """Floats per half of a strips buffer: ``halo`` rows of net (C channels) + of disp, rounded up to a multiple of 4 so that the
+    second half - and with it the net rows the 16-byte row mover writes - starts 16-byte aligned for any image width."""
+    return (halo * w * (C + 1) + 3) // 4 * 4
+
+
 def pack_strips(net, disp, buf, w, r0, r1, e0, halo=HALO, copy=_device_copy, rows=None):
     """The first / last ``halo`` OWNED rows of net [rows_ext*w, C] and disp [rows_ext*w] -> buf, laid out as two halves
     [net top | disp top] [net bottom | disp bottom] (the top half is what rank g-1 needs, the bottom half what g+1 needs).
@@ -188,14 +194,14 @@ def pack_strips(net, disp, buf, w, r0, r1, e0, halo=HALO, copy=_device_copy, row
     ``rows(net, flat, y0, nrows, to_tensor)``: row mover for a hidden state kept in an m-tile-major layout (s16 path)."""
     C = net.shape[1]
     n, t0, b0 = halo * w, (r0 - e0) * w, (r1 - halo - e0) * w
-    hb = n * (C + 1)
+    hb = strip_half(w, C, halo)
     if rows is not None:
         rows(net, buf[:n * C], r0 - e0, halo, False)
         rows(net, buf[hb:hb + n * C], r1 - halo - e0, halo, False)
-        copy([(disp[t0:t0 + n], buf[n * C:hb]), (disp[b0:b0 + n], buf[hb + n * C:])])
+        copy([(disp[t0:t0 + n], buf[n * C:n * C + n]), (disp[b0:b0 + n], buf[hb + n * C:hb + n * C + n])])
         return
-    copy([(net[t0:t0 + n], buf[:n * C]), (disp[t0:t0 + n], buf[n * C:hb]),
-          (net[b0:b0 + n], buf[hb:hb + n * C]), (disp[b0:b0 + n], buf[hb + n * C:])])
+    copy([(net[t0:t0 + n], buf[:n * C]), (disp[t0:t0 + n], buf[n * C:n * C + n]),
+          (net[b0:b0 + n], buf[hb:hb + n * C]), (disp[b0:b0 + n], buf[hb + n * C:hb + n * C + n])])
 
 
 def unpack_halves(net, disp, prev_half, next_half, w, g, G, r0, r1, e0, e1, halo=HALO, copy=_device_copy, rows=None):
@@ -211,7 +217,7 @@ def unpack_halves(net, disp, prev_half, next_half, w, g, G, r0, r1, e0, e1, halo
             rows(net, prev_half[(n - k) * C:n * C], 0, r0 - e0, True)
         else:
             pairs += [(prev_half[(n - k) * C:n * C], net[:k])]
-        pairs += [(prev_half[n * C + (n - k):], disp[:k])]
+        pairs += [(prev_half[n * C + (n - k):n * C + n], disp[:k])]
     if g < G - 1 and e1 > r1:      # rows [r1, e1) = the first (e1-r1) rows of rank g+1's top strip
         k, o = (e1 - r1) * w, (r1 - e0) * w
         if rows is not None:
@@ -224,8 +230,8 @@ def unpack_halves(net, disp, prev_half, next_half, w, g, G, r0, r1, e0, e1, halo
 
 
 def unpack_halo(net, disp, allbuf, w, g, G, r0, r1, e0, e1, halo=HALO, copy=_device_copy, rows=None):
-    """``unpack_halves`` on the gathered strips allbuf [G, 2*halo*w*(C+1)] of the all-gather form of the exchange."""
-    hb = halo * w * (net.shape[1] + 1)
+    """``unpack_halves`` on the gathered strips allbuf [G, 2 * strip_half] of the all-gather form of the exchange."""
+    hb = strip_half(w, net.shape[1], halo)
     unpack_halves(net, disp, allbuf[g - 1][hb:] if g > 0 else None, allbuf[g + 1][:hb] if g < G - 1 else None, w, g, G, r0, r1, e0, e1,
                   halo, copy, rows)
 
@@ -296,7 +302,7 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
         d["disp"] = torch.zeros((e1 - e0) * w, device=dev, dtype=torch.float32)
         d["hoist"] = ub.hoist_all(d["inp"], e1 - e0, w, len(model.cascade))
         d["ws"] = ub.workspace(e1 - e0, w, dev)
-        d["strips"] = torch.empty(2 * HALO * w * (d["net"].shape[1] + 1), device=dev, dtype=torch.float32)
+        d["strips"] = torch.zeros(2 * strip_half(w, d["net"].shape[1]), device=dev, dtype=torch.float32)
         # s16 path: the hidden state lives in the m-tile-major frag16 layout - image rows move through cer_s16_rows_f32
         d["rows"] = (lambda t, flat, y0, nr, to_t, hs=e1 - e0: ops.s16_rows(t, flat, hs, w, y0, nr, to_t)) if ub.conv_mode == "s16" else None
 

@@ -155,7 +155,7 @@ def _slab_worker(rank, world, port, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
-    h, w, C = 23, 6, 5
+    h, w, C = 23, 5, 5                                  # (7 * 5 * 6 floats per strip: not a multiple of 4 - the halves are padded)
     full = hashed((h * w, C), 77)
     ex = slab.DistExchange(dist.group.WORLD)
     r0, r1, e0, e1 = slab.slab_bounds(h, world, rank)
@@ -163,7 +163,7 @@ def _slab_worker(rank, world, port, ret):
     ref = full.clone()
     fulld = hashed((h * w,), 79)
     xd, refd = fulld[e0 * w:e1 * w].clone(), fulld.clone()
-    buf = torch.empty(2 * slab.HALO * w * (C + 1))
+    buf = torch.zeros(2 * slab.strip_half(w, C))
     for _ in range(3):
         x = _fake_step(x, e1 - e0, w)
         ref = _fake_step(ref, h, w)
@@ -230,7 +230,7 @@ def test_local_exchange_simulation_matches_full_image():
             slab.refresh_halo(xs[g], got[g], w, g, G, *b[g])
         # flat pack / gather / refresh path on the same data (disp = channel 0 as a separate tensor)
         ds = [y[:, 0].contiguous() for y in ys]
-        bufs = [torch.empty(2 * slab.HALO * w * (C + 1)) for _ in range(G)]
+        bufs = [torch.zeros(2 * slab.strip_half(w, C)) for _ in range(G)]
         for g, (r0, r1, e0, e1) in enumerate(b):
             slab.pack_strips(ys[g], ds[g], bufs[g], w, r0, r1, e0, copy=_torch_copy)
         flat = ex.all_gather_flat(bufs)

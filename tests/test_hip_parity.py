@@ -668,6 +668,25 @@ def test_end_to_end_ragged_sizes_match_oracle(dev, size, V):
     assert rel_l1(got, ref) < TOL
 
 
+@pytest.mark.parametrize("size,V,G", [((100, 132), 2, 2), ((132, 100), 3, 3), ((68, 148), 1, 2)])
+def test_slab_sharded_forward_at_ragged_sizes(dev, size, V, G):
+    """Row slabs whose heights (25 / 3 ranks, 33 / 3, 17 / 2) and widths fit no tile size: the sharded forward must reproduce the
+    single-GPU forward (uneven slabs, halo rows inside partial m-tile rows, more ranks than views)."""
+    from cer_mvs_amd import RAFT, slab
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+    H, W = size
+    images, poses, intr, scale = synthetic_scene(H, W, V, seed=23)
+    model = RAFT(cascade=[(64, 64, 2), (-1, 320, 2)], test_mode=True)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=10))
+    model = model.to(dev).eval()
+    assert slab.can_shard(H // 4, G)
+    with torch.no_grad():
+        single = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale)
+        sharded = slab.sharded_forward(model, images.to(dev), poses.to(dev), intr.to(dev), scale, slab.LocalExchange(G))
+    assert sharded.shape == single.shape
+    assert rel_l1(sharded.cpu(), single.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("name", ["e2e_blended", "e2e_tnt"])
 def test_end_to_end_other_baseline_configs(dev, golden, name):
     """BASELINE.json configs[4] (BlendedMVS 2048x1536, 7 source views) and configs[2] (Tanks&Temples 3840x2160, 15 source
