@@ -646,11 +646,11 @@ def test_end_to_end_cfg2_bench_workload(dev, golden):
     assert e_disp < TOL and e_depth < TOL
 
 
-@pytest.mark.parametrize("size,V", [((100, 132), 2), ((68, 148), 3), ((52, 76), 1)])
+@pytest.mark.parametrize("size,V", [((100, 132), 2), ((68, 148), 3), ((52, 76), 1), ((32, 48), 2), ((36, 20), 1), ((20, 260), 2)])
 def test_end_to_end_ragged_sizes_match_oracle(dev, size, V):
     """Whole forward at image sizes whose feature maps (25 x 33, 17 x 37, 13 x 19) are multiples of none of the kernels' tiles
-    (2 x 16 m-tiles, 8 / 16-row conv tiles, 64-pixel lookup tiles, 8 x 32 stem tiles): every kernel's partial-tile path in one
-    run, against the CPU oracle (which is pinned to the reference captures at the regular sizes)."""
+    (2 x 16 m-tiles, 8 / 16-row conv tiles, 64-pixel lookup tiles, 8 x 32 stem tiles) - down to feature maps smaller than one
+    tile (8 x 12, 9 x 5, 5 x 65): every kernel's partial-tile path in one run, against the CPU oracle (which is pinned to the reference captures at the regular sizes)."""
     from cer_mvs_amd import RAFT
     from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
     from oracle import cer_oracle as O

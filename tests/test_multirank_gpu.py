@@ -97,3 +97,46 @@ def test_two_process_literal_forward_with_max_aggregation(dev, golden, tmp_path)
     outs = [torch.from_numpy(np.load(f"{out_path}.{r}.npy")) for r in range(world)]
     assert rel_l1(outs[0], outs[1]) < 1e-6 and rel_l1(outs[0], ref) < 1e-5 and rel_l1(outs[1], ref) < 1e-5, \
         (rel_l1(outs[0], outs[1]), rel_l1(outs[0], ref), rel_l1(outs[1], ref))
+
+
+def _ragged_worker(rank, world, port, shard, H, W, V, out_path):
+    import sys
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    images, poses, intr, scale = synthetic_scene(H, W, V, seed=31)
+    model = RAFT(cascade=[(64, 64, 2), (-1, 320, 2)], test_mode=True, view_group=dist.group.WORLD, shard=shard)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=12))
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        out = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale)
+    torch.cuda.synchronize()
+    np.save(f"{out_path}.{rank}.npy", out.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shard", ["slab", "views"])
+def test_two_process_forward_at_ragged_size(dev, tmp_path, shard):
+    """Uneven work per rank: 25 feature rows over 2 ranks (13 + 12, partial m-tile rows, odd width 33) and 3 views over 2 ranks
+    (2 + 1); every rank must reproduce the single-process forward."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+    H, W, V, world = 100, 132, 3, 2
+    out_path = str(tmp_path / "disp")
+    mp.spawn(_ragged_worker, args=(world, _free_port(), shard, H, W, V, out_path), nprocs=world, join=True)
+    images, poses, intr, scale = synthetic_scene(H, W, V, seed=31)
+    model = RAFT(cascade=[(64, 64, 2), (-1, 320, 2)], test_mode=True)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=12))
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        ref = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale).cpu()
+    for r in range(world):
+        got = torch.from_numpy(np.load(f"{out_path}.{r}.npy"))
+        assert got.shape == ref.shape and rel_l1(got, ref) < 1e-5, (r, rel_l1(got, ref))
