@@ -755,14 +755,15 @@ def test_slab_forward_over_rccl_single_rank(dev, golden):
     assert rel_l1(out.cpu(), torch.from_numpy(g["disp"])) < TOL
 
 
-def test_odd_image_size_vs_oracle(dev):
-    """h1, w1 not multiples of the 8x16 conv tile, V = 1."""
+@pytest.mark.parametrize("gru_precision", ["s16", "f16x3", "fp32"])
+def test_odd_image_size_vs_oracle(dev, gru_precision):
+    """h1, w1 not multiples of the 8x16 conv tile, V = 1; every arithmetic mode of the update block."""
     from cer_mvs_amd import RAFT
     from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
     from oracle import cer_oracle as O
     cascade = [(64, 64, 2), (-1, 320, 1)]
     images, poses, intr, scale = synthetic_scene(76, 108, 1, seed=6)
-    model = RAFT(cascade=cascade, test_mode=True)
+    model = RAFT(cascade=cascade, test_mode=True, gru_precision=gru_precision)
     sd = fill_state_dict(model.state_dict(), seed=12)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
