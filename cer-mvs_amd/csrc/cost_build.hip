@@ -65,7 +65,6 @@ __global__ __launch_bounds__(256) void cost_build_kernel(const float* __restrict
         const int nk = min(64, D - kb);
         for (int v = v_lo; v < v_hi; ++v) {
             const float* m = Pij + v * 16;
-            const float* f2v = fmap2 + (long)v * P2C + loff;
             // ---- projection of hypothesis kb + lane (utils/projective_ops.py:26-28, core/corr.py:56,65,88)
             const float hyp = __fadd_rn(__fmul_rn((float)(kb + lane - half), incre), origin);
             const float X = fmaf(m[3], hyp, fmaf(m[1], py, m[0] * px) + m[2]);
@@ -91,35 +90,35 @@ __global__ __launch_bounds__(256) void cost_build_kernel(const float* __restrict
                 wl[3 * 64 + lane] = wy1 * wx1;
                 __builtin_amdgcn_s_waitcnt(0xC07F);        // wave-local exchange: LDS ops of a wave complete in order
             }
-            int coff = -1;                                 // cell of the previous sample (offsets are >= 0)
+            // "new texel cell?" for all 64 hypotheses at once (lane = hypothesis against lane - 1; hypothesis 0 always loads): one
+            // shuffle + compare + ballot per view replace a scalar compare / select chain per sample - the walk is instruction
+            // -issue bound (with every load removed it still needed 1.24 ms at stage 0), most of it scalar bookkeeping.
+            const int prev_off = __shfl_up(off, 1);
+            const unsigned long long newcell = __ballot(lane == 0 || off != prev_off);
+            // byte offsets fit 32 bits (one padded source map), so a load is scalar base + 32-bit vector offset
+            const char* vbase = reinterpret_cast<const char*>(fmap2 + (long)v * P2C);
             float sdot = 0.f;
             // samples are walked in groups of 8: first all (needed) texel loads of the group are issued,
             // then consumed - 8 loads in flight per wave instead of one dependent load per sample
 #pragma unroll
             for (int g = 0; g < NACC / 8; ++g) {
                 if (g * 8 < nk) {                          // wave-uniform
-                    int soff[8];
-                    bool need[8];
                     float4 t[8][NQ];
                     const float4 wa = *reinterpret_cast<const float4*>(wl + corner * 64 + g * 8);
                     const float4 wb = *reinterpret_cast<const float4*>(wl + corner * 64 + g * 8 + 4);
                     const float wgt[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+                    const unsigned bits = (unsigned)(newcell >> (g * 8)) & 0xFFu;        // scalar
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        soff[i] = __builtin_amdgcn_readlane(off, g * 8 + i);
-                        need[i] = soff[i] != (i ? soff[i - 1] : coff);      // scalar: new texel cell?
-                    }
-                    coff = soff[7];
+                        if (bits & (1u << i)) {
+                            const unsigned bo = (unsigned)(__builtin_amdgcn_readlane(off, g * 8 + i) + loff) * 4u;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        if (need[i]) {
-#pragma unroll
-                            for (int q = 0; q < NQ; ++q) t[i][q] = cer_ld4(f2v + soff[i] + 64 * q);
+                            for (int q = 0; q < NQ; ++q) t[i][q] = cer_ld4(reinterpret_cast<const float*>(vbase + bo) + 64 * q);
                         }
                     }
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        if (need[i]) {
+                        if (bits & (1u << i)) {
                             sdot = 0.f;
 #pragma unroll
                             for (int q = 0; q < NQ; ++q) sdot = cer_dot4(f1q[q], t[i][q], sdot);
