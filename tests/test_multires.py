@@ -84,3 +84,31 @@ def test_multires_driver_files(tmp_path):
     for name, w in want.items():
         got = read_pfm(d / f"{name}_nf10_nf7_th0.02.pfm")
         assert got.shape == w.shape and (np.abs(got - w) > 1e-6 * np.abs(w)).mean() < 1e-3
+
+
+@pytest.mark.gpu
+def test_inference_two_scales_then_multires(tmp_path):
+    """The reference's demo chain (demo.py:28-62: inference at scale 1 and 2, then multires) on a synthetic scene: the file names
+    one step writes are the ones the next step reads, and the merged map has the scale-2 size."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd import inference as I
+    from cer_mvs_amd import multires as MR
+    from cer_mvs_amd.fusion import read_pfm
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+    dev = torch.device("cuda:0")
+    images, poses, intr, scale = synthetic_scene(64, 96, 2, seed=5)
+    model = RAFT(cascade=[(64, 64, 1), (-1, 320, 1)], test_mode=True)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=2))
+    model = model.to(dev)
+    loader = [(images, poses, intr, [["00000007"]], scale)]
+    I.inference(loader, None, tmp_path, rescale=1, model=model, num_frames=3)
+    I.inference(loader, None, tmp_path, rescale=2, model=model, num_frames=3)
+    written = MR.multires(tmp_path, suffix1="_nf3", suffix2="_nf3", th=0.02)
+    assert [p.name for p in written] == ["00000007_nf3_nf3_th0.02.pfm"]
+    d1 = read_pfm(tmp_path / "depths" / "00000007_scale1_nf3.pfm")
+    d2 = read_pfm(tmp_path / "depths" / "00000007_scale2_nf3.pfm")
+    m = read_pfm(written[0])
+    assert d1.shape == (16, 24) and d2.shape == (32, 48) and m.shape == d2.shape
+    from oracle import multires_oracle as M
+    want = M.merge(d1, d2, 0.02, 1)
+    assert (np.abs(m - want) > 1e-6 * np.abs(want)).mean() < 1e-2
