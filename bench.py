@@ -9,7 +9,8 @@ HBM -> disparity in HBM) at BASELINE.json configs[1]: DTU 1600x1184, 10 source v
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1 (configs[3]): ONE reference frame is sharded over the ranks.  The default `--mode both` times the two schemes one
-after the other and reports both under "modes"; the headline (`value`, `ms_per_step`) is a fresh timed run of the faster one:
+after the other and reports both under "modes" (plus, as context, `replica`: N independent depth maps, weak scaling); the headline
+(`value`, `ms_per_step`) is a fresh timed run of the faster of the two strong-scaling schemes:
   shard   rank g encodes the source views v with (v-1) % N == g; their feature maps are all-gathered (RCCL over xGMI) while
           the rank encodes the reference view; image rows are sharded for the cost volume and the GRU loop, with the 7-row
           halo of (net, disp) exchanged point-to-point with the two neighbours per iteration (cer-mvs_amd/slab.py);
@@ -238,6 +239,15 @@ def main():
             except Exception as exc:                       # (a scheme the transport refuses must not cost the other scheme's line)
                 modes[m] = {"error": f"{type(exc).__name__}: {exc}"[:300], "parallelism": label}
             torch.cuda.empty_cache()
+        try:
+            # context, never the headline: N independent depth maps, one per GPU, no communication (weak scaling)
+            e_r, out_r, model_r, _, _, _ = timed_run("replica")
+            modes["replica"] = {"value": world * args.steps / e_r, "ms_per_step": 1e3 * e_r / args.steps, "scaling": "weak",
+                                "parallelism": f"replica x{world}: {world} independent depth maps per step"}
+            del model_r, out_r
+        except Exception as exc:
+            modes["replica"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        torch.cuda.empty_cache()
         ok = [m for m in ("shard", "views") if "ms_per_step" in modes[m]]
         if not ok:
             raise SystemExit(f"bench.py: both sharding schemes failed: {modes}")
