@@ -183,15 +183,10 @@ static int launch_build(const float* f1, const float* f2, const float* Pij, cons
     return CER_OK;
 }
 
-// round 2 experiment: the fold modes at C = 64 can run as band GEMM + gather (cost_gemm.hip, cer_cost_build_algo(2)); this file's
-// wave-per-pixel walk is the default
-int cer_cost_gemm_launch(const float* f1, const float* f2, const float* Pij, const float* disp_in, float* vol, float* origin_out, int V, int h1,
-                         int w1, int h2, int w2, int C, int D, int rs, double incre_d, int shift, int mode, int y0, int levels, float scale,
-                         hipStream_t st);
 static int g_cost_build_algo = 0;
-extern "C" int cer_cost_build_algo(int algo) {             // 0: automatic, 1: always the round-1 walk, 2: band GEMM wherever it applies
+extern "C" int cer_cost_build_algo(int algo) {             // 0: automatic (host layer prefers cost_lines.hip), 1: always this file's walk
     const int prev = g_cost_build_algo;
-    if (algo >= 0 && algo <= 2) g_cost_build_algo = algo;
+    if (algo >= 0 && algo <= 1) g_cost_build_algo = algo;
     return prev;
 }
 
@@ -207,17 +202,9 @@ extern "C" int cer_cost_build_f32(const float* fmap1, const float* fmap2, const 
     }
     if (V <= 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || C <= 0 || D <= 0 || row_stride < D || mode < 0 || mode > 2) return CER_EINVAL;
     if (C % 64 != 0 || C > 256 || V > 65535) return CER_ESHAPE;
-    if ((long)(h2 + 4) * (w2 + 4) * C >= (1L << 31)) return CER_ESHAPE;
+    if ((long)(h2 + 4) * (w2 + 4) * C >= (1L << 30)) return CER_ESHAPE;      // the walk forms 32-bit BYTE offsets into one padded map
     if (!cer_aligned16(fmap1) || !cer_aligned16(fmap2)) return CER_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    // The band GEMM (cost_gemm.hip) is selectable, not the default: measured at 1600x1184 x 10 views it ties the walk on the shifted
-    // first stage (2.60 vs 2.52 ms; its per-chunk project / reduce / multiply / gather phases are barrier-separated) and loses on
-    // re-centred stages whose per-pixel origins scatter the tile's segments (rough disparity: 11 ms vs 1.4 ms)
-    if (mode != 0 && g_cost_build_algo == 2) {
-        const int rc = cer_cost_gemm_launch(fmap1, fmap2, Pij, disp_in, vol, origin_out, V, h1, w1, h2, w2, C, D, row_stride, incre, shift, mode, y0,
-                                            fuse_levels, fuse_scale, st);
-        if (rc != CER_ESHAPE) return rc;
-    }
     switch (C / 64) {
         case 1: return launch_build<1>(fmap1, fmap2, Pij, disp_in, vol, origin_out, V, h1, w1, h2, w2, C, D, row_stride, incre, shift, mode, y0, fuse_levels, fuse_scale, st);
         case 2: return launch_build<2>(fmap1, fmap2, Pij, disp_in, vol, origin_out, V, h1, w1, h2, w2, C, D, row_stride, incre, shift, mode, y0, fuse_levels, fuse_scale, st);

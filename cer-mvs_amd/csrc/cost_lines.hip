@@ -1,0 +1,591 @@
+// K1, round 3: epipolar cost-volume build on EPIPOLAR-LINE TILES
+// (reference: core/corr.py:56-91 + utils/projective_ops.py:5-28 + core/corr.py:28-43 +
+//  alt_cuda_corr/correlation_kernel.cu:18-119; pyramid core/corr.py:94-97).
+//
+// The round-1/2 walk (cost_build.hip) fetches a 2 x 2 x 256-B footprint per sample: 1 KiB through the L1 per (pixel, view,
+// hypothesis) - 46 GB per launch at 1600x1184, which IS its run time (64 B/clk/CU).  The correlation is bilinear in the
+// texel dot products,
+//     <f1(p), bilerp(f2)(u, w)>  =  bilerp over the 4 texels of  <f1(p), f2(texel)>,
+// and all samples of a reference pixel lie on ONE line of the source image (its epipolar line); reference pixels on the same
+// reference epipolar line share that source line.  So the reference image is partitioned, per source view, into tiles of 64
+// pixels that follow the view's epipolar direction (digital lines: a shear of the pixel grid, chosen per view from Pij), and
+// per (view, tile):
+//   1. the tile's samples live in a thin band of the source map: `ncol` columns along the band's major axis x R texels
+//      across (R = 4..6 when the shear fits).  The band is processed in chunks of CL_T = 128 texels;
+//   2. per chunk, dots[texel][pixel] = <f2(texel), f1(pixel)> for ALL 128 x 64 pairs is one MFMA product per wave
+//      (32 texels x 64 pixels x 64 channels, split-f16: three f16 MFMAs into one fp32 accumulator, fp32-class - conv_s16.hip);
+//      operands arrive as pre-split hi|lo f16 rows (cer_feat_split_f16) straight from global memory in fragment order:
+//      every band texel is read once per tile (4 x fewer L1 bytes than there are samples x 16 B), nothing is staged;
+//   3. lane = pixel: each lane walks ITS hypotheses in order (a cursor), and for every sample whose cell lies in the chunk
+//      reads its 4 dots from LDS (16 B instead of 1 KiB), applies the bilinear weights and stores the value in the tile's
+//      [hypothesis][pixel] output tile; samples outside the source image are zeros (the walk's zero border);
+//   4. anything the band analysis did not cover (projections blown apart near Z = 0, epipoles inside the image, rough
+//      per-pixel origins that break the cursor's monotonic order) takes a per-sample direct path: correct, slow, rare.
+// Views are independent (their tiles differ), so each (view, tile) writes its [64 px][D] result to a per-view partial
+// volume; cost_lines_reduce_kernel sums the partials in view order (deterministic), applies the view-mean scale and emits
+// the pooled pyramid levels - the fused epilogue of the walk.
+//
+// The coordinate arithmetic (hypothesis, projection, IEEE divisions, clamps, floor, fractions) is expression-for-expression
+// that of cost_build.hip, so cells and weights are bit-identical to the walk; only the 64-channel dot differs in rounding.
+#include "common.hpp"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define CL_T 128                            // texels per chunk (one 32-texel MFMA row tile per wave)
+#define CL_DP 33                            // pitch (float2) of the [hypothesis][pixel] sample / output tile
+#define CL_LOG2S 6                          // operand scale of the split: features (already / 8) saturate at 65504 / 64
+#define CL_RMAX 32                          // widest band (texels across) that still goes through the MFMA path
+#ifndef CL_ABL
+#define CL_ABL 0                            // ablation builds for timing attribution (variants/libcermvs_clabl<N>.so): wrong results
+#endif
+
+// ---- fp32 rows -> split-f16 rows: per texel 64 hi halves | 64 lo halves of x * 2^CL_LOG2S (hi = f16(xs), lo = f16(xs - hi))
+__global__ __launch_bounds__(256) void feat_split_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long n8, int* __restrict__ flag) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;    // one thread per 8 channels
+    if (i >= n8) return;
+    const float4 a = cer_ld4(src + i * 8), b = cer_ld4(src + i * 8 + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    cer_h2 h[4], l[4];
+    bool sat = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        cer_f2 x = (cer_f2){v[2 * j], v[2 * j + 1]} * (float)(1 << CL_LOG2S);
+        sat |= !(fabsf(x.x) <= 65504.0f) || !(fabsf(x.y) <= 65504.0f);
+        x = __builtin_elementwise_min(__builtin_elementwise_max(x, (cer_f2){-65504.0f, -65504.0f}), (cer_f2){65504.0f, 65504.0f});
+        h[j] = __builtin_convertvector(x, cer_h2);
+        l[j] = __builtin_convertvector(x - __builtin_convertvector(h[j], cer_f2), cer_h2);
+    }
+    const long texel = i >> 3;
+    const int c8 = (int)(i & 7);
+    *reinterpret_cast<half8*>(dst + texel * 128 + c8 * 8) = (half8){h[0].x, h[0].y, h[1].x, h[1].y, h[2].x, h[2].y, h[3].x, h[3].y};
+    *reinterpret_cast<half8*>(dst + texel * 128 + 64 + c8 * 8) = (half8){l[0].x, l[0].y, l[1].x, l[1].y, l[2].x, l[2].y, l[3].x, l[3].y};
+    if (sat && flag) atomicOr(flag, 1);                     // sticky: a feature beyond +-1023 was clamped (or is not finite)
+}
+
+extern "C" int cer_feat_split_f16(const float* src, void* dst, long texels, int C, int* overflow_flag, void* stream) {
+    if (!src || !dst || texels <= 0) return CER_EINVAL;
+    if (C != 64) return CER_ESHAPE;
+    if (!cer_aligned16(src) || !cer_aligned16(dst)) return CER_EALIGN;
+    const long n8 = texels * 8;
+    hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst, n8,
+                       overflow_flag);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}
+
+// ---- per view: the tile partition of the reference image.  params[v] = {axis, shear, 0, 0}: tiles run along x (axis 0) or
+// y (axis 1); pixel `a` along the axis of line j sits at b = j + rint(shear * (a - centre)) across it.
+// Reference epipole e_h = adj(A) t with A = Pij[:3,:3], t = Pij[:3,3] (A e ~ t: the pixel whose ray passes through the
+// source camera); the epipolar direction at the grid centre c is e_h.xy - c * e_h.z (finite or not).
+__global__ void cost_lines_setup_kernel(const float* __restrict__ Pij, float* __restrict__ params, int V, int h1, int w1, int y0) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const float* m = Pij + v * 16;
+    const double a00 = m[0], a01 = m[1], a02 = m[2], a10 = m[4], a11 = m[5], a12 = m[6], a20 = m[8], a21 = m[9], a22 = m[10];
+    const double t0 = m[3], t1 = m[7], t2 = m[11];
+    const double c00 = a11 * a22 - a12 * a21, c01 = a02 * a21 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+    const double c10 = a12 * a20 - a10 * a22, c11 = a00 * a22 - a02 * a20, c12 = a02 * a10 - a00 * a12;
+    const double c20 = a10 * a21 - a11 * a20, c21 = a01 * a20 - a00 * a21, c22 = a00 * a11 - a01 * a10;
+    const double ex = c00 * t0 + c01 * t1 + c02 * t2, ey = c10 * t0 + c11 * t1 + c12 * t2, ez = c20 * t0 + c21 * t1 + c22 * t2;
+    const double cx = 0.5 * w1, cy = y0 + 0.5 * h1;
+    double dx = ex - cx * ez, dy = ey - cy * ez;
+    if (!(dx == dx) || !(dy == dy) || fabs(dx) > 1e300 || fabs(dy) > 1e300) { dx = 1.0; dy = 0.0; }
+    int axis = 0;
+    double s = 0.0;
+    if (fabs(dx) >= fabs(dy)) {
+        axis = 0;
+        s = dx != 0.0 ? dy / dx : 0.0;
+    } else {
+        axis = 1;
+        s = dx / dy;
+    }
+    if (!(s == s)) s = 0.0;
+    s = fmin(1.0, fmax(-1.0, s));
+    params[v * 4 + 0] = (float)axis;
+    params[v * 4 + 1] = (float)s;
+    params[v * 4 + 2] = 0.f;
+    params[v * 4 + 3] = 0.f;
+}
+
+// wave-wide min / max: 4 DPP permutes within each 16-lane row, then the four row results through SGPRs (uniform result)
+__device__ __forceinline__ float cl_wmin(float x) {
+    x = fminf(x, cer_dpp<0xB1>(x));
+    x = fminf(x, cer_dpp<0x4E>(x));
+    x = fminf(x, cer_dpp<0x141>(x));
+    x = fminf(x, cer_dpp<0x140>(x));
+    const float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0)), s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+    const float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32)), s3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+    return fminf(fminf(s0, s1), fminf(s2, s3));
+}
+__device__ __forceinline__ float cl_wmax(float x) {
+    x = fmaxf(x, cer_dpp<0xB1>(x));
+    x = fmaxf(x, cer_dpp<0x4E>(x));
+    x = fmaxf(x, cer_dpp<0x141>(x));
+    x = fmaxf(x, cer_dpp<0x140>(x));
+    const float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0)), s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+    const float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32)), s3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+    return fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
+}
+
+// direct path: the four texel dots of one sample from the split rows in global memory (scaled by 2^(2 CL_LOG2S), like the MFMA path)
+__device__ __noinline__ float cl_direct(const _Float16* __restrict__ f1row, const _Float16* __restrict__ tex00, int smajS, int sminS,
+                                        float wm0, float wm1, float wn0, float wn1) {
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
+    const _Float16* tp[4] = {tex00, tex00 + (long)smajS * 128, tex00 + (long)sminS * 128, tex00 + (long)(smajS + sminS) * 128};
+    for (int c8 = 0; c8 < 8; ++c8) {
+        const half8 ah = *reinterpret_cast<const half8*>(f1row + 8 * c8), al = *reinterpret_cast<const half8*>(f1row + 64 + 8 * c8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const half8 bh = *reinterpret_cast<const half8*>(tp[q] + 8 * c8), bl = *reinterpret_cast<const half8*>(tp[q] + 64 + 8 * c8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[q] = fmaf((float)ah[e] + (float)al[e], (float)bh[e] + (float)bl[e], d[q]);
+        }
+    }
+    return d[0] * (wn0 * wm0) + d[1] * (wn0 * wm1) + d[2] * (wn1 * wm0) + d[3] * (wn1 * wm1);
+}
+
+// -DCL_TRACE=1 (variants/libcermvs_cltrace.so, tools/trace_lines.py): wave 0 of every block adds its cycle counts per phase
+// and a few event counts to a global table - where a tile's life goes.  Not compiled into the product library.
+#ifdef CL_TRACE
+__device__ unsigned long long cl_trace[32];
+extern "C" int cer_cost_lines_trace(unsigned long long* host32, int reset) {
+    if (reset) {
+        unsigned long long z[32] = {0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(cl_trace), z, sizeof(z));
+    }
+    return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(cl_trace), 32 * sizeof(unsigned long long));
+}
+#define CL_STAMP(slot)                                                 \
+    do {                                                               \
+        const unsigned long long now__ = __builtin_readcyclecounter(); \
+        tr_acc[slot] += now__ - tr_last;                               \
+        tr_last = now__;                                               \
+    } while (0)
+#define CL_COUNT(slot, n) do { tr_cnt[(slot) - 24] += (unsigned long long)(n); } while (0)
+#define CL_FLUSH()                                                                  \
+    do {                                                                            \
+        if (tid == 0) {                                                             \
+            for (int i__ = 0; i__ < 16; ++i__) atomicAdd(&cl_trace[i__], tr_acc[i__]);     \
+            for (int i__ = 0; i__ < 8; ++i__) atomicAdd(&cl_trace[24 + i__], tr_cnt[i__]); \
+        }                                                                           \
+    } while (0)
+#else
+#define CL_STAMP(slot) do { } while (0)
+#define CL_COUNT(slot, n) do { } while (0)
+#define CL_FLUSH() do { } while (0)
+#endif
+
+struct ClArgs {
+    const _Float16* f1s;      // [P][hi 64 | lo 64]   reference rows of this call's pixel grid
+    const _Float16* f2s;      // [V][(h2+4)*(w2+4)][hi 64 | lo 64]   zero border included
+    const float* Pij;         // [V][16]
+    const float* params;      // [V][4]  cost_lines_setup_kernel
+    const float* disp_in;     // [P]
+    float* part;              // [V][P][D]  per-view partial volume, scaled by 2^(2 CL_LOG2S)
+    int V, h1, w1, h2, w2, D;
+    float incre, lim;
+    int shift, y0, tpv;
+};
+
+__global__ __launch_bounds__(256, 3) void cost_lines_kernel(const ClArgs A) {
+    __shared__ __attribute__((aligned(16))) float prod[CL_T * 32];      // dots[texel of the chunk][pixel of the tile]
+    // per (hypothesis, pixel): {packed cell, fraction along the band, fraction across it, value}
+    //   packed: bits 0-15 band column of the cell + 4; bits 30-31 kind: 0 = samples through the band (bits 16-20 / 21-25: band row
+    //   of the cell in its own / the next column), 1 = zero (outside the map / non-finite), 2 = direct path (bits 16-29: cell row + 4)
+    __shared__ __attribute__((aligned(16))) float desc[64 * CL_DP * 4];
+    __shared__ int pidx[32];                                             // pixel index of tile slot i, or -1
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kg = lane >> 5;
+#ifdef CL_TRACE
+    unsigned long long tr_last = __builtin_readcyclecounter(), tr_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    // XCD-aware order (blocks are dealt round-robin over the 8 XCDs): each XCD gets a contiguous range of (view, segment, line):
+    // neighbouring lines share most of their band, which then stays in that XCD's L2
+    unsigned o;
+    {
+        const unsigned nblk = gridDim.x, bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+        o = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int v = (int)(o / (unsigned)A.tpv), rem = (int)(o % (unsigned)A.tpv);
+    const int h1 = A.h1, w1 = A.w1, h2 = A.h2, w2 = A.w2, D = A.D;
+    const int axis = (int)A.params[v * 4 + 0];
+    const float shear = A.params[v * 4 + 1];
+    const int La = axis ? h1 : w1, Hm = axis ? w1 : h1;     // extent along / across the tile axis
+    const int njm = Hm + 32, nseg = (La + 31) >> 5;
+    const int seg = (int)((unsigned)rem / (unsigned)njm), jj = rem - seg * njm;
+    if (seg >= nseg) return;
+    const float cm = 0.5f * (float)La;
+    const int a_first = seg * 32, a_last = min(seg * 32 + 31, La - 1);
+    const int sh_f = (int)rintf(shear * ((float)a_first - cm)), sh_l = (int)rintf(shear * ((float)a_last - cm));
+    const int sh_lo = min(sh_f, sh_l), sh_hi = max(sh_f, sh_l);
+    const int j = jj - sh_hi;
+    if (j > Hm - 1 - sh_lo) return;
+    const int a_me = seg * 32 + li;                         // lanes l and l + 32 share pixel slot li (they own different hypotheses)
+    const int b_me = j + (int)rintf(shear * ((float)a_me - cm));
+    const bool valid = a_me < La && b_me >= 0 && b_me < Hm;
+    if (__ballot(valid) == 0ull) return;                    // (block-uniform: every wave sees the same 32 slots)
+    const int x_me = axis ? b_me : a_me, y_me = axis ? a_me : b_me;
+    const long p_me = (long)min(max(y_me, 0), h1 - 1) * w1 + min(max(x_me, 0), w1 - 1);
+    if (wave == 0 && lane < 32) pidx[lane] = valid ? (int)p_me : -1;
+    CL_STAMP(8);                                            // tile decode
+    if (CL_ABL == 4) return;
+
+    // ---- B fragments: the tile's 32 reference rows (lane: pixel slot li, channels 16 ks + 8 kg .. + 7), held for the whole
+    // tile-view; requested first: they arrive under the projections below
+    const _Float16* f1row = A.f1s + p_me * 128;
+    half8 bh[4], bl[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        bh[ks] = *reinterpret_cast<const half8*>(f1row + 8 * kg + 16 * ks);
+        bl[ks] = *reinterpret_cast<const half8*>(f1row + 8 * kg + 64 + 16 * ks);
+    }
+
+    // ---- this lane's pixel: origin (core/corr.py:59-62) and ray (utils/projective_ops.py:26-28)
+    const float* m = A.Pij + v * 16;
+    const float px = (float)x_me, py = (float)(y_me + A.y0);
+    float origin = A.disp_in[p_me];
+    if (A.shift && origin < A.lim) origin = A.lim;
+    const float a0 = fmaf(m[1], py, m[0] * px) + m[2], a1 = fmaf(m[5], py, m[4] * px) + m[6], a2 = fmaf(m[9], py, m[8] * px) + m[10];
+    const float m3 = m[3], m7 = m[7], m11 = m[11];
+    const int half = D / 2;
+    const float incre = A.incre;
+    auto project = [&](int k, float& u, float& w) -> bool {      // same fp32 expressions as cost_build.hip / the reference
+        const float hyp = __fadd_rn(__fmul_rn((float)(k - half), incre), origin);
+        const float X = fmaf(m3, hyp, a0), Y = fmaf(m7, hyp, a1), Z = fmaf(m11, hyp, a2);
+        u = X / Z;
+        w = Y / Z;
+        const bool ok = (u == u) && (w == w);               // 0/0 samples nothing
+        u = fminf(fmaxf(u, -1e4f), 1e4f);
+        w = fminf(fmaxf(w, -1e4f), 1e4f);
+        return ok;
+    };
+
+    // ---- band analysis (every wave computes the same wave-uniform values).  End points of every pixel's segment: lanes with
+    // kg = 0 project hypothesis 0, lanes with kg = 1 hypothesis D - 1, and the halves swap
+    float ua, wa, ub, wb;
+    bool part0;
+    {
+        float ue, we;
+        const bool oke = project(kg ? D - 1 : 0, ue, we);
+        const float uo = __shfl_xor(ue, 32), wo = __shfl_xor(we, 32);
+        const bool oko = ((__ballot(oke) >> (lane ^ 32)) & 1ull) != 0ull;
+        ua = kg ? uo : ue; wa = kg ? wo : we;
+        ub = kg ? ue : uo; wb = kg ? we : wo;
+        part0 = valid && oke && oko;
+    }
+    const unsigned long long pm0 = __ballot(part0);
+    int smaj = 0;                                            // 0: band runs along u (x of the source map), 1: along w
+    if (pm0) {
+        const float INF = 3e38f;
+        const float mnu = cl_wmin(part0 ? fminf(ua, ub) : INF), mxu = cl_wmax(part0 ? fmaxf(ua, ub) : -INF);
+        const float mnw = cl_wmin(part0 ? fminf(wa, wb) : INF), mxw = cl_wmax(part0 ? fmaxf(wa, wb) : -INF);
+        smaj = (mxw - mnw) > (mxu - mnu) ? 1 : 0;
+    }
+    smaj = __builtin_amdgcn_readfirstlane(smaj);
+    const int Wmaj = smaj ? h2 : w2, Wmin = smaj ? w2 : h2;
+    const int wp = w2 + 4;
+    const int smajS = smaj ? wp : 1, sminS = smaj ? 1 : wp;      // texel strides of the padded source map along / across the band
+    int nchunks = 0, R = 1, Wc = 1, cmin = 0, cmax = 0, dir = 1;
+    float bm = 0.f, bl0 = 0.f;                               // base row of band column c: floor(bl0 + bm * c)
+    if (pm0) {
+        const float ma = smaj ? wa : ua, na = smaj ? ua : wa, mb = smaj ? wb : ub, nb = smaj ? ub : wb;
+        // clip the segment to the columns of the (padded) map: what lies beyond samples zeros and needs no band
+        const float lo = -2.0f, hi = (float)Wmaj + 1.0f;
+        const float dm = mb - ma, dn = nb - na;
+        float t0 = 0.f, t1 = 1.f;
+        bool inside;
+        if (fabsf(dm) < 1e-6f) {
+            inside = ma >= lo && ma <= hi;
+        } else {
+            const float ta = (lo - ma) / dm, tb = (hi - ma) / dm;
+            t0 = fmaxf(0.f, fminf(ta, tb));
+            t1 = fminf(1.f, fmaxf(ta, tb));
+            inside = t0 <= t1;
+        }
+        const bool part1 = part0 && inside;
+        const unsigned long long pm1 = __ballot(part1);
+        if (pm1) {
+            const float INF = 3e38f;
+            const float ma1 = fmaf(t0, dm, ma), na1 = fmaf(t0, dn, na), mb1 = fmaf(t1, dm, ma), nb1 = fmaf(t1, dn, na);
+            const bool aFirst = ma1 <= mb1;
+            const float lmin = part1 ? (aFirst ? ma1 : mb1) : INF, lminN = aFirst ? na1 : nb1;
+            const float lmax = part1 ? (aFirst ? mb1 : ma1) : -INF, lmaxN = aFirst ? nb1 : na1;
+            const float gmin = cl_wmin(lmin), gmax = cl_wmax(lmax);
+            const int l0 = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(part1 && lmin == gmin)) - 1);
+            const int l1 = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(part1 && lmax == gmax)) - 1);
+            const float q0n = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lminN), l0));
+            const float q1n = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lmaxN), l1));
+            bm = (gmax - gmin > 1e-3f) ? (q1n - q0n) / (gmax - gmin) : 0.f;
+            bm = fminf(fmaxf(bm, -4.f), 4.f);
+            const float oa = na1 - fmaf(bm, ma1 - gmin, q0n), ob = nb1 - fmaf(bm, mb1 - gmin, q0n);
+            const float omin = cl_wmin(part1 ? fminf(oa, ob) : INF), omax = cl_wmax(part1 ? fmaxf(oa, ob) : -INF);
+            const float am = fabsf(bm);
+            const float spread = omax - omin + 2.f * am + 0.02f;
+            cmin = min(max((int)floorf(gmin), -2), Wmaj + 1);
+            cmax = min(max((int)floorf(gmax) + 1, -2), Wmaj + 1);
+            if (spread < (float)(CL_RMAX - 3) && cmax > cmin) {
+                R = (int)floorf(spread) + 3;
+                Wc = CL_T / R;
+                bl0 = q0n - bm * gmin + omin - am - 0.01f;
+                nchunks = (cmax - cmin + Wc - 2) / (Wc - 1);
+                const unsigned long long fw = __ballot(part1 && mb1 > ma1), bw = __ballot(part1 && mb1 < ma1);
+                dir = __popcll(fw) >= __popcll(bw) ? 1 : -1;
+            }
+        }
+    }
+    nchunks = __builtin_amdgcn_readfirstlane(nchunks);
+    R = __builtin_amdgcn_readfirstlane(R);
+    Wc = __builtin_amdgcn_readfirstlane(Wc);
+    cmin = __builtin_amdgcn_readfirstlane(cmin);
+    cmax = __builtin_amdgcn_readfirstlane(cmax);
+    dir = __builtin_amdgcn_readfirstlane(dir);
+    bm = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bm)));
+    bl0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bl0)));
+    CL_STAMP(11);                                           // band analysis
+    if (CL_ABL == 5) return;
+
+    const _Float16* f2v = A.f2s + (long)v * (long)(h2 + 4) * wp * 128;
+
+    // ---- A fragments of a chunk: wave `wave` owns band texels 32 wave .. + 31 of the chunk (lane: texel li, channels as above)
+    half8 ahf[4], alf[4];
+    const int t_me = wave * 32 + li;
+    const int colo = t_me / R, rowo = t_me - colo * R;
+    const int cstep = dir * (Wc - 1), cb0 = dir > 0 ? cmin : cmax - (Wc - 1);      // chunk n covers band columns cb0 + n cstep .. + Wc - 1
+    auto loadA = [&](int n) {
+        const int col = cb0 + n * cstep + colo;
+        const int row = (int)floorf(fmaf(bm, (float)col, bl0)) + rowo;
+        const int cc = min(max(col, -2), Wmaj + 1), rc = min(max(row, -2), Wmin + 1);
+        const _Float16* tp = f2v + (long)((cc + 2) * smajS + (rc + 2) * sminS) * 128 + 8 * kg;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            ahf[ks] = *reinterpret_cast<const half8*>(tp + 16 * ks);
+            alf[ks] = *reinterpret_cast<const half8*>(tp + 64 + 16 * ks);
+        }
+    };
+    if (nchunks > 0) loadA(0);                              // arrives under the projections below
+
+    // ---- the samples of this lane: hypotheses k0, k0 + 8, ... (k0 = 2 wave + kg) of pixel slot li.  Straight-line code, two IEEE
+    // divisions per sample, nothing divergent: cell, fractions and band rows go to LDS; the chunk loop only looks things up
+    const int k0 = 2 * wave + kg;
+#pragma unroll 2
+    for (int k = k0; k < D; k += 8) {
+        if (CL_ABL == 3) { *reinterpret_cast<float4*>(desc + (k * CL_DP + li) * 4) = make_float4(__uint_as_float(((unsigned)(cmin + 4 + (k * (cmax - cmin)) / D)) & 0xFFFFu), 0.5f, 0.5f, 0.f); continue; }
+        float u, w;
+        const bool ok = project(k, u, w);
+        const float fu = floorf(u), fw = floorf(w);
+        const float du = ok ? u - fu : 0.f, dw = ok ? w - fw : 0.f;
+        const int iu = ok ? min(max((int)fu, -2), w2) : -2, iw = ok ? min(max((int)fw, -2), h2) : -2;
+        const int sc = smaj ? iw : iu, sr = smaj ? iu : iw;
+        // cells without a corner inside the map read only border zeros (cost_build.hip clamps them into the zero border)
+        const bool zero = iu < -1 || iu > w2 - 1 || iw < -1 || iw > h2 - 1;
+        const int b0 = (int)floorf(fmaf(bm, (float)sc, bl0)), b1 = (int)floorf(fmaf(bm, (float)(sc + 1), bl0));
+        const int r0 = sr - b0, r1 = sr - b1;
+        const bool fits = nchunks > 0 && sc >= cmin && sc < cmax && r0 >= 0 && r0 + 1 < R && r1 >= 0 && r1 + 1 < R;
+        const int hi14 = fits ? (r0 + r1 * 32) : (sr + 4);
+        const int kind2 = zero ? 1 : (fits ? 0 : 2);
+        const unsigned packed = (unsigned)(sc + 4) + ((unsigned)(hi14 & 0x3FFF) << 16) + ((unsigned)kind2 << 30);
+        *reinterpret_cast<float4*>(desc + (k * CL_DP + li) * 4) = make_float4(__uint_as_float(packed), smaj ? dw : du, smaj ? du : dw, 0.f);
+    }
+    CL_STAMP(9);                                            // projections
+    if (CL_ABL == 6) return;
+
+    // ---- per-lane sample cursor
+    int k = valid ? k0 : D;
+    unsigned pk = 3u << 30;                                 // kind 3: done
+    float fm = 0.f, fn = 0.f;
+    auto load_sample = [&]() {                              // (a lane only ever reads descriptors it wrote itself)
+        if (k >= D) { pk = 3u << 30; return; }
+        const float4 d = *reinterpret_cast<const float4*>(desc + (k * CL_DP + li) * 4);
+        pk = CL_ABL == 1 ? (1u << 30) : __float_as_uint(d.x);
+        fm = d.y;
+        fn = d.z;
+    };
+    load_sample();
+    auto direct_value = [&]() -> float {
+        const int sc = (int)(pk & 0xFFFFu) - 4, sr = (int)((pk >> 16) & 0x3FFFu) - 4;
+        const _Float16* t00 = f2v + (long)((sc + 2) * smajS + (sr + 2) * sminS) * 128;
+        return cl_direct(f1row, t00, smajS, sminS, 1.0f - fm, fm, 1.0f - fn, fn);
+    };
+
+    CL_COUNT(24, 1);
+    CL_COUNT(25, nchunks);
+    CL_COUNT(26, R);
+    for (int n = 0; n < nchunks; ++n) {
+        const int cb = cb0 + n * cstep;
+        // ---- dots of this wave's 32 texels with the 32 pixels: 12 MFMAs
+        floatx16 acc0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < (CL_ABL == 2 ? 0 : 4); ++ks) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahf[ks], bh[ks], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahf[ks], bl[ks], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alf[ks], bh[ks], acc0, 0, 0, 0);
+        }
+        CL_STAMP(1);                                        // wait for A + MFMA issue
+        if (n + 1 < nchunks) loadA(n + 1);                  // in flight during the gather below
+        // acc0[r]: texel row (r & 3) + 8 (r >> 2) + 4 kg of this wave's tile, pixel column li
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            prod[row * 32 + li] = acc0[r];
+        }
+        CL_STAMP(2);                                        // MFMA results + dot stores
+        __syncthreads();
+        CL_STAMP(3);                                        // barrier 1
+        // ---- gather: every lane consumes its samples whose cell lies in this chunk; zeros and direct-path samples as they come
+        const int cbe = cb + Wc - 2, cbR = (cb - 4) * R;    // last cell column of the chunk; band index of (column c, row r) = c R + r - cb R
+        for (;;) {
+            const unsigned kind = pk >> 30;
+            const int scp = (int)(pk & 0xFFFFu);            // cell column + 4
+            const bool in = kind == 0 && scp >= cb + 4 && scp <= cbe + 4;
+            const bool behind = kind == 0 && (dir > 0 ? scp < cb + 4 : scp > cbe + 4);
+            const bool consume = in || behind || kind == 1 || kind == 2;
+            if (__ballot(consume) == 0ull) break;
+            CL_COUNT(27, 1);
+            CL_COUNT(28, __popcll(__ballot(consume)));
+            CL_COUNT(29, __popcll(__ballot(behind || kind == 2)));
+            float val = 0.f;
+            if (in) {
+                const int t0 = scp * R + (int)((pk >> 16) & 31u) - cbR - 8 * R;      // (scp - 4 - cb) R + r0  [cbR = (cb - 4) R]
+                const int t1 = t0 + R + (int)((pk >> 21) & 31u) - (int)((pk >> 16) & 31u);
+                const float* d0 = prod + t0 * 32 + li;
+                const float* d1 = prod + t1 * 32 + li;
+                const float wm1 = fm, wm0 = 1.0f - fm, wn1 = fn, wn0 = 1.0f - fn;
+                val = d0[0] * (wn0 * wm0) + d1[0] * (wn0 * wm1) + d0[32] * (wn1 * wm0) + d1[32] * (wn1 * wm1);
+            }
+            if (__ballot(behind || kind == 2) != 0ull) {    // rare: the wave-level test keeps the call off the hot path
+                if (behind || kind == 2) {
+                    if (kind == 0) {                        // re-pack a band sample as a direct one: its cell row from the band row
+                        const int sc = scp - 4;
+                        const int sr = (int)floorf(fmaf(bm, (float)sc, bl0)) + (int)((pk >> 16) & 31u);
+                        pk = (pk & 0xFFFFu) | ((unsigned)(sr + 4) << 16) | (2u << 30);
+                    }
+                    val = direct_value();
+                }
+            }
+            if (consume) {
+                desc[(k * CL_DP + li) * 4 + 3] = val;
+                k += 8;
+                load_sample();
+            }
+        }
+        CL_STAMP(4);                                        // gather
+        __syncthreads();
+        CL_STAMP(5);                                        // barrier 2
+    }
+    // ---- what the chunks did not cover (no band, samples out of order): direct path
+    while (__ballot((pk >> 30) != 3u) != 0ull) {
+        CL_COUNT(30, __popcll(__ballot((pk >> 30) != 3u && (pk >> 30) != 1u)));
+        if ((pk >> 30) != 3u) {
+            float val = 0.f;
+            if ((pk >> 30) != 1u) {
+                if ((pk >> 30) == 0u) {
+                    const int sc = (int)(pk & 0xFFFFu) - 4;
+                    const int sr = (int)floorf(fmaf(bm, (float)sc, bl0)) + (int)((pk >> 16) & 31u);
+                    pk = (pk & 0xFFFFu) | ((unsigned)(sr + 4) << 16) | (2u << 30);
+                }
+                val = direct_value();
+            }
+            desc[(k * CL_DP + li) * 4 + 3] = val;
+            k += 8;
+            load_sample();
+        }
+    }
+    CL_STAMP(6);                                            // leftovers
+    __syncthreads();
+    // ---- rows out: wave w writes pixel slots w, w + 4, ...; lane = hypothesis (one coalesced D-float row per store)
+    float* pv = A.part + (long)v * ((long)h1 * w1) * D;
+    for (int i = wave; i < 32; i += 4) {
+        const int p = pidx[i];
+        if (p >= 0 && lane < D) pv[(long)p * D + lane] = desc[(lane * CL_DP + i) * 4 + 3];
+    }
+    CL_STAMP(7);                                            // rows out
+    CL_FLUSH();
+}
+
+// ---- sum of the per-view partials (view order: deterministic) * scale, origin, pooled levels: wave per pixel, lane = hypothesis
+__global__ __launch_bounds__(256) void cost_lines_reduce_kernel(const float* __restrict__ part, const float* __restrict__ disp_in,
+                                                               float* __restrict__ vol, float* __restrict__ origin_out, int V, long P, int D,
+                                                               int rs, int levels, float scale, int accumulate, float lim, int shift) {
+    const int lane = threadIdx.x & 63;
+    const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    if (origin_out && lane == 0) {
+        float origin = disp_in[p];
+        if (shift && origin < lim) origin = lim;
+        origin_out[p] = origin;
+    }
+    float s = 0.f;
+    if (lane < D)
+        for (int v = 0; v < V; ++v) s += part[((long)v * P + p) * D + lane];
+    float* orow = vol + p * rs;
+    float cur = s * scale;
+    if (levels > 1) {
+        if (lane < D) orow[lane] = cur;
+        int off = 0, n = D;
+        for (int l = 1; l < levels; ++l) {                  // core/corr.py:94-97: (a + b) * 0.5 level by level; element j of level l on lane j << l
+            const int mlen = n / 2;
+            const float other = __shfl_xor(cur, 1 << (l - 1));
+            cur = (cur + other) * 0.5f;
+            off += n;
+            if ((lane & ((1 << l) - 1)) == 0 && (lane >> l) < mlen) orow[off + (lane >> l)] = cur;
+            n = mlen;
+        }
+    } else if (lane < D) {
+        orow[lane] = accumulate ? (orow[lane] + cur) : cur;
+    }
+}
+
+extern "C" long cer_cost_lines_workspace(int V, int h1, int w1, int D) {
+    if (V <= 0 || h1 <= 0 || w1 <= 0 || D <= 0) return CER_EINVAL;
+    return (long)V * h1 * w1 * D * 4 + (long)V * 16 + 256;
+}
+
+extern "C" int cer_cost_lines_f32(const void* fmap1_split, const void* fmap2_split, const float* Pij, const float* disp_in, float* vol,
+                                  float* origin_out, void* workspace, int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride,
+                                  double incre_d, int shift, int mode, int y0, int fuse_levels, float fuse_scale, void* stream) {
+    if (!fmap1_split || !fmap2_split || !Pij || !disp_in || !vol || !workspace) return CER_EINVAL;
+    if (V <= 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || D <= 0 || row_stride < D || (mode != 1 && mode != 2)) return CER_EINVAL;
+    if (C != 64 || D > 64 || V > 4096) return CER_ESHAPE;
+    if (fuse_levels > 1) {
+        if (mode != 1) return CER_EINVAL;
+        int need = 0, n = D;
+        for (int l = 0; l < fuse_levels; ++l) { need += n; n /= 2; }
+        if (row_stride < need || fuse_levels > 6) return CER_ESHAPE;
+    }
+    if ((long)(h2 + 4) * (w2 + 4) >= (1L << 24) || (long)h1 * w1 >= (1L << 24)) return CER_ESHAPE;
+    if (!cer_aligned16(fmap1_split) || !cer_aligned16(fmap2_split) || !cer_aligned16(workspace)) return CER_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const long P = (long)h1 * w1;
+    float* part = (float*)workspace;
+    float* params = part + (long)V * P * D;
+    params = (float*)(((uintptr_t)params + 63) & ~(uintptr_t)63);
+    hipLaunchKernelGGL(cost_lines_setup_kernel, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, st, Pij, params, V, h1, w1, y0);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    ClArgs a;
+    a.f1s = (const _Float16*)fmap1_split;
+    a.f2s = (const _Float16*)fmap2_split;
+    a.Pij = Pij;
+    a.params = params;
+    a.disp_in = disp_in;
+    a.part = part;
+    a.V = V; a.h1 = h1; a.w1 = w1; a.h2 = h2; a.w2 = w2; a.D = D;
+    a.incre = (float)incre_d;
+    a.lim = (float)((D / 2) * incre_d);
+    a.shift = shift;
+    a.y0 = y0;
+    const long tx = (long)((w1 + 31) / 32) * (h1 + 32), ty = (long)((h1 + 31) / 32) * (w1 + 32);
+    a.tpv = (int)(tx > ty ? tx : ty);
+    const long nblk = (long)V * a.tpv;
+    if (nblk >= (1L << 31)) return CER_ESHAPE;
+    hipLaunchKernelGGL(cost_lines_kernel, dim3((unsigned)nblk), dim3(256), 0, st, a);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    const float scale = (fuse_levels > 1 ? fuse_scale : 1.0f) / (float)(1 << (2 * CL_LOG2S));
+    hipLaunchKernelGGL(cost_lines_reduce_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, part, disp_in, vol, origin_out, V, P, D,
+                       row_stride, fuse_levels, scale, mode == 2 ? 1 : 0, a.lim, shift);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}

@@ -72,21 +72,79 @@ def alt_corr_backward(fmap1, fmap2, coords, corr_grad, radius, deterministic=Non
     return g1, g2, gc
 
 
+_OVERFLOW = {}
+
+
+def overflow_flag(device):
+    """Sticky device int32 or-ed by kernels that had to saturate an operand (feature split beyond +-1023, ...): read it with
+    ``check_overflow`` when convenient (reading synchronises)."""
+    key = str(device)
+    f = _OVERFLOW.get(key)
+    if f is None:
+        f = torch.zeros(1, device=device, dtype=torch.int32)
+        _OVERFLOW[key] = f
+    return f
+
+
+def check_overflow(device, reset=True):
+    """True if any kernel since the last reset saturated an operand on ``device`` (one device->host read)."""
+    f = overflow_flag(device)
+    hit = bool(int(f.item()))
+    if reset and hit:
+        f.zero_()
+    return hit
+
+
+def feat_split(x, out=None):
+    """fp32 rows [..., 64] -> split-f16 rows (same shape in bytes: per row 64 hi | 64 lo halves of x * 2^6) for
+    ``cost_build(..., split=...)`` / cer_cost_lines_f32."""
+    if x.shape[-1] != 64:
+        raise RuntimeError("feat_split: rows of 64 channels only")
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (128,), device=x.device, dtype=torch.float16)
+    n = x.numel() // 64
+    L.check(L.load().cer_feat_split_f16(L.dev_ptr(x, "x"), L.dev_ptr(out, "out", torch.float16), n, 64,
+                                        L.dev_ptr(overflow_flag(x.device), "flag", torch.int32), L.cur_stream()), "feat_split")
+    return out
+
+
+_LINES_WS = {}
+
+
+def _lines_workspace(V, h1, w1, D, device):
+    need = int(L.load().cer_cost_lines_workspace(V, h1, w1, D))
+    key = str(device)
+    ws = _LINES_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, device=device, dtype=torch.uint8)
+        _LINES_WS[key] = ws
+    return ws
+
+
 def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, fold, vol=None, accumulate=False, src_hw=None, y0=0,
-               pyramid_scale=None):
+               pyramid_scale=None, split=None):
     """fmap1 [P,C], fmap2 [V,(h2+4)*(w2+4),C] (NHWC, pre-scaled, 2-texel zero border), Pij [V,4,4], disp_in [P].
     (h1, w1): reference grid of this call, first image row ``y0`` (row slabs); ``src_hw``: source-map size (default h1, w1).
     Returns (vol [V,P,rs] or [P,rs], origin [P]).  Level 0 only; call ``pyramid`` next - unless ``pyramid_scale`` is given
-    (fold, no accumulate, D <= 64): then the kernel's epilogue scales level 0 and writes the pooled levels itself."""
+    (fold, no accumulate, D <= 64): then the kernel's epilogue scales level 0 and writes the pooled levels itself.
+    Fold modes at C = 64, D <= 64 run on the epipolar-line-tile kernel (cer_cost_lines_f32) unless ``cer_cost_build_algo(1)``
+    selects the walk; ``split`` = (feat_split(fmap1), feat_split(fmap2)) if the caller already has them (they are the same for
+    every stage of a forward), else they are made here."""
     V, P2, C = fmap2.shape
     P = h1 * w1
     h2, w2 = src_hw if src_hw is not None else (h1, w1)
     if P2 != (h2 + 4) * (w2 + 4):
         raise RuntimeError("cost_build: fmap2 must carry a 2-texel zero border ([V,(h+4)*(w+4),C])")
     _, _, rs = row_layout(D, num_levels)
+    fuse = pyramid_scale is not None
+    if fuse and (not fold or accumulate or D > 64):
+        raise ValueError("cost_build: the fused pyramid needs fold=True, accumulate=False and D <= 64")
+    late_scale = None
+    if fuse and num_levels < 2:          # nothing to pool: the kernels' fused epilogue is keyed on levels > 1, so scale afterwards
+        fuse, late_scale = False, float(pyramid_scale)
     if vol is None:
         shape = (P, rs) if fold else (V, P, rs)
-        if pyramid_scale is not None:
+        if fuse:
             # fused pyramid (the forward's hot path): the kernel writes every level of every row - no 50 MB zero fill; only the
             # alignment pad of a row (rs - used, <= 3 floats) is cleared
             vol = torch.empty(shape, device=fmap1.device, dtype=torch.float32)
@@ -97,14 +155,27 @@ def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, 
             vol = torch.zeros(shape, device=fmap1.device, dtype=torch.float32)     # pooled levels stay 0 until ``pyramid`` runs
     origin = torch.empty(P, device=fmap1.device, dtype=torch.float32)
     mode = (2 if accumulate else 1) if fold else 0
-    fuse = pyramid_scale is not None
-    if fuse and (mode != 1 or D > 64):
-        raise ValueError("cost_build: the fused pyramid needs fold=True, accumulate=False and D <= 64")
-    L.check(L.load().cer_cost_build_f32(L.dev_ptr(fmap1, "fmap1"), L.dev_ptr(fmap2, "fmap2"), L.dev_ptr(Pij, "Pij"),
-                                        L.dev_ptr(disp_in, "disp_in"), L.dev_ptr(vol, "vol"), L.dev_ptr(origin, "origin"),
-                                        V, h1, w1, h2, w2, C, D, rs, float(incre), int(bool(shift)), mode, int(y0),
-                                        num_levels if fuse else 0, float(pyramid_scale) if fuse else 1.0, L.cur_stream()),
-            "cost_build")
+    lib = L.load()
+    if fold and C == 64 and D <= 64 and lib.cer_cost_build_algo(-1) != 1:
+        f1s, f2s = split if split is not None else (None, None)
+        if f1s is None:
+            f1s = feat_split(fmap1)
+        if f2s is None:
+            f2s = feat_split(fmap2)
+        ws = _lines_workspace(V, h1, w1, D, fmap1.device)
+        L.check(lib.cer_cost_lines_f32(L.dev_ptr(f1s, "fmap1_split", torch.float16), L.dev_ptr(f2s, "fmap2_split", torch.float16),
+                                       L.dev_ptr(Pij, "Pij"), L.dev_ptr(disp_in, "disp_in"), L.dev_ptr(vol, "vol"),
+                                       L.dev_ptr(origin, "origin"), L.dev_ptr(ws, "workspace", torch.uint8), V, h1, w1, h2, w2, C, D, rs,
+                                       float(incre), int(bool(shift)), mode, int(y0), num_levels if fuse else 0,
+                                       float(pyramid_scale) if fuse else 1.0, L.cur_stream()), "cost_lines")
+    else:
+        L.check(lib.cer_cost_build_f32(L.dev_ptr(fmap1, "fmap1"), L.dev_ptr(fmap2, "fmap2"), L.dev_ptr(Pij, "Pij"),
+                                       L.dev_ptr(disp_in, "disp_in"), L.dev_ptr(vol, "vol"), L.dev_ptr(origin, "origin"),
+                                       V, h1, w1, h2, w2, C, D, rs, float(incre), int(bool(shift)), mode, int(y0),
+                                       num_levels if fuse else 0, float(pyramid_scale) if fuse else 1.0, L.cur_stream()),
+                "cost_build")
+    if late_scale is not None:
+        pyramid(vol, D, num_levels, scale=late_scale)
     return vol, origin
 
 

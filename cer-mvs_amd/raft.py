@@ -185,6 +185,8 @@ class RAFT(nn.Module):
         net_l, inp_l, f1, f2 = self.encode(images, views, raw=True)
         net_l = ub.prepare_net(net_l, h, w)
         del images
+        # split-f16 operand rows of the cost volume's MFMA products (csrc/cost_lines.hip): the same for every stage
+        split = (ops.feat_split(f1), ops.feat_split(f2)) if (views and self.dim_fmap == 64) else None
 
         disp = torch.zeros(P, device=dev, dtype=torch.float32)
         hoisted_all = ub.hoist_all(inp_l, h, w, len(self.cascade))
@@ -194,7 +196,7 @@ class RAFT(nn.Module):
             single = self.view_group is None   # no cross-rank sum between the build and the pooling: fuse them
             if views:
                 vol, origin = ops.cost_build(f1, f2, Pij, disp, D, incre, stage == 0, h, w, ub.num_levels, fold=True,
-                                             pyramid_scale=(1.0 / V) if (single and D <= 64) else None)
+                                             pyramid_scale=(1.0 / V) if (single and D <= 64) else None, split=split)
             else:                      # more ranks than views: contribute zeros
                 _, _, rs = ops.row_layout(D, ub.num_levels)
                 vol = torch.zeros(P, rs, device=dev)

@@ -95,10 +95,31 @@ int cer_cost_build_f32(const float* fmap1, const float* fmap2, const float* Pij,
                        float* vol, float* origin_out,
                        int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride,
                        double incre, int shift, int mode, int y0, int fuse_levels, float fuse_scale, void* stream);
-/* Implementation choice of the fold modes (1, 2) of cer_cost_build_f32: 0 / 1 = the wave-per-pixel walk (default), 2 = the
- * round-2 experiment "band GEMM + 4-tap gather" (csrc/cost_gemm.hip) wherever it applies (C == 64): same results, tested against
- * the walk, not faster yet.  Returns the previous setting. */
+/* Implementation choice of the fold modes (1, 2) of cer_cost_build_f32 when called through the host layer: 0 = automatic
+ * (cer_cost_lines_f32 below wherever it applies, else the walk), 1 = always the wave-per-pixel walk.  Returns the previous
+ * setting.  (Process-wide switch for tests and A/B timing; the library's entry points themselves are stateless.) */
 int cer_cost_build_algo(int algo);
+
+/* ------------------------------------------------------------------------------------
+ * The same cost volume (fold modes 1 / 2 of cer_cost_build_f32; C == 64, D <= 64) on epipolar-line tiles
+ * (csrc/cost_lines.hip): per source view the reference grid is cut into 64-pixel digital lines along the view's
+ * epipolar direction; per (view, tile) the dot products of the tile's reference rows with every texel of the tile's
+ * epipolar band are MFMA products (split-f16, fp32-class) and every sample gathers its 4 dots from LDS.  Cells, weights
+ * and the treatment of out-of-map / non-finite samples are those of cer_cost_build_f32 (same fp32 expressions); results
+ * agree to fp32 rounding of the 64-channel dot.
+ *
+ * cer_feat_split_f16: fp32 rows [texels, 64] -> split-f16 rows [texels][64 hi | 64 lo] of x * 2^6 (hi = f16(xs),
+ *   lo = f16(xs - hi)); same bytes per texel.  |x| > 1023 saturates: *overflow_flag (device int, may be NULL) is or-ed with 1.
+ *   Apply to fmap1 [P,64] and to the bordered fmap2 [V,(h2+4)*(w2+4),64] (the zero border stays zero).
+ * cer_cost_lines_workspace: bytes of `workspace` (per-view partial volumes [V,P,D] + tile parameters).
+ * cer_cost_lines_f32: arguments as cer_cost_build_f32 with the split rows in place of fmap1 / fmap2; mode 1 or 2 only.
+ */
+int cer_feat_split_f16(const float* src, void* dst, long texels, int C, int* overflow_flag, void* stream);
+long cer_cost_lines_workspace(int V, int h1, int w1, int D);
+int cer_cost_lines_f32(const void* fmap1_split, const void* fmap2_split, const float* Pij, const float* disp_in,
+                       float* vol, float* origin_out, void* workspace,
+                       int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride,
+                       double incre, int shift, int mode, int y0, int fuse_levels, float fuse_scale, void* stream);
 
 /* Correlation pyramid (reference: core/corr.py:94-97, F.avg_pool2d([1,2]) x (L-1)), in place on
  * rows laid out [level0 (D) | level1 (D/2) | level2 (D/4) | ... | pad]: first level0 *= scale

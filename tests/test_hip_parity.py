@@ -242,56 +242,92 @@ def test_conv3x3_disp_encoder_source(dev):
         assert rel_l1(out.cpu(), ref) < 2e-6, mode
 
 
-@pytest.mark.parametrize("geom", ["horizontal", "diagonal", "vertical", "wild"])
-@pytest.mark.parametrize("D,stage0", [(64, True), (44, False), (20, False)])
-def test_cost_build_band_gemm_matches_walk(dev, D, stage0, geom):
-    """The round-2 fold kernel (band GEMM + 4-tap gather, csrc/cost_gemm.hip) against the round-1 wave-per-pixel walk on the
-    same inputs: epipolar lines of every direction, a view whose projection blows up (Z crosses 0 inside the hypothesis range:
-    the bounding box never fits and the direct per-sample path runs), odd image sizes (partial tiles), a row-slab offset,
-    accumulate mode and the fused pyramid."""
-    from cer_mvs_amd import _lib as L, ops
+def _lines_case(dev, D, stage0, geom, h1, w1):
     from cer_mvs_amd.corr import fmaps_to_nhwc
-    h1, w1, V, C = 19, 45, 3, 64
+    V, C = 3, 64
     fm = hashed((1, V + 1, C, h1, w1), 311, -2, 2).to(dev)
     f1 = fmaps_to_nhwc(fm[0, 0:1])[0]
     f2 = fmaps_to_nhwc(fm[0, 1:], border=2)
     Pij = torch.eye(4).repeat(V, 1, 1)
     for v in range(V):
         if geom == "horizontal":
-            Pij[v, 0, 3] = (900.0 if stage0 else 9000.0) * (v + 1)
+            Pij[v, 0, 3] = (900.0 if stage0 else 9000.0) * (v + 1) * (1 if v != 1 else -1)
         elif geom == "vertical":
             Pij[v, 1, 3] = -(700.0 if stage0 else 7000.0) * (v + 1)
         elif geom == "diagonal":
-            Pij[v, 0, 3], Pij[v, 1, 3] = 600.0 * (v + 1), -500.0 * (v + 1)
+            Pij[v, 0, 3], Pij[v, 1, 3] = 600.0 * (v + 1), (-500.0, 450.0, -80.0)[v] * (v + 1)
             Pij[v, 0, 1] = 0.05 * v
+        elif geom == "rotation":          # no baseline: every hypothesis of a pixel lands on one point (+ a small homography)
+            Pij[v, 0, 1], Pij[v, 1, 0], Pij[v, 0, 2], Pij[v, 1, 2] = 0.02 * v, -0.02 * v, 1.3 * v, -0.7
+        elif geom == "forward":           # epipole inside the image: lines of every direction within one view
+            Pij[v, 0, 3], Pij[v, 1, 3], Pij[v, 2, 3] = 0.5 * w1 * 400.0, 0.5 * h1 * 400.0, 400.0 * (v + 1)
+        elif geom == "converging":        # rotation + baseline (the bench scene's kind of pair): the epipole is finite, far away
+            th = 0.12 * (v + 1) * (1 if v % 2 else -1)
+            f = 1.8 * w1
+            K = torch.tensor([[f, 0, w1 / 2], [0, f, h1 / 2], [0, 0, 1.0]])
+            R = torch.tensor([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]], dtype=torch.float32)
+            Rx = torch.tensor([[1, 0, 0], [0, np.cos(0.04 * v), -np.sin(0.04 * v)], [0, np.sin(0.04 * v), np.cos(0.04 * v)]], dtype=torch.float32)
+            R = Rx @ R
+            c = torch.tensor([0.0, 0.0, 600.0])
+            Pij[v, :3, :3] = K @ R @ torch.linalg.inv(K)
+            Pij[v, :3, 3] = K @ (c - R @ c)
         else:   # wild: Z = 1 + m[11] * hyp crosses zero inside the range; one view entirely behind the camera
             Pij[v, 0, 3], Pij[v, 2, 3] = 4000.0, (-700.0, -1500.0, 0.0)[v]
             if v == 2:
                 Pij[v, 2, 2] = -1.0
-    Pij = Pij.to(dev)
     d0 = hashed((h1 * w1,), 312, 0.0005, 0.002).to(dev) if not stage0 else torch.zeros(h1 * w1, device=dev)
-    incre = 0.0025 / (64 if stage0 else 320)
+    return f1, f2, Pij.to(dev), d0, V
+
+
+@pytest.mark.parametrize("geom", ["horizontal", "diagonal", "vertical", "wild", "rotation", "forward", "converging"])
+@pytest.mark.parametrize("D,stage0", [(64, True), (44, False), (20, False)])
+def test_cost_lines_matches_walk(dev, D, stage0, geom):
+    """The round-3 fold kernel (epipolar-line tiles: MFMA band products + 4-tap gather, csrc/cost_lines.hip) against the
+    wave-per-pixel walk on the same inputs: epipolar lines of every direction (both tile axes, both band axes, both travel
+    directions), a view whose projection blows up (Z crosses 0 inside the hypothesis range: direct per-sample path), no
+    baseline, an epipole inside the image, image sizes with partial tiles and several segments, a row-slab offset,
+    accumulate mode and the fused pyramid."""
+    from cer_mvs_amd import _lib as L, ops
     lib = L.load()
-    res = {}
-    for algo in (1, 2):
-        prev = lib.cer_cost_build_algo(algo)
-        try:
-            a, oa = ops.cost_build(f1, f2, Pij, d0, D, incre, stage0, h1, w1, 3, fold=True)
-            b, ob = ops.cost_build(f1, f2, Pij, d0, D, incre, stage0, h1, w1, 3, fold=True, pyramid_scale=1.0 / V if D <= 64 else None)
-            c, _ = ops.cost_build(f1, f2, Pij, d0, D, incre, stage0, h1, w1, 3, fold=True, vol=a.clone(), accumulate=True)
-            s_, _ = ops.cost_build(f1[5 * w1:], f2, Pij, d0[5 * w1:], D, incre, stage0, h1 - 5, w1, 3, fold=True, src_hw=(h1, w1), y0=5)
-            res[algo] = (a, oa, b, ob, c, s_)
-        finally:
-            lib.cer_cost_build_algo(prev)
-    ref, new = res[1], res[2]
-    n = D + D // 2 + D // 4
-    assert torch.equal(ref[1], new[1]) and torch.equal(ref[3], new[3])                    # origins
-    mag = ref[0][:, :D].abs().max().clamp_min(1e-6)
-    for i, cols in ((0, D), (2, n), (4, D), (5, D)):
-        err = (ref[i][:, :cols] - new[i][:, :cols]).abs().max()
-        assert err <= 2e-6 * max(float(mag), 1.0) * (2 if i == 4 else 1), (i, float(err), float(mag))
-    assert torch.equal(new[5][:, :D], new[0][5 * w1:, :D])                                    # the slab sees the same samples
-    assert new[0][:, :D].abs().sum() > 0
+    for h1, w1 in ((19, 45), (70, 150)):
+        f1, f2, Pij, d0, V = _lines_case(dev, D, stage0, geom, h1, w1)
+        incre = 0.0025 / (64 if stage0 else 320)
+        res = {}
+        for algo in (1, 0):
+            prev = lib.cer_cost_build_algo(algo)
+            try:
+                a, oa = ops.cost_build(f1, f2, Pij, d0, D, incre, stage0, h1, w1, 3, fold=True)
+                b, ob = ops.cost_build(f1, f2, Pij, d0, D, incre, stage0, h1, w1, 3, fold=True, pyramid_scale=1.0 / V)
+                c, _ = ops.cost_build(f1, f2, Pij, d0, D, incre, stage0, h1, w1, 3, fold=True, vol=a.clone(), accumulate=True)
+                s_, _ = ops.cost_build(f1[5 * w1:], f2, Pij, d0[5 * w1:], D, incre, stage0, h1 - 5, w1, 3, fold=True, src_hw=(h1, w1), y0=5)
+                res[algo] = (a, oa, b, ob, c, s_)
+            finally:
+                lib.cer_cost_build_algo(prev)
+        ref, new = res[1], res[0]
+        n = D + D // 2 + D // 4
+        assert torch.equal(ref[1], new[1]) and torch.equal(ref[3], new[3])                    # origins
+        mag = max(float(ref[0][:, :D].abs().max()), 1.0)
+        for i, cols in ((0, D), (2, n), (4, D), (5, D)):
+            err = float((ref[i][:, :cols] - new[i][:, :cols]).abs().max())
+            assert err <= 4e-6 * mag * (2 if i == 4 else 1), (geom, h1, w1, i, err, mag)
+        assert float((new[5][:, :D] - new[0][5 * w1:, :D]).abs().max()) <= 4e-6 * mag         # the slab sees the same samples
+        assert new[0][:, :D].abs().sum() > 0
+    assert not ops.check_overflow(dev)
+
+
+def test_feat_split_roundtrip_and_overflow_flag(dev):
+    """cer_feat_split_f16: hi + lo reconstructs x * 64 to 2^-22 relative; a value beyond +-1023 saturates and raises the
+    sticky overflow flag (saturation must not be silent)."""
+    from cer_mvs_amd import ops
+    x = hashed((500, 64), 881, -900.0, 900.0).to(dev)
+    x[3, 5] = 1e-4
+    s = ops.feat_split(x).float()
+    rec = (s[:, :64] + s[:, 64:]) / 64.0
+    assert float(((rec - x).abs() / x.abs().clamp_min(1e-3)).max()) < 3e-7
+    assert not ops.check_overflow(dev)
+    x[7, 9] = 1500.0
+    ops.feat_split(x)
+    assert ops.check_overflow(dev) and not ops.check_overflow(dev)            # reported once, then cleared
 
 
 @pytest.mark.parametrize("D", [64, 44, 20])

@@ -24,13 +24,30 @@ with torch.no_grad():
     Pij = pij_matrices(p[0], k[0], [0] * V, list(range(1, V + 1))).to(dev)
     net_l, inp_l, f1, f2 = model.encode(images.to(dev).float() * (2 / 255.0) - 1, list(range(1, V + 1)))
     stages = list(model.stages())
+    from cer_mvs_amd import _lib as L
+    lib = L.load()
+    split = (ops.feat_split(f1), ops.feat_split(f2))
     for st, (D, incre, T) in enumerate(stages):
         d_in = torch.zeros(h * w, device=dev) if st == 0 else disp1
-        fn = lambda: ops.cost_build(f1, f2, Pij, d_in, D, incre, st == 0, h, w, model.update_block.num_levels, fold=True)
-        fn(); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            fn()
-        e1.record(); torch.cuda.synchronize()
-        print(f"stage {st}: D={D} cost_build {1e3 * e0.elapsed_time(e1) / 5:.1f} us")
+        res = {}
+        for algo, name in ((1, "walk"), (0, "lines")):
+            lib.cer_cost_build_algo(algo)
+            fn = lambda: ops.cost_build(f1, f2, Pij, d_in, D, incre, st == 0, h, w, model.update_block.num_levels, fold=True,
+                                        pyramid_scale=1.0 / V, split=split)
+            res[name] = fn()[0]
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            print(f"stage {st}: D={D} cost_build[{name}] {1e3 * e0.elapsed_time(e1) / 5:.1f} us")
+        lib.cer_cost_build_algo(0)
+        a, b = res["walk"], res["lines"]
+        print(f"   max |walk - lines| = {float((a - b).abs().max()):.3e}  (max |walk| = {float(a.abs().max()):.3e}, rel-L1 {float((a - b).abs().sum() / a.abs().sum()):.3e})")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        ops.feat_split(f1); ops.feat_split(f2)
+    e1.record(); torch.cuda.synchronize()
+    print(f"feat_split (f1 + f2): {1e3 * e0.elapsed_time(e1) / 5:.1f} us")
