@@ -1,7 +1,7 @@
 // Library-level entry points of libcermvs.so (include/cer_mvs.h).
 #include "common.hpp"
 
-extern "C" int cer_abi_version(void) { return 1028; }
+extern "C" int cer_abi_version(void) { return 1030; }
 
 extern "C" const char* cer_error_string(int code) {
     switch (code) {
@@ -18,4 +18,14 @@ extern "C" int cer_device_count(void) {
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) return -(int)e - 100;
     return n;
+}
+
+// ---- sticky overflow flag: a caller-owned device int; kernels that saturate a split-f16 operand or into it (bit 1: feature rows of
+// the cost volume, cer_feat_split_f16 takes its flag explicitly; bit 2: the hidden map of the fused delta head; cer_f16_scan_overflow
+// sets the bit it is given).  One per process (one process per GPU); NULL (default) disables the in-kernel checks.
+static int* g_overflow_flag = nullptr;
+int* cer_overflow_flag_get() { return g_overflow_flag; }
+extern "C" int cer_overflow_flag(int* flag) {
+    g_overflow_flag = flag;
+    return CER_OK;
 }

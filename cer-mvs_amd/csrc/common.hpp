@@ -32,6 +32,9 @@ __device__ __forceinline__ void cer_split8(const float (&v)[8], cer_h8& hi, cer_
 }
 #endif
 
+// process-wide sticky overflow flag (cer_overflow_flag in capi.hip): a device int that saturating conversions or into, or null
+int* cer_overflow_flag_get();
+
 static inline bool cer_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- cross-lane sum over one 16-lane DPP row (4 v_add_f32_dpp, no LDS) -------------------

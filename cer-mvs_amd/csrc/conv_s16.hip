@@ -71,6 +71,7 @@ struct S16Args {
     float disp_scale;                      // generated disparity features
     float proj_inv;                        // DELTA: 1 / (hidden scale * w2 scale)
     int out_split;
+    int* flag;                             // sticky overflow flag (cer_overflow_flag) or null
 };
 
 // ---- operand split: 8 fp32 -> hi | lo halves of v * scale (packed conversions)
@@ -531,6 +532,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
         static_assert(WN_ * MT * 9 * 32 * 4 <= 2 * ABUF, "reduction scratch does not fit");
         barrier();                                         // every wave has finished reading the activation buffers
         const float hs = a.invS * (float)(1 << SX_HID_LOG2);
+        float hmax = 0.f;                                  // largest hidden activation of this lane (the map never reaches HBM: checked here)
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             floatx16 tm;
@@ -545,6 +547,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
                     v[e] = fmaxf(__uint_as_float(sw[0]), 0.f);
                     v[4 + e] = fmaxf(__uint_as_float(sw[1]), 0.f);
                 }
+                hmax = fmaxf(hmax, fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7]))));
                 half8 hh, hl;
                 sx_split8(v, hs, hh, hl);
                 const half8 wh = *reinterpret_cast<const half8*>(w2 + (jp * 2 + 0) * 512 + lane * 8);
@@ -559,6 +562,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
             for (int r = 0; r < 4; ++r) rp[(r + 4 * kg) * 32] = tm[r];
             if (kg == 0) rp[8 * 32] = tm[4];
         }
+        if (a.flag && __ballot(!(hmax * hs <= 65504.0f)) != 0ull && lane == 0) atomicOr(a.flag, 2);     // saturated (or not finite)
         barrier();
         const long P = (long)a.h * a.w;
         for (int idx = tid; idx < MT * 9 * 32; idx += 256) {
@@ -995,6 +999,7 @@ extern "C" int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, con
     a.aux_inv = ldexpf(1.0f, -log2s_aux);
     a.proj_inv = ldexpf(1.0f, -(SX_HID_LOG2 + log2s_aux));         // DELTA: log2s_aux carries the projection weights' scale
     a.out_split = out_split;
+    a.flag = cer_overflow_flag_get();
     hipStream_t st = (hipStream_t)stream;
     const int ncu = sx_num_cus();
     // Tile height: blocks are 4 waves, two of them fit a CU.  A launch costs rounds x (tile rows + a fixed prologue / epilogue
@@ -1084,6 +1089,28 @@ __global__ __launch_bounds__(256) void s16_layout_kernel(const float* __restrict
 }
 
 extern "C" long cer_s16_padded_pixels(int h, int w) { return (h <= 0 || w <= 0) ? CER_EINVAL : (long)((h + 1) / 2) * ((w + 15) / 16) * 32; }
+
+// ---- saturation scan of a split-f16 tensor (frag16 / split rows): any half at the f16 maximum (the clamp of the split) or not finite
+__global__ __launch_bounds__(256) void f16_scan_kernel(const uint4* __restrict__ p, long n16, int* __restrict__ flag, int bit) {
+    bool hit = false;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
+        const uint4 q = p[i];
+        const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hit |= ((w[j] & 0x7FFFu) >= 0x7BFFu) || ((w[j] & 0x7FFF0000u) >= 0x7BFF0000u);
+    }
+    if (__ballot(hit) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, bit);
+}
+extern "C" int cer_f16_scan_overflow(const void* data, long bytes, int* flag, int bit, void* stream) {
+    if (!data || !flag || bytes <= 0 || bytes % 16 != 0) return CER_EINVAL;
+    if (!cer_aligned16(data)) return CER_EALIGN;
+    const long n16 = bytes / 16;
+    long blocks = (n16 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(f16_scan_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)data, n16, flag, bit);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}
 
 extern "C" int cer_s16_layout_f32(const float* src, float* dst, int h, int w, int C, int layout, int log2s, int inverse, void* stream) {
     if (!src || !dst || h <= 0 || w <= 0 || C <= 0 || layout < 0 || layout > 2) return CER_EINVAL;

@@ -183,6 +183,7 @@ struct ClArgs {
     const float* params;      // [V][4]  cost_lines_setup_kernel
     const float* disp_in;     // [P]
     float* part;              // [V][P][D]  per-view partial volume, scaled by 2^(2 CL_LOG2S)
+    const int* slot;          // [V] or null: view v's rows are block slot[v] of f2s (sharded forward: the gathered layout)
     int V, h1, w1, h2, w2, D;
     float incre, lim;
     int shift, y0, tpv;
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256, 3) void cost_lines_kernel(const ClArgs A) {
     CL_STAMP(11);                                           // band analysis
     if (CL_ABL == 5) return;
 
-    const _Float16* f2v = A.f2s + (long)v * (long)(h2 + 4) * wp * 128;
+    const _Float16* f2v = A.f2s + (long)(A.slot ? A.slot[v] : v) * (long)(h2 + 4) * wp * 128;
 
     // ---- A fragments of a chunk: wave `wave` owns band texels 32 wave .. + 31 of the chunk (lane: texel li, channels as above)
     half8 ahf[4], alf[4];
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(256, 3) void cost_lines_kernel(const ClArgs A) {
                 const float wm1 = fm, wm0 = 1.0f - fm, wn1 = fn, wn0 = 1.0f - fn;
                 val = d0[0] * (wn0 * wm0) + d1[0] * (wn0 * wm1) + d0[32] * (wn1 * wm0) + d1[32] * (wn1 * wm1);
             }
-            if (__ballot(behind || kind == 2) != 0ull) {    // rare: the wave-level test keeps the call off the hot path
+            if (CL_ABL != 7 && __ballot(behind || kind == 2) != 0ull) {    // rare: the wave-level test keeps the call off the hot path
                 if (behind || kind == 2) {
                     if (kind == 0) {                        // re-pack a band sample as a direct one: its cell row from the band row
                         const int sc = scp - 4;
@@ -544,8 +545,8 @@ extern "C" long cer_cost_lines_workspace(int V, int h1, int w1, int D) {
     return (long)V * h1 * w1 * D * 4 + (long)V * 16 + 256;
 }
 
-extern "C" int cer_cost_lines_f32(const void* fmap1_split, const void* fmap2_split, const float* Pij, const float* disp_in, float* vol,
-                                  float* origin_out, void* workspace, int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride,
+extern "C" int cer_cost_lines_f32(const void* fmap1_split, const void* fmap2_split, const int* view_slot, const float* Pij, const float* disp_in,
+                                  float* vol, float* origin_out, void* workspace, int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride,
                                   double incre_d, int shift, int mode, int y0, int fuse_levels, float fuse_scale, void* stream) {
     if (!fmap1_split || !fmap2_split || !Pij || !disp_in || !vol || !workspace) return CER_EINVAL;
     if (V <= 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || D <= 0 || row_stride < D || (mode != 1 && mode != 2)) return CER_EINVAL;
@@ -572,6 +573,7 @@ extern "C" int cer_cost_lines_f32(const void* fmap1_split, const void* fmap2_spl
     a.params = params;
     a.disp_in = disp_in;
     a.part = part;
+    a.slot = view_slot;
     a.V = V; a.h1 = h1; a.w1 = w1; a.h2 = h2; a.w2 = w2; a.D = D;
     a.incre = (float)incre_d;
     a.lim = (float)((D / 2) * incre_d);

@@ -83,16 +83,54 @@ def overflow_flag(device):
     if f is None:
         f = torch.zeros(1, device=device, dtype=torch.int32)
         _OVERFLOW[key] = f
+        L.check(L.load().cer_overflow_flag(L.dev_ptr(f, "flag", torch.int32)), "overflow_flag")     # in-kernel checks report here too
     return f
 
 
+def scan_overflow(t, bit=4):
+    """Or ``bit`` into the device's overflow flag if any half of the split-f16 tensor ``t`` (frag16 activations, split feature
+    rows; any dtype, the bytes are scanned) is saturated or not finite.  ~8 us per 30 MB."""
+    nbytes = t.numel() * t.element_size()
+    L.check(L.load().cer_f16_scan_overflow(ctypes.c_void_p(t.data_ptr()), nbytes, L.dev_ptr(overflow_flag(t.device), "flag", torch.int32),
+                                           int(bit), L.cur_stream()), "scan_overflow")
+
+
 def check_overflow(device, reset=True):
-    """True if any kernel since the last reset saturated an operand on ``device`` (one device->host read)."""
+    """Non-zero if any kernel since the last reset saturated an operand on ``device`` (one device->host read): bit 1 = cost-volume
+    feature rows, 2 = hidden map of the delta head, 4 = an update-block activation tensor (``scan_overflow``)."""
     f = overflow_flag(device)
-    hit = bool(int(f.item()))
+    hit = int(f.item())
     if reset and hit:
         f.zero_()
     return hit
+
+
+_OVERFLOW_SNAP = {}
+
+
+def overflow_snapshot(device):
+    """Enqueue an asynchronous copy of the flag into pinned host memory (end of a forward); ``overflow_poll`` reads it later
+    without synchronising."""
+    key = str(device)
+    snap = _OVERFLOW_SNAP.get(key)
+    if snap is None:
+        snap = [torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event()]
+        _OVERFLOW_SNAP[key] = snap
+    snap[0].copy_(overflow_flag(device), non_blocking=True)
+    snap[1].record()
+
+
+def overflow_poll(device):
+    """Bits of the last completed ``overflow_snapshot`` (the device flag is cleared on a hit), 0 if clean, None if the
+    snapshot has not completed yet or none was taken - never blocks."""
+    snap = _OVERFLOW_SNAP.get(str(device))
+    if snap is None or not snap[1].query():
+        return None
+    bits = int(snap[0][0])
+    if bits:
+        overflow_flag(device).zero_()
+        snap[0].zero_()
+    return bits
 
 
 def feat_split(x, out=None):
@@ -129,8 +167,16 @@ def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, 
     (fold, no accumulate, D <= 64): then the kernel's epilogue scales level 0 and writes the pooled levels itself.
     Fold modes at C = 64, D <= 64 run on the epipolar-line-tile kernel (cer_cost_lines_f32) unless ``cer_cost_build_algo(1)``
     selects the walk; ``split`` = (feat_split(fmap1), feat_split(fmap2)) if the caller already has them (they are the same for
-    every stage of a forward), else they are made here."""
-    V, P2, C = fmap2.shape
+    every stage of a forward), else they are made here; a third element ``slots`` (int32 [V], device) says that view v's split
+    rows are block slots[v] of the second element (any leading shape; the sharded forward's gathered buffer) - ``fmap2`` may then
+    be None and ``V`` = len(slots)."""
+    if fmap2 is None:
+        if split is None or len(split) < 3 or src_hw is None:
+            raise ValueError("cost_build: without fmap2 the split rows, their view slots and src_hw are required")
+        V, C = int(split[2].numel()), 64
+        P2 = (src_hw[0] + 4) * (src_hw[1] + 4)
+    else:
+        V, P2, C = fmap2.shape
     P = h1 * w1
     h2, w2 = src_hw if src_hw is not None else (h1, w1)
     if P2 != (h2 + 4) * (w2 + 4):
@@ -156,19 +202,22 @@ def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, 
     origin = torch.empty(P, device=fmap1.device, dtype=torch.float32)
     mode = (2 if accumulate else 1) if fold else 0
     lib = L.load()
-    if fold and C == 64 and D <= 64 and lib.cer_cost_build_algo(-1) != 1:
-        f1s, f2s = split if split is not None else (None, None)
+    slots = split[2] if (split is not None and len(split) > 2) else None
+    if fold and C == 64 and D <= 64 and (fmap2 is None or lib.cer_cost_build_algo(-1) != 1):
+        f1s, f2s = split[:2] if split is not None else (None, None)
         if f1s is None:
             f1s = feat_split(fmap1)
         if f2s is None:
             f2s = feat_split(fmap2)
         ws = _lines_workspace(V, h1, w1, D, fmap1.device)
         L.check(lib.cer_cost_lines_f32(L.dev_ptr(f1s, "fmap1_split", torch.float16), L.dev_ptr(f2s, "fmap2_split", torch.float16),
-                                       L.dev_ptr(Pij, "Pij"), L.dev_ptr(disp_in, "disp_in"), L.dev_ptr(vol, "vol"),
+                                       L.dev_ptr(slots, "view_slot", torch.int32), L.dev_ptr(Pij, "Pij"), L.dev_ptr(disp_in, "disp_in"), L.dev_ptr(vol, "vol"),
                                        L.dev_ptr(origin, "origin"), L.dev_ptr(ws, "workspace", torch.uint8), V, h1, w1, h2, w2, C, D, rs,
                                        float(incre), int(bool(shift)), mode, int(y0), num_levels if fuse else 0,
                                        float(pyramid_scale) if fuse else 1.0, L.cur_stream()), "cost_lines")
     else:
+        if fmap2 is None:
+            raise RuntimeError("cost_build: this shape needs the fp32 walk, which takes fmap2 itself")
         L.check(lib.cer_cost_build_f32(L.dev_ptr(fmap1, "fmap1"), L.dev_ptr(fmap2, "fmap2"), L.dev_ptr(Pij, "Pij"),
                                        L.dev_ptr(disp_in, "disp_in"), L.dev_ptr(vol, "vol"), L.dev_ptr(origin, "origin"),
                                        V, h1, w1, h2, w2, C, D, rs, float(incre), int(bool(shift)), mode, int(y0),

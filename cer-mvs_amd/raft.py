@@ -47,6 +47,12 @@ class RAFT(nn.Module):
         self._engines = None
         self._src_buf = {}
         self.last_timings = None
+        # What to do when a split-f16 kernel had to clamp an operand (ops.check_overflow; cer_mvs.h "Saturation is never silent"):
+        #   "lazy"  (default) the flag is read at the START of the next forward (no extra synchronisation) and by check_overflow();
+        #           a hit raises there;  "raise": read at the end of every forward (one device->host read);  "fallback": as "raise",
+        #           but the forward is repeated with the wide-range arithmetic (gru_precision "f16x3", fp32 cost-volume walk);
+        #   "ignore": never read.
+        self.overflow_policy = "lazy"
         # packed encoder weights are a cache of the parameters: drop them whenever parameters are (re)loaded - through this
         # module, a wrapper (nn.DataParallel(model).load_state_dict, as the reference's inference.py does) or a submodule
         for m in (self, self.fnet, self.cnet):
@@ -54,6 +60,22 @@ class RAFT(nn.Module):
 
     def _drop_engines(self):
         self._engines = None
+
+    _OVERFLOW_WHAT = {1: "cost-volume feature rows beyond +-1023 (after the reference's /8)", 2: "hidden map of the delta head beyond 4094",
+                      4: "a ReLU-class activation of the update block (inp, corr features) beyond 4094"}
+
+    def check_overflow(self, device=None, raise_error=True):
+        """Read (and clear) the sticky saturation flag of the split-f16 kernels; returns the bits, raises RuntimeError on a hit."""
+        device = device if device is not None else next(self.parameters()).device
+        bits = ops.check_overflow(device)
+        if bits and raise_error:
+            self._raise_overflow(bits)
+        return bits
+
+    def _raise_overflow(self, bits):
+        what = "; ".join(v for k, v in self._OVERFLOW_WHAT.items() if bits & k)
+        raise RuntimeError(f"cer-mvs_amd: a split-f16 kernel saturated an operand ({what}): the result of that forward is not fp32-class. "
+                           "Use RAFT(..., gru_precision='f16x3') / _lib.load().cer_cost_build_algo(1), or overflow_policy='fallback'.")
 
     def refresh_weights(self):
         """Call after mutating parameters in place: drops every packed copy (encoder engines, update-block packs)."""
@@ -157,6 +179,29 @@ class RAFT(nn.Module):
         batch, num, ch, ht, wd = images.shape
         if batch != 1:
             raise RuntimeError("RAFT.forward: batch must be 1 in test mode")
+        if self.overflow_policy == "lazy":
+            bits = ops.overflow_poll(dev)              # what an EARLIER forward left (asynchronous snapshot: never blocks)
+            if bits:
+                self._raise_overflow(bits)
+        elif self.overflow_policy in ("raise", "fallback") and self.view_group is None:
+            out = self._forward_fast(images, poses, intrinsics, scale, do_report)
+            bits = self.check_overflow(dev, raise_error=self.overflow_policy == "raise")
+            if bits:                                   # fallback: repeat with the wide-range arithmetic
+                from . import _lib as L
+                mode, algo = self.update_block.conv_mode, L.load().cer_cost_build_algo(1 if bits & 1 else -1)
+                self.update_block.conv_mode = "f16x3" if bits & 6 else mode
+                try:
+                    out = self._forward_fast(images, poses, intrinsics, scale, do_report)
+                finally:
+                    self.update_block.conv_mode = mode
+                    L.load().cer_cost_build_algo(algo)
+                ops.check_overflow(dev)
+            return out
+        return self._forward_fast(images, poses, intrinsics, scale, do_report)
+
+    def _forward_fast(self, images, poses, intrinsics, scale, do_report):
+        dev = images.device
+        batch, num, ch, ht, wd = images.shape
         if self.view_group is not None and self.shard == "slab":
             from . import slab
             ex = slab.DistExchange(self.view_group)
@@ -207,6 +252,8 @@ class RAFT(nn.Module):
             if do_report and stage > 0:
                 report()
             ub.run(T, vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws)
+        if self.overflow_policy == "lazy":
+            ops.overflow_snapshot(dev)
         return disp.view(1, 1, h, w) * s
 
     def _forward_literal(self, images, poses, intrinsics, scale, do_report):

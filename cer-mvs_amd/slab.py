@@ -47,6 +47,23 @@ class LocalExchange:
     def wait(self, handle):
         return handle
 
+    def gather_flat_async(self, tensors, tag="f"):
+        """Start gathering every rank's tensor into ONE persistent [G, ...] buffer; ``wait_flat`` returns it per local rank."""
+        t = tensors[0]
+        key = (tag, tuple(t.shape), t.device, t.dtype)
+        bufs = getattr(self, "_gf", None)
+        if bufs is None:
+            bufs = self._gf = {}
+        if key not in bufs:
+            bufs[key] = torch.empty((self.G,) + tuple(t.shape), device=t.device, dtype=t.dtype)
+        out = bufs[key]
+        for g, x in enumerate(tensors):
+            out[g].copy_(x)
+        return out
+
+    def wait_flat(self, handle):
+        return [handle for _ in range(self.G)]
+
     def neighbor_exchange(self, bufs):
         """Simulated point-to-point halo refresh: rank g sees the bottom half of g-1's buffer and the top half of g+1's
         (copies, like the real receive buffers)."""
@@ -142,6 +159,28 @@ class DistExchange:
         return dist.all_gather(out, t, group=self.group, async_op=True), out, t
 
     def wait(self, handle):
+        handle[0].wait()
+        return [handle[1]]
+
+    def gather_flat_async(self, tensors, tag="f"):
+        """Start an all-gather of this rank's tensor into ONE persistent [G, ...] buffer (no per-call allocations, nothing to
+        reassemble afterwards); the collective runs on RCCL's own stream until ``wait_flat``."""
+        import torch.distributed as dist
+        t = tensors[0]
+        key = (tag, tuple(t.shape), t.device, t.dtype)
+        bufs = getattr(self, "_gf", None)
+        if bufs is None:
+            bufs = self._gf = {}
+        if key not in bufs:
+            bufs[key] = torch.empty((self.G,) + tuple(t.shape), device=t.device, dtype=t.dtype)
+        out = bufs[key]
+        if dist.get_backend(self.group) == "nccl":
+            work = dist.all_gather_into_tensor(out, t, group=self.group, async_op=True)
+        else:
+            work = dist.all_gather(list(out.unbind(0)), t, group=self.group, async_op=True)
+        return work, out, t
+
+    def wait_flat(self, handle):
         handle[0].wait()
         return [handle[1]]
 
@@ -271,25 +310,41 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
     # step of the cost volume) is in flight while the rank encodes the reference view and the context map
     st = {}
     send = []
+    lib = L.load()
+    # cost volume on the epipolar-line-tile kernel (C = 64, D <= 64): every rank splits ITS views' rows to f16 hi|lo (same bytes)
+    # and the all-gather lands them in one persistent [G, vmax, Pb, 128] buffer that the kernel reads through a view -> block map -
+    # no per-view reassembly copies, no fresh 333 MB buffer per forward.  Otherwise (fp32 walk): gather fp32 rows and reorder.
+    lines = C == 64 and all(D <= 64 for D, _, _ in model.stages()) and lib.cer_cost_build_algo(-1) != 1
+    pads = getattr(model, "_slab_pads", None)
+    if pads is None:
+        pads = model._slab_pads = {}
     for g in ex.ranks:
         views = local_views_for(V, G, g)
         _, _, _, f2 = model.encode(images, views, raw=True, parts="src")
-        pad = torch.zeros(vmax, Pb, C, device=dev, dtype=torch.float32)
+        key = (g, vmax, Pb, lines, str(dev))
+        pad = pads.get(key)
+        if pad is None:                                   # persistent; rows of unused view slots stay zero
+            pad = pads[key] = torch.zeros(vmax, Pb, 128 if lines else C, device=dev, dtype=torch.float16 if lines else torch.float32)
         if views:
-            pad[:len(views)] = f2
+            if lines:
+                ops.feat_split(f2, out=pad[:len(views)])
+            else:
+                pad[:len(views)] = f2
         send.append(pad)
-    pending = ex.all_gather_async(send)
+    pending = ex.gather_flat_async(send, tag="f2")
     for g in ex.ranks:
         net_l, inp_l, f1, _ = model.encode(images, [], raw=True, parts="ref")
         st[g] = dict(net=net_l, inp=inp_l, f1=f1)
-    gathered = ex.wait(pending)
+    gathered = ex.wait_flat(pending)
+    # view v (1-based) lives with rank (v-1) % G in that rank's slot (v-1) // G
+    slots = torch.tensor([((v - 1) % G) * vmax + (v - 1) // G for v in range(1, V + 1)], dtype=torch.int32)
     for i, g in enumerate(ex.ranks):
-        f2_all = torch.empty(V, Pb, C, device=dev, dtype=torch.float32)
-        for r in range(G):
-            vr = local_views_for(V, G, r)
-            for j, v in enumerate(vr):
-                f2_all[v - 1] = gathered[i][r][j]
-        st[g]["f2"] = f2_all
+        if lines:
+            st[g]["f2"] = None
+            st[g]["f2s"] = gathered[i]
+            st[g]["slots"] = slots.to(dev)
+        else:
+            st[g]["f2"] = gathered[i].view(G * vmax, Pb, C).index_select(0, slots.to(dev).long())
 
     # ---- slabs
     for g in ex.ranks:
@@ -299,6 +354,7 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
         d["net"] = ub.prepare_net(d["net"][e0 * w:e1 * w].clone(), e1 - e0, w)
         d["inp"] = d["inp"][e0 * w:e1 * w].contiguous()
         d["f1s"] = d["f1"][e0 * w:e1 * w].contiguous()
+        d["split"] = (ops.feat_split(d["f1s"]), d["f2s"], d["slots"]) if lines else None
         d["disp"] = torch.zeros((e1 - e0) * w, device=dev, dtype=torch.float32)
         d["hoist"] = ub.hoist_all(d["inp"], e1 - e0, w, len(model.cascade))
         d["ws"] = ub.workspace(e1 - e0, w, dev)
@@ -310,7 +366,8 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
         for g in ex.ranks:
             d = st[g]
             vol, origin = ops.cost_build(d["f1s"], d["f2"], Pij, d["disp"], D, incre, stage == 0, d["hs"], w, ub.num_levels,
-                                         fold=True, src_hw=(h, w), y0=d["e0"], pyramid_scale=(1.0 / V) if D <= 64 else None)
+                                         fold=True, src_hw=(h, w), y0=d["e0"], pyramid_scale=(1.0 / V) if D <= 64 else None,
+                                         split=d["split"])
             if D > 64:
                 ops.pyramid(vol, D, ub.num_levels, scale=1.0 / V)
             d["vol"], d["origin"] = vol, origin
@@ -346,16 +403,24 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
                 else:
                     d["plan_halo"].replay()
 
-    # ---- gather the owned rows of every rank
+    # ---- gather the owned rows of every rank (persistent send / receive buffers)
     rows_max = (h + G - 1) // G
     send = []
+    owns = getattr(model, "_slab_own", None)
+    if owns is None:
+        owns = model._slab_own = {}
     for g in ex.ranks:
         d = st[g]
-        own = torch.zeros(rows_max * w, device=dev, dtype=torch.float32)
+        key = (g, rows_max * w, str(dev))
+        own = owns.get(key)
+        if own is None:
+            own = owns[key] = torch.zeros(rows_max * w, device=dev, dtype=torch.float32)
         n = (d["r1"] - d["r0"]) * w
         own[:n] = d["disp"][(d["r0"] - d["e0"]) * w:(d["r1"] - d["e0"]) * w]
         send.append(own)
-    gathered = ex.all_gather(send)
+    gathered = ex.wait_flat(ex.gather_flat_async(send, tag="disp"))
+    if h % G == 0:                                        # equal slabs: the gathered buffer IS the disparity map
+        return gathered[0].reshape(1, 1, h, w) * s
     out = torch.empty(h * w, device=dev, dtype=torch.float32)
     for r in range(G):
         r0, r1, _, _ = slab_bounds(h, G, r)

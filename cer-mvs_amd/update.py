@@ -127,7 +127,7 @@ class UpdateBlock(nn.Module):
 
     def packed(self, stage, device):
         """Packed weights for ``stage`` on ``device`` (built once, cached)."""
-        key = (stage, str(device))
+        key = (stage, str(device), self.conv_mode)      # (the dict's contents depend on the arithmetic mode: s16 packs exist only for "s16")
         if key in self._packed:
             return self._packed[key]
         cn, gn, dn = self._names(stage)
@@ -176,6 +176,8 @@ class UpdateBlock(nn.Module):
         p = self.packed(stage, inp_l.device)
         if self.conv_mode == "s16":     # (the results are in the acc32 layout: they seed the accumulators of the loop's convs)
             inp_s = ops.to_frag16(inp_l, h, w, L.S16_RELU)
+            if self.CHECK_OVERFLOW:
+                ops.scan_overflow(inp_s)
             return (ops.conv3x3_s16(p["s_zr_inp"], [inp_s], h, w, L.EPI_LINEAR), ops.conv3x3_s16(p["s_q_inp"], [inp_s], h, w, L.EPI_LINEAR))
         return (ops.conv3x3(p["zr_inp"], [inp_l], h, w, L.EPI_LINEAR, mode=self.conv_mode), ops.conv3x3(p["q_inp"], [inp_l], h, w, L.EPI_LINEAR, mode=self.conv_mode))
 
@@ -191,6 +193,7 @@ class UpdateBlock(nn.Module):
     # with plain 16-byte copies instead of re-splitting them (staging was ~10 % of the conv time, VALU-bound).  The hidden
     # state is therefore carried at 2^-22 relative resolution (the resolution the f16x3 products see anyway).
     SPLIT_ACTS = True
+    CHECK_OVERFLOW = True       # s16 path: scan the ReLU-class activation tensors for saturation once per stage (ops.check_overflow reads the flag)
 
     def split_acts(self):
         return self.SPLIT_ACTS and self.conv_mode == "f16x3"
@@ -262,6 +265,11 @@ class UpdateBlock(nn.Module):
                 plan.replay()
             if after is not None:
                 after(i)
+        if self.conv_mode == "s16" and iters > 0 and self.CHECK_OVERFLOW:
+            # the s16 layouts clamp ReLU-class activations beyond 4094 (65504 / 2^4): saturation must not be silent - scan what the
+            # last iteration left in memory (2 x ~8 us; the delta head's hidden map is checked inside its kernel)
+            ops.scan_overflow(ws["c1"])
+            ops.scan_overflow(ws["c2"])
 
     def workspace(self, h, w, device):
         """Scratch tensors of the loop for an h x w image (s16 path: m-tile-major layouts over whole m-tiles, ops.s16_pixels)."""

@@ -33,6 +33,15 @@ const char* cer_error_string(int code);
 /* Number of visible HIP devices (>=1) or a negative CER_E*; used by loaders to fail loudly. */
 int cer_device_count(void);
 
+/* Saturation is never silent.  The split-f16 kernels clamp an operand whose scaled value leaves the f16 range (update block,
+ * "s16" path: ReLU-class activations beyond 4094 = 65504 / 2^4; cost-volume feature rows beyond 1023).  cer_overflow_flag
+ * registers a caller-owned DEVICE int (one per process; NULL = off, the default) that such kernels or into when they clamp in
+ * registers (bit 2: the hidden map of the fused delta head, which never reaches memory).  Tensors that do reach memory are
+ * checked after the fact: cer_f16_scan_overflow ors `bit` into *flag if any half of a split-f16 buffer (frag16 tensors, split
+ * feature rows; `bytes` % 16 == 0) sits at the f16 maximum or is not finite.  The host reads the flag when convenient. */
+int cer_overflow_flag(int* flag);
+int cer_f16_scan_overflow(const void* data, long bytes, int* flag, int bit, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * alt_cuda_corr.forward  (reference: alt_cuda_corr/correlation.cpp:23-33,
  * correlation_kernel.cu:18-119,260-286).  Literal semantics, any radius:
@@ -113,10 +122,12 @@ int cer_cost_build_algo(int algo);
  *   Apply to fmap1 [P,64] and to the bordered fmap2 [V,(h2+4)*(w2+4),64] (the zero border stays zero).
  * cer_cost_lines_workspace: bytes of `workspace` (per-view partial volumes [V,P,D] + tile parameters).
  * cer_cost_lines_f32: arguments as cer_cost_build_f32 with the split rows in place of fmap1 / fmap2; mode 1 or 2 only.
+ *   view_slot (device int [V], may be NULL = identity): view v's rows are block view_slot[v] of fmap2_split - the multi-GPU
+ *   forward all-gathers every rank's split rows into one [G, ceil(V/G), ...] buffer and builds from it without a reordering copy.
  */
 int cer_feat_split_f16(const float* src, void* dst, long texels, int C, int* overflow_flag, void* stream);
 long cer_cost_lines_workspace(int V, int h1, int w1, int D);
-int cer_cost_lines_f32(const void* fmap1_split, const void* fmap2_split, const float* Pij, const float* disp_in,
+int cer_cost_lines_f32(const void* fmap1_split, const void* fmap2_split, const int* view_slot, const float* Pij, const float* disp_in,
                        float* vol, float* origin_out, void* workspace,
                        int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride,
                        double incre, int shift, int mode, int y0, int fuse_levels, float fuse_scale, void* stream);

@@ -4,6 +4,7 @@ view-sum volume reproduce the single-process view mean.  The per-rank partial vo
 import os
 import socket
 
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -53,8 +54,7 @@ def _worker(rank, world, port, V, ret):
     dist.destroy_process_group()
 
 
-def _run(V):
-    world = 2
+def _run(V, world=2):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), V, ret), nprocs=world, join=True)
@@ -65,6 +65,15 @@ def test_view_shards_sum_to_the_full_volume():
     out = _run(5)
     assert out[0][0] == [1, 3, 5] and out[1][0] == [2, 4]
     for r in (0, 1):
+        assert out[r][1] < 1e-6 and out[r][2]
+
+
+def test_view_shards_over_eight_ranks():
+    """BASELINE configs[3] at G = 8: 10 views -> 2,2,1,1,1,1,1,1; the all-reduced partial sums give the full view mean on every rank."""
+    out = _run(10, world=8)
+    assert [len(out[r][0]) for r in range(8)] == [2, 2, 1, 1, 1, 1, 1, 1]
+    assert sorted(v for r in range(8) for v in out[r][0]) == list(range(1, 11))
+    for r in range(8):
         assert out[r][1] < 1e-6 and out[r][2]
 
 
@@ -155,7 +164,7 @@ def _slab_worker(rank, world, port, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
-    h, w, C = 23, 5, 5                                  # (7 * 5 * 6 floats per strip: not a multiple of 4 - the halves are padded)
+    h, w, C = {2: 23, 4: 37, 8: 61}[world], 5, 5        # (7 * 5 * 6 floats per strip: not a multiple of 4 - the halves are padded)
     full = hashed((h * w, C), 77)
     ex = slab.DistExchange(dist.group.WORLD)
     r0, r1, e0, e1 = slab.slab_bounds(h, world, rank)
@@ -183,6 +192,9 @@ def _slab_worker(rank, world, port, ret):
         strips = ex.all_gather([slab.border_strips(y, w, r0, r1, e0)])[0]
         slab.refresh_halo(y, strips, w, rank, world, r0, r1, e0, e1)
         assert torch.equal(x, y)
+        # the persistent flat gather of the feature / disparity exchange
+        flat = ex.wait_flat(ex.gather_flat_async([buf], tag="t"))[0]
+        assert flat.shape[0] == world and torch.equal(flat[rank], buf) and torch.equal(flat, allbuf)
     own = x[(r0 - e0) * w:(r1 - e0) * w]
     ret[rank] = (float((own - ref[r0 * w:r1 * w]).abs().max()),
                  max(float((x - ref[e0 * w:e1 * w]).abs().max()), float((xd - refd[e0 * w:e1 * w]).abs().max())))
@@ -190,8 +202,9 @@ def _slab_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_row_slabs_with_halo_exchange_reproduce_the_full_image():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_row_slabs_with_halo_exchange_reproduce_the_full_image(world):
+    """world = 4 / 8: middle ranks exchange with BOTH neighbours (2 sends + 2 receives in one batch_isend_irecv)."""
     ret = mp.Manager().dict()
     mp.spawn(_slab_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     for r in range(world):

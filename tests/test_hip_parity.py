@@ -315,6 +315,58 @@ def test_cost_lines_matches_walk(dev, D, stage0, geom):
     assert not ops.check_overflow(dev)
 
 
+def test_encoder_type_lr_matches_reference_capture(dev, golden):
+    """encoder_type="LR" (core/extractor.py:87-90,151: a third residual stage, features at 1/8 resolution, core/raft.py:38) end to
+    end against the reference's own output (tests/golden/e2e_lr.npz) - fast path and literal path."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.synthetic import fill_state_dict
+    g = golden("e2e_lr")
+    cascade = [tuple(int(x) for x in c) for c in g["cascade"]]
+    model = RAFT(cascade=cascade, encoder_type="LR", test_mode=True)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(g["weight_seed"])))
+    model = model.to(dev).eval()
+    images, poses, intr, scale = cached_scene(int(g["H"]), int(g["W"]), int(g["V"]), int(g["scene_seed"]))
+    args = (images.to(dev), poses.to(dev), intr.to(dev))
+    ref = torch.from_numpy(g["disp"])
+    with torch.no_grad():
+        fast = model(*args, scale=scale)
+        lit = model._forward_literal(*args, scale, False)
+    assert fast.shape == ref.shape
+    assert rel_l1(fast.cpu(), ref) < TOL and rel_l1(lit.cpu(), ref) < TOL
+
+
+def test_s16_saturation_raises_the_overflow_flag(dev):
+    """The s16 layouts clamp ReLU-class activations beyond 4094 = 65504 / 2^4 (silent saturation).  An activation of
+    5000 in a frag16 tensor is found by the scan, a hidden activation beyond the limit inside the fused delta head by the kernel's
+    own check, and RAFT.check_overflow turns the flag into an error."""
+    from cer_mvs_amd import RAFT, _lib as L, ops
+    h, w = 16, 32
+    ops.check_overflow(dev)
+    x = torch.relu(hashed((h * w, 64), 901, -1.0, 3000.0)).to(dev)
+    fr = ops.to_frag16(x, h, w, L.S16_RELU)
+    ops.scan_overflow(fr)
+    assert ops.check_overflow(dev) == 0                     # 3000 * 16 = 48000 < 65504: clean
+    x[5, 7] = 5000.0
+    fr = ops.to_frag16(x, h, w, L.S16_RELU)
+    ops.scan_overflow(fr)
+    assert ops.check_overflow(dev) == 4 and ops.check_overflow(dev) == 0
+    assert float(ops.from_frag16(fr, h, w, L.S16_RELU)[5, 7]) < 4095.0          # ... and it WAS clamped
+    # fused delta head: hidden = relu(conv(net)) with weights large enough to push one channel beyond 4094
+    wt = hashed((256, 64, 3, 3), 902, -0.02, 0.02)
+    wt[3] = 12.0
+    pc = ops.PackedConvS16(wt, torch.zeros(256), [(64, 2, L.S16_UNIT)], dev)
+    proj = ops.delta_proj_pack_s16(hashed((1, 256, 3, 3), 903, -0.1, 0.1), dev)
+    net = ops.to_frag16(torch.full((h * w, 64), 0.9, device=dev), h, w, L.S16_UNIT)
+    T = torch.empty(2, 9, h * w, device=dev)
+    ops.conv3x3_s16(pc, [net], h, w, L.EPI_DELTA, out=T, aux=proj)
+    assert ops.check_overflow(dev) & 2
+    model = RAFT(test_mode=True)
+    ops.overflow_flag(dev).fill_(4)
+    with pytest.raises(RuntimeError, match="saturated"):
+        model.to(dev).check_overflow(dev)
+    assert ops.check_overflow(dev) == 0
+
+
 def test_feat_split_roundtrip_and_overflow_flag(dev):
     """cer_feat_split_f16: hi + lo reconstructs x * 64 to 2^-22 relative; a value beyond +-1023 saturates and raises the
     sticky overflow flag (saturation must not be silent)."""

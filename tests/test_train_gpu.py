@@ -128,6 +128,44 @@ def test_training_mode_forward_and_loss(dev, golden):
         assert grad is not None and torch.isfinite(grad).all() and float(grad.abs().sum()) > 0, name
 
 
+def test_training_row_matches_reference_capture(dev, golden):
+    """The training row against the REFERENCE ITSELF (tests/golden/train_tiny.npz = tools/gen_golden.py --only train_tiny: the
+    reference's RAFT(test_mode=False) + loss.sequence_loss under the generator's shims): the whole prediction list
+    (core/raft.py:103,109), the loss and its metrics (loss.py:5-41), and the gradients of seven parameters - through the HIP
+    correlation forward AND the deterministic HIP backward (core/corr.py:19-25)."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.synthetic import fill_state_dict
+    from cer_mvs_amd.train import sequence_loss
+    g = golden("train_tiny")
+    cascade = [tuple(int(x) for x in c) for c in g["cascade"]]
+    model = RAFT(cascade=cascade, test_mode=False)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(g["weight_seed"])))
+    model = model.to(dev).train()
+    images, poses, intr, scale = cached_scene(int(g["H"]), int(g["W"]), int(g["V"]), int(g["scene_seed"]))
+    preds = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale)
+    want = torch.from_numpy(g["predictions"])
+    assert len(preds) == want.shape[0]
+    for i, p_ in enumerate(preds):
+        assert rel_l1(p_.detach().cpu(), want[i]) < 1e-4, i
+    gt = torch.from_numpy(g["gt"]).to(dev)
+    loss, metrics = sequence_loss(list(preds), gt, gradual_weight=float(g["gradual_weight"]))
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    for k, v in zip(("mean_depth_error", "less3", "less10", "less25"), g["metrics"]):
+        assert abs(metrics[k] - float(v)) <= 1e-4 * max(abs(float(v)), 1.0), k
+    loss.backward()
+    params = dict(model.named_parameters())
+    for key in g.files:
+        if not key.startswith("grad_"):
+            continue
+        name = key[5:]
+        grad = params[name].grad.detach().reshape(-1).cpu()
+        ref = torch.from_numpy(g[key])
+        sub = grad if grad.numel() == ref.numel() else grad[::7]
+        assert sub.numel() == ref.numel(), name
+        assert rel_l1(sub, ref) < 1e-3, (name, rel_l1(sub, ref))
+        assert abs(float(grad.double().abs().sum()) - float(g["gradsum_" + name])) <= 1e-3 * float(g["gradsum_" + name]), name
+
+
 def test_sequence_loss_matches_restatement(dev):
     """sequence_loss against a direct numpy evaluation of loss.py:5-41 on small tensors."""
     from cer_mvs_amd.train import sequence_loss

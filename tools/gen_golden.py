@@ -96,7 +96,17 @@ def install_shims():
             out[:, n] = acc_n
         return [out[:, :, None]]
 
+    def backward(fmap1, fmap2, coords, corr_grad, radius):
+        # correlation_kernel.cu:122-256 accumulates d corr / d fmap1 and d corr / d fmap2 and leaves coords_grad at its zero
+        # fill (:307); here: autograd through the gather form above
+        a, b = fmap1.detach().clone().requires_grad_(True), fmap2.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            out, = forward(a, b, coords.detach(), radius)
+            (out * corr_grad).sum().backward()
+        return [a.grad, b.grad, torch.zeros_like(coords)]
+
     acc.forward = forward
+    acc.backward = backward
     sys.modules["alt_cuda_corr"] = acc
 
     torch.Tensor.cuda = lambda self, *a, **k: self
@@ -193,6 +203,61 @@ def gen_e2e(name, H, W, V, cascade, seed):
     print(name, "disp", disp.shape, float(disp.min()), float(disp.mean()), float(disp.max()))
 
 
+TRAIN_GRADS = ("fnet.conv1.weight", "fnet.conv2.weight", "cnet.conv2.weight", "update_block.gru.convz.weight",
+               "update_block.corr_encoder.0.weight", "update_block.delta0.0.weight", "update_block.delta1.2.weight")
+
+
+def gen_train_tiny():
+    """The training row pinned to the reference itself: RAFT(test_mode=False) (core/raft.py:62-64,103,109) -> the list of
+    predictions, loss.sequence_loss (loss.py:5-41) -> loss + metrics, and the gradients of seven parameters (through
+    DirectCorr.backward, core/corr.py:19-25, with the shim's autograd form of the CUDA backward)."""
+    from core.raft import RAFT
+    from loss import sequence_loss
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene, tensor_checksum
+    H, W, V, seed = 64, 96, 3, 2
+    cascade = [(64, 64, 3), (-1, 320, 3)]
+    images, poses, intr, scale = synthetic_scene(H, W, V, seed=seed)
+    model = RAFT(cascade=cascade, test_mode=False)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=seed + 5), strict=True)
+    model.train()
+    preds = model(images.clone(), poses.clone(), intr.clone(), scale=scale.clone().float())
+    import torch.nn.functional as F
+    gt = F.interpolate(preds[-1].detach() * 1.1 + 1e-4, [H, W], mode="bilinear", align_corners=True).clamp_min(1e-4)
+    gt[:, :, :9, :] = 0.0                                          # invalid rows
+    gt[:, :, 20:31, 40:57] = 0.0                                   # an invalid block
+    loss, metrics = sequence_loss(list(preds), gt, gradual_weight=0.3)
+    loss.backward()
+    out = {"H": H, "W": W, "V": V, "cascade": np.array(cascade), "scene_seed": seed, "weight_seed": seed + 5,
+           "images_checksum": np.uint64(tensor_checksum(images)), "gt": gt.numpy(), "gradual_weight": 0.3,
+           "predictions": torch.stack([p_.detach() for p_ in preds]).numpy(), "loss": np.float64(loss.item()),
+           "metrics": np.array([metrics[k] for k in ("mean_depth_error", "less3", "less10", "less25")], dtype=np.float64)}
+    params = dict(model.named_parameters())
+    for name in TRAIN_GRADS:
+        g = params[name].grad.detach().reshape(-1)
+        out["gradsum_" + name] = np.float64(g.double().abs().sum().item())
+        out["grad_" + name] = (g if g.numel() <= 20000 else g[::7]).numpy()       # large tensors: every 7th element + the L1 norm
+    np.savez_compressed(os.path.join(OUT, "train_tiny.npz"), **out)
+    print("train_tiny.npz loss", float(loss), metrics, {k: v.shape for k, v in out.items() if k.startswith("grad_")})
+
+
+def gen_e2e_lr():
+    """encoder_type="LR" (core/extractor.py:87-90,151; core/raft.py:38: features at 1/8 resolution), end to end at a tiny size."""
+    from core.raft import RAFT
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene, tensor_checksum
+    H, W, V, seed = 64, 96, 3, 3
+    cascade = [(64, 64, 2), (-1, 320, 2)]
+    images, poses, intr, scale = synthetic_scene(H, W, V, seed=seed)
+    model = RAFT(cascade=cascade, encoder_type="LR", test_mode=True)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=seed + 5), strict=True)
+    model.eval()
+    with torch.no_grad():
+        disp = model(images.clone(), poses.clone(), intr.clone(), scale=scale.clone())
+    out = {"H": H, "W": W, "V": V, "cascade": np.array(cascade), "scene_seed": seed, "weight_seed": seed + 5,
+           "images_checksum": np.uint64(tensor_checksum(images)), "disp": disp.numpy()}
+    np.savez_compressed(os.path.join(OUT, "e2e_lr.npz"), **out)
+    print("e2e_lr", disp.shape, float(disp.min()), float(disp.mean()), float(disp.max()))
+
+
 def gen_caller():
     from utils.data_utils import crop_operation, scale_operation
     from utils.frame_utils import write_pfm
@@ -232,6 +297,8 @@ def main():
         "e2e_tiny": lambda: gen_e2e("e2e_tiny", 64, 96, 3, [(64, 64, 3), (-1, 320, 3)], seed=2),
         "e2e_cfg1": lambda: gen_e2e("e2e_cfg1", 480, 640, 2, [(64, 64, 2), (-1, 320, 2)], seed=0),
         "caller": gen_caller,
+        "train_tiny": gen_train_tiny,
+        "e2e_lr": gen_e2e_lr,
     }
     # BASELINE.json configs[1] - the bench workload itself (1600x1184, 10 source views, 32 GRU iterations; same scene and weight
     # seeds as bench.py).  Minutes of CPU time, so only on request: --only e2e_cfg2
