@@ -47,20 +47,25 @@ def alt_corr_backward(fmap1, fmap2, coords, corr_grad, radius, deterministic=Non
         L.check(lib.cer_alt_corr_backward_f32(L.dev_ptr(fmap1, "fmap1"), L.dev_ptr(fmap2, "fmap2"), L.dev_ptr(coords, "coords"),
                                               L.dev_ptr(corr_grad, "corr_grad"), L.dev_ptr(g1, "g1"), None, None, B, N, H1, W1, H2, W2, C,
                                               radius, L.cur_stream()), "alt_corr_backward[f1]")
-        n = B * N * H1 * W1 * (2 * radius + 2) ** 2
+        # one batch element (= one source view under DirectCorr) at a time: its tuples (key, coefficient, source pixel: ~32 B each with
+        # the sort's temporaries) are N*H1*W1*(2r+2)^2 - 1/B of the transient memory of sorting all views at once (~1.7 GB per stage
+        # at 10 views x 64 hypotheses x 128x160), and B small sorts instead of one large one; keys are partitioned by b anyway
+        n = N * H1 * W1 * (2 * radius + 2) ** 2
         keys = torch.empty(n, device=dev, dtype=torch.int64)
         coef = torch.empty(n, device=dev, dtype=torch.float32)
         src = torch.empty(n, device=dev, dtype=torch.int32)
-        L.check(lib.cer_alt_corr_bwd_tuples_f32(L.dev_ptr(coords, "coords"), L.dev_ptr(corr_grad, "corr_grad"), L.dev_ptr(keys, "keys", torch.int64),
-                                                L.dev_ptr(coef, "coef"), L.dev_ptr(src, "src", torch.int32), B, N, H1, W1, H2, W2, radius,
-                                                L.cur_stream()), "alt_corr_bwd_tuples")
-        skeys, order = torch.sort(keys, stable=True)
-        T = B * H2 * W2
-        seg = torch.searchsorted(skeys, torch.arange(T + 1, device=dev, dtype=torch.int64)).contiguous()
+        T = H2 * W2
+        bounds = torch.arange(T + 1, device=dev, dtype=torch.int64)
         g2 = torch.empty_like(fmap2)
-        L.check(lib.cer_alt_corr_bwd_reduce_f32(L.dev_ptr(fmap1, "fmap1"), L.dev_ptr(order.contiguous(), "order", torch.int64), L.dev_ptr(coef, "coef"),
-                                                L.dev_ptr(src, "src", torch.int32), L.dev_ptr(seg, "seg", torch.int64), L.dev_ptr(g2, "g2"), T, C,
-                                                L.cur_stream()), "alt_corr_bwd_reduce")
+        for b in range(B):
+            L.check(lib.cer_alt_corr_bwd_tuples_f32(L.dev_ptr(coords[b:b + 1], "coords"), L.dev_ptr(corr_grad[b:b + 1], "corr_grad"),
+                                                    L.dev_ptr(keys, "keys", torch.int64), L.dev_ptr(coef, "coef"), L.dev_ptr(src, "src", torch.int32),
+                                                    1, N, H1, W1, H2, W2, radius, L.cur_stream()), "alt_corr_bwd_tuples")
+            skeys, order = torch.sort(keys, stable=True)
+            seg = torch.searchsorted(skeys, bounds).contiguous()
+            L.check(lib.cer_alt_corr_bwd_reduce_f32(L.dev_ptr(fmap1[b:b + 1], "fmap1"), L.dev_ptr(order.contiguous(), "order", torch.int64),
+                                                    L.dev_ptr(coef, "coef"), L.dev_ptr(src, "src", torch.int32), L.dev_ptr(seg, "seg", torch.int64),
+                                                    L.dev_ptr(g2[b:b + 1], "g2"), T, C, L.cur_stream()), "alt_corr_bwd_reduce")
         return g1, g2, gc
     g1 = torch.empty_like(fmap1)
     g2 = torch.empty_like(fmap2)
@@ -515,7 +520,8 @@ class PackedConvS16:
         wp = ctypes.c_void_p(w.data_ptr())
         self.log2S = lib.cer_conv3x3_s16_scale(wp, Cout, Cin, self.ch, self.kind, self.log2sx, n)
         if self.log2S < -1000:
-            raise RuntimeError("conv3x3_s16: cannot scale these weights / sources")
+            raise RuntimeError("conv3x3_s16: cannot scale these weights / sources (one source's weights are too small next to another's "
+                               "for a shared split-f16 scale); use gru_precision='f16x3'")
 
         def pack(collapsed):
             size = lib.cer_conv3x3_s16_packed_size(Cout, self.ch, self.kind, n, collapsed)

@@ -55,11 +55,28 @@ class RAFT(nn.Module):
         self.overflow_policy = "lazy"
         # packed encoder weights are a cache of the parameters: drop them whenever parameters are (re)loaded - through this
         # module, a wrapper (nn.DataParallel(model).load_state_dict, as the reference's inference.py does) or a submodule
+        # (the hooks hold a weak reference: a deep copy's hooks still point at the ORIGINAL model, which is why the packs are also
+        # validated against the parameters' storage + version counters on every forward, ``_params_sig``)
+        import weakref
+        me = weakref.ref(self)
         for m in (self, self.fnet, self.cnet):
-            m.register_load_state_dict_post_hook(lambda module, incompatible, me=self: me._drop_engines())
+            m.register_load_state_dict_post_hook(lambda module, incompatible, me=me: me() is not None and me()._drop_engines())
+        self._sig = None
 
     def _drop_engines(self):
         self._engines = None
+
+    def _params_sig(self):
+        """Identity + in-place version of every parameter: packed weights are a cache of these (optimizer steps, copy_, deepcopy)."""
+        return tuple((p_.data_ptr(), p_._version) for p_ in self.parameters())
+
+    def _validate_packs(self):
+        sig = self._params_sig()
+        if sig != self._sig:
+            if self._sig is not None:
+                self._engines = None
+                self.update_block.refresh_weights()
+            self._sig = sig
 
     _OVERFLOW_WHAT = {1: "cost-volume feature rows beyond +-1023 (after the reference's /8)", 2: "hidden map of the delta head beyond 4094",
                       4: "a ReLU-class activation of the update block (inp, corr features) beyond 4094"}
@@ -200,6 +217,7 @@ class RAFT(nn.Module):
         return self._forward_fast(images, poses, intrinsics, scale, do_report)
 
     def _forward_fast(self, images, poses, intrinsics, scale, do_report):
+        self._validate_packs()
         dev = images.device
         batch, num, ch, ht, wd = images.shape
         if self.view_group is not None and self.shard == "slab":
@@ -228,6 +246,14 @@ class RAFT(nn.Module):
         # until everything enqueued so far has finished)
         Pij = pij_matrices(poses[0], intrinsics[0], [0] * len(views), views).to(dev) if views else None
         net_l, inp_l, f1, f2 = self.encode(images, views, raw=True)
+        if ub.conv_mode == "s16":
+            try:
+                for st_ in range(len(self.cascade)):
+                    ub.packed(st_, dev)
+            except RuntimeError as e:                     # weights that do not fit a shared split-f16 scale: wide-range kernels instead
+                import warnings
+                warnings.warn(f"cer-mvs_amd: {e}; this model runs with gru_precision='f16x3'")
+                ub.conv_mode = "f16x3"
         net_l = ub.prepare_net(net_l, h, w)
         del images
         # split-f16 operand rows of the cost volume's MFMA products (csrc/cost_lines.hip): the same for every stage

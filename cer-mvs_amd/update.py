@@ -155,7 +155,9 @@ class UpdateBlock(nn.Module):
         p["d1"] = ops.PackedConv3x3(de[0].weight, de[0].bias, [(dn_, 0)], device)
         if self.conv_mode == "s16":
             # s16 fast path (csrc/conv_s16.hip): every loop tensor lives in HBM in the split16 layout with a per-class power-of-two
-            # scale (hidden state and r*h: |x| <= 1; ReLU outputs; generated disparity features)
+            # scale (hidden state and r*h: |x| <= 1; ReLU outputs; generated disparity features).  PackedConvS16 raises when the
+            # weights of one conv do not fit a shared scale (cer_conv3x3_s16_scale): callers of ``packed`` see that error and may
+            # switch ``conv_mode`` to "f16x3" (RAFT does, with a warning).
             U, R, Dp = L.S16_UNIT, L.S16_RELU, L.S16_DISP
             p["s_corr2"] = ops.PackedConvS16(ce[2].weight, ce[2].bias, [(64, 2, R)], device)
             p["s_zr"] = ops.PackedConvS16(wzr[:, rest], None, [(dn_, 2, U), (49, 1, Dp), (64, 2, R)], device)

@@ -271,8 +271,8 @@ int cer_conv3x3_f16x3(const cer_conv_inputs* in, const void* packed_w, const voi
  *   GRU: out = new h frag16 (2^log2s_out), aux = h frag16 (2^log2s_aux; may alias out), aux2 = z f32x8;
  *   DELTA (Cout % 128 == 0): out = tap planes T [Cout/128, 9, h*w] (plain) as for cer_conv3x3_f16x3, aux = projection weights
  *   packed by cer_delta_proj_s16_pack, log2s_aux = their scale.
- * tile_mt: 0 = choose the tile height from (h, w) and the CU count; else force it (tests: 4 | 5 for Cout % 128 == 0,
- * 3 | 4 for Cout = 64). */
+ * tile_mt: 0 = choose the tile height from (h, w) and the CU count; else force it (tests: 2 | 4 for Cout % 128 == 0,
+ * 2 | 3 | 4 for Cout = 64; other values choose automatically). */
 long cer_conv3x3_s16_packed_size(int Cout, const int* ch, const int* kind, int nsrc, int collapsed);
 int cer_conv3x3_s16_scale(const float* w_oihw, int Cout, int Cin, const int* ch, const int* kind, const int* log2sx, int nsrc);
 int cer_conv3x3_s16_pack(const float* w_oihw, void* packed, int Cout, int Cin, const int* ch, const int* kind, const int* log2sx,

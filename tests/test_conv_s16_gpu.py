@@ -73,7 +73,7 @@ def test_s16_layouts_roundtrip(dev, h, w):
     assert torch.equal(back[y0 * w:(y0 + n) * w], ref[y0 * w:(y0 + n) * w]) and back[:y0 * w].abs().sum() == 0
 
 
-@pytest.mark.parametrize("mt", [0, 2, 3, 4, 5])
+@pytest.mark.parametrize("mt", [0, 2, 3, 4])
 @pytest.mark.parametrize("h,w,cout", [(8, 16, 64), (11, 21, 64), (9, 17, 128), (24, 40, 256), (5, 70, 128), (37, 33, 64)])
 def test_conv_s16_matches_torch(dev, tile_mt, h, w, cout, mt):
     from cer_mvs_amd import _lib as L, ops
@@ -111,7 +111,7 @@ def test_conv_s16_two_sources_and_error_bound(dev):
     assert float(((unacc(out, h, w) - ref).abs() / mag).max()) < 1e-6
 
 
-@pytest.mark.parametrize("mt", [2, 4, 5])
+@pytest.mark.parametrize("mt", [2, 4])
 @pytest.mark.parametrize("h,w,cout", [(30, 70, 128), (13, 101, 64), (41, 50, 64)])
 def test_conv_s16_disparity_source(dev, tile_mt, h, w, cout, mt):
     """Kind-1 source: 100 * (unfold7x7(disp) - disp) (core/update.py:80-85,97) generated in the kernel - collapsed 81-tap form
@@ -119,7 +119,7 @@ def test_conv_s16_disparity_source(dev, tile_mt, h, w, cout, mt):
     leaves the image."""
     from cer_mvs_amd import _lib as L, ops
     from oracle import cer_oracle as O
-    ops.TILE_MT = mt if cout == 128 else {2: 2, 4: 3, 5: 4}[mt]
+    ops.TILE_MT = mt if cout == 128 else {2: 2, 4: 3}[mt]
     disp = hashed((1, 1, h, w), 211, 0.0005, 0.0025)
     a = hashed((1, 32, h, w), 212)
     feat = 100 * O.disp_features(disp)
@@ -208,7 +208,7 @@ def test_conv_s16_gates_and_gru_epilogues(dev):
     assert rel_l1(unfrag(new, h, w, U), new_ref) < 1e-6
 
 
-@pytest.mark.parametrize("mt", [2, 4, 5])
+@pytest.mark.parametrize("mt", [2, 4])
 def test_conv_s16_fused_delta_head(dev, tile_mt, mt):
     """EPI_DELTA: hid = relu(conv3x3(net, 64 -> 256)) projected onto the nine taps of the 256 -> 1 conv (core/update.py:68-71);
     cer_delta_sum_f32 then gives delta = 0.01 * conv3x3(hid, w2) (core/update.py:114)."""

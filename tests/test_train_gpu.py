@@ -228,6 +228,27 @@ def test_packed_encoder_weights_follow_parameter_reloads(dev, golden):
     assert not torch.equal(a, b) and torch.equal(a, c)
 
 
+def test_packed_weights_follow_in_place_updates_and_deepcopy(dev, golden):
+    """Packed weights are a cache of the parameters: an in-place update (what an optimizer step does) and a deep copy
+    whose parameters are then changed must both be seen by the next test-mode forward - without refresh_weights()."""
+    import copy
+    model, inputs, scale, g, _ = _tiny_model(dev, golden, test_mode=True)
+    model.eval()
+    with torch.no_grad():
+        a = model(*inputs, scale=scale)
+        twin = copy.deepcopy(model)
+        for p_ in list(twin.fnet.parameters())[:2] + [twin.update_block.gru.convq.weight]:
+            p_.mul_(1.01)
+        b = twin(*inputs, scale=scale)
+        a2 = model(*inputs, scale=scale)
+        model.update_block.delta1[2].bias.add_(1e-4)                 # in place on the original
+        c = model(*inputs, scale=scale)
+        fresh = copy.deepcopy(model)
+        fresh.refresh_weights()
+        c2 = fresh(*inputs, scale=scale)
+    assert torch.equal(a, a2) and not torch.equal(a, b) and not torch.equal(a, c) and torch.equal(c, c2)
+
+
 def test_forward_rejects_sizes_that_are_not_multiples_of_four(dev, golden):
     model, inputs, scale, _, _ = _tiny_model(dev, golden, test_mode=True)
     bad = inputs[0][..., :-2]
