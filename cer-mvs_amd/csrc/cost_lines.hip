@@ -78,9 +78,9 @@ extern "C" int cer_feat_split_f16(const float* src, void* dst, long texels, int 
 // y (axis 1); pixel `a` along the axis of line j sits at b = j + rint(shear * (a - centre)) across it.
 // Reference epipole e_h = adj(A) t with A = Pij[:3,:3], t = Pij[:3,3] (A e ~ t: the pixel whose ray passes through the
 // source camera); the epipolar direction at the grid centre c is e_h.xy - c * e_h.z (finite or not).
-__global__ void cost_lines_setup_kernel(const float* __restrict__ Pij, float* __restrict__ params, int V, int h1, int w1, int y0) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= V) return;
+__global__ void cost_lines_setup_kernel(const float* __restrict__ Pij, float* __restrict__ params, int v0, int nv, int h1, int w1, int y0) {
+    const int v = v0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= v0 + nv) return;
     const float* m = Pij + v * 16;
     const double a00 = m[0], a01 = m[1], a02 = m[2], a10 = m[4], a11 = m[5], a12 = m[6], a20 = m[8], a21 = m[9], a22 = m[10];
     const double t0 = m[3], t1 = m[7], t2 = m[11];
@@ -184,7 +184,7 @@ struct ClArgs {
     const float* disp_in;     // [P]
     float* part;              // [V][P][D]  per-view partial volume, scaled by 2^(2 CL_LOG2S)
     const int* slot;          // [V] or null: view v's rows are block slot[v] of f2s (sharded forward: the gathered layout)
-    int V, h1, w1, h2, w2, D;
+    int V, v0, h1, w1, h2, w2, D;       // V: views in the workspace; this launch builds views v0 .. v0 + gridDim.x / tpv - 1
     float incre, lim;
     int shift, y0, tpv;
 };
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 3) void cost_lines_kernel(const ClArgs A) {
         const unsigned nblk = gridDim.x, bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
         o = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
-    const int v = (int)(o / (unsigned)A.tpv), rem = (int)(o % (unsigned)A.tpv);
+    const int v = A.v0 + (int)(o / (unsigned)A.tpv), rem = (int)(o % (unsigned)A.tpv);
     const int h1 = A.h1, w1 = A.w1, h2 = A.h2, w2 = A.w2, D = A.D;
     const int axis = (int)A.params[v * 4 + 0];
     const float shear = A.params[v * 4 + 1];
@@ -545,26 +545,30 @@ extern "C" long cer_cost_lines_workspace(int V, int h1, int w1, int D) {
     return (long)V * h1 * w1 * D * 4 + (long)V * 16 + 256;
 }
 
-extern "C" int cer_cost_lines_f32(const void* fmap1_split, const void* fmap2_split, const int* view_slot, const float* Pij, const float* disp_in,
-                                  float* vol, float* origin_out, void* workspace, int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride,
-                                  double incre_d, int shift, int mode, int y0, int fuse_levels, float fuse_scale, void* stream) {
-    if (!fmap1_split || !fmap2_split || !Pij || !disp_in || !vol || !workspace) return CER_EINVAL;
-    if (V <= 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || D <= 0 || row_stride < D || (mode != 1 && mode != 2)) return CER_EINVAL;
+static int cl_check(int V, int h1, int w1, int h2, int w2, int C, int D) {
+    if (V <= 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || D <= 0) return CER_EINVAL;
     if (C != 64 || D > 64 || V > 4096) return CER_ESHAPE;
-    if (fuse_levels > 1) {
-        if (mode != 1) return CER_EINVAL;
-        int need = 0, n = D;
-        for (int l = 0; l < fuse_levels; ++l) { need += n; n /= 2; }
-        if (row_stride < need || fuse_levels > 6) return CER_ESHAPE;
-    }
-    if ((long)(h2 + 4) * (w2 + 4) >= (1L << 24) || (long)h1 * w1 >= (1L << 24)) return CER_ESHAPE;
+    if ((long)(h2 + 4) * (w2 + 4) >= (1L << 24) || (long)h1 * w1 >= (1L << 24) || h2 > 16000 || w2 > 16000) return CER_ESHAPE;
+    return CER_OK;
+}
+static float* cl_params(void* workspace, int V, long P, int D) {
+    float* params = (float*)workspace + (long)V * P * D;
+    return (float*)(((uintptr_t)params + 63) & ~(uintptr_t)63);
+}
+
+// views v0 .. v0 + nv - 1 of a V-view workspace: tile parameters + per-view partial volumes (no reduction)
+extern "C" int cer_cost_lines_views_f32(const void* fmap1_split, const void* fmap2_split, const int* view_slot, const float* Pij,
+                                        const float* disp_in, void* workspace, int V, int v0, int nv, int h1, int w1, int h2, int w2, int C, int D,
+                                        double incre_d, int shift, int y0, void* stream) {
+    if (!fmap1_split || !fmap2_split || !Pij || !disp_in || !workspace) return CER_EINVAL;
+    const int rc = cl_check(V, h1, w1, h2, w2, C, D);
+    if (rc != CER_OK) return rc;
+    if (v0 < 0 || nv <= 0 || v0 + nv > V) return CER_EINVAL;
     if (!cer_aligned16(fmap1_split) || !cer_aligned16(fmap2_split) || !cer_aligned16(workspace)) return CER_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     const long P = (long)h1 * w1;
-    float* part = (float*)workspace;
-    float* params = part + (long)V * P * D;
-    params = (float*)(((uintptr_t)params + 63) & ~(uintptr_t)63);
-    hipLaunchKernelGGL(cost_lines_setup_kernel, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, st, Pij, params, V, h1, w1, y0);
+    float* params = cl_params(workspace, V, P, D);
+    hipLaunchKernelGGL(cost_lines_setup_kernel, dim3((unsigned)((nv + 63) / 64)), dim3(64), 0, st, Pij, params, v0, nv, h1, w1, y0);
     CER_RETURN_IF_LAUNCH_FAILED();
     ClArgs a;
     a.f1s = (const _Float16*)fmap1_split;
@@ -572,22 +576,48 @@ extern "C" int cer_cost_lines_f32(const void* fmap1_split, const void* fmap2_spl
     a.Pij = Pij;
     a.params = params;
     a.disp_in = disp_in;
-    a.part = part;
+    a.part = (float*)workspace;
     a.slot = view_slot;
-    a.V = V; a.h1 = h1; a.w1 = w1; a.h2 = h2; a.w2 = w2; a.D = D;
+    a.V = V; a.v0 = v0; a.h1 = h1; a.w1 = w1; a.h2 = h2; a.w2 = w2; a.D = D;
     a.incre = (float)incre_d;
     a.lim = (float)((D / 2) * incre_d);
     a.shift = shift;
     a.y0 = y0;
     const long tx = (long)((w1 + 31) / 32) * (h1 + 32), ty = (long)((h1 + 31) / 32) * (w1 + 32);
     a.tpv = (int)(tx > ty ? tx : ty);
-    const long nblk = (long)V * a.tpv;
+    const long nblk = (long)nv * a.tpv;
     if (nblk >= (1L << 31)) return CER_ESHAPE;
     hipLaunchKernelGGL(cost_lines_kernel, dim3((unsigned)nblk), dim3(256), 0, st, a);
     CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}
+
+// sum of the V partial volumes of a workspace (view order) -> vol rows (+ origin, pooled levels): the second half of cer_cost_lines_f32
+extern "C" int cer_cost_lines_reduce_f32(const void* workspace, const float* disp_in, float* vol, float* origin_out, int V, int h1, int w1, int D,
+                                         int row_stride, double incre_d, int shift, int mode, int fuse_levels, float fuse_scale, void* stream) {
+    if (!workspace || !disp_in || !vol) return CER_EINVAL;
+    if (V <= 0 || h1 <= 0 || w1 <= 0 || D <= 0 || D > 64 || row_stride < D || (mode != 1 && mode != 2)) return CER_EINVAL;
+    if (fuse_levels > 1) {
+        if (mode != 1) return CER_EINVAL;
+        int need = 0, n = D;
+        for (int l = 0; l < fuse_levels; ++l) { need += n; n /= 2; }
+        if (row_stride < need || fuse_levels > 6) return CER_ESHAPE;
+    }
+    const long P = (long)h1 * w1;
     const float scale = (fuse_levels > 1 ? fuse_scale : 1.0f) / (float)(1 << (2 * CL_LOG2S));
-    hipLaunchKernelGGL(cost_lines_reduce_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, part, disp_in, vol, origin_out, V, P, D,
-                       row_stride, fuse_levels, scale, mode == 2 ? 1 : 0, a.lim, shift);
+    hipLaunchKernelGGL(cost_lines_reduce_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, disp_in, vol,
+                       origin_out, V, P, D, row_stride, fuse_levels, scale, mode == 2 ? 1 : 0, (float)((D / 2) * incre_d), shift);
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
+}
+
+extern "C" int cer_cost_lines_f32(const void* fmap1_split, const void* fmap2_split, const int* view_slot, const float* Pij, const float* disp_in,
+                                  float* vol, float* origin_out, void* workspace, int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride,
+                                  double incre_d, int shift, int mode, int y0, int fuse_levels, float fuse_scale, void* stream) {
+    if (!vol || row_stride < D || (mode != 1 && mode != 2)) return CER_EINVAL;
+    int rc = cer_cost_lines_views_f32(fmap1_split, fmap2_split, view_slot, Pij, disp_in, workspace, V, 0, V, h1, w1, h2, w2, C, D, incre_d, shift, y0,
+                                      stream);
+    if (rc != CER_OK) return rc;
+    return cer_cost_lines_reduce_f32(workspace, disp_in, vol, origin_out, V, h1, w1, D, row_stride, incre_d, shift, mode, fuse_levels, fuse_scale,
+                                     stream);
 }

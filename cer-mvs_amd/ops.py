@@ -233,6 +233,41 @@ def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, 
     return vol, origin
 
 
+def cost_lines_views(f1s, f2s, slots, Pij, disp_in, V, v0, nv, h1, w1, D, incre, shift, src_hw=None, y0=0):
+    """First half of the epipolar-line-tile cost volume for views v0 .. v0 + nv - 1 of V: their partial volumes go to the device's
+    lines workspace (cer_cost_lines_views_f32).  ``cost_lines_reduce`` finishes the volume once every view has been built."""
+    h2, w2 = src_hw if src_hw is not None else (h1, w1)
+    ws = _lines_workspace(V, h1, w1, D, f1s.device)
+    L.check(L.load().cer_cost_lines_views_f32(L.dev_ptr(f1s, "fmap1_split", torch.float16), L.dev_ptr(f2s, "fmap2_split", torch.float16),
+                                              L.dev_ptr(slots, "view_slot", torch.int32), L.dev_ptr(Pij, "Pij"), L.dev_ptr(disp_in, "disp_in"),
+                                              L.dev_ptr(ws, "workspace", torch.uint8), V, int(v0), int(nv), h1, w1, h2, w2, 64, D, float(incre),
+                                              int(bool(shift)), int(y0), L.cur_stream()), "cost_lines_views")
+
+
+def cost_lines_reduce(disp_in, V, h1, w1, D, incre, shift, num_levels, pyramid_scale=None, vol=None, accumulate=False):
+    """Second half: sum of the V partial volumes -> (vol [P, rs], origin [P]) with the fused view-mean scale + pooled levels when
+    ``pyramid_scale`` is given (as ``cost_build``)."""
+    P = h1 * w1
+    _, _, rs = row_layout(D, num_levels)
+    fuse = pyramid_scale is not None and num_levels > 1 and not accumulate
+    dev = disp_in.device
+    if vol is None:
+        vol = torch.empty(P, rs, device=dev, dtype=torch.float32) if fuse else torch.zeros(P, rs, device=dev, dtype=torch.float32)
+        if fuse:
+            offs, lens, _ = row_layout(D, num_levels)
+            if offs[-1] + lens[-1] < rs:
+                vol[..., offs[-1] + lens[-1]:] = 0
+    origin = torch.empty(P, device=dev, dtype=torch.float32)
+    ws = _lines_workspace(V, h1, w1, D, dev)
+    L.check(L.load().cer_cost_lines_reduce_f32(L.dev_ptr(ws, "workspace", torch.uint8), L.dev_ptr(disp_in, "disp_in"), L.dev_ptr(vol, "vol"),
+                                               L.dev_ptr(origin, "origin"), V, h1, w1, D, rs, float(incre), int(bool(shift)),
+                                               2 if accumulate else 1, num_levels if fuse else 0, float(pyramid_scale) if fuse else 1.0,
+                                               L.cur_stream()), "cost_lines_reduce")
+    if pyramid_scale is not None and not fuse:
+        pyramid(vol, D, num_levels, scale=float(pyramid_scale))
+    return vol, origin
+
+
 def pyramid(vol, D, num_levels, scale=1.0):
     rs = vol.shape[-1]
     rows = vol.numel() // rs

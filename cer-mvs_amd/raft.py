@@ -28,6 +28,9 @@ from .projective import pij_matrices
 from .update import UpdateBlock
 
 
+_SIDE_STREAMS = {}
+
+
 class RAFT(nn.Module):
     def __init__(self, cascade=[(64, 64, 8), (-1, 320, 8)], encoder_type="HR", dim_fmap=64, dim_net=64, dim_inp=64,
                  test_mode=False, precision="fp32", view_group=None, gru_precision="s16", encoder_backend="hip", shard="slab"):
@@ -180,6 +183,58 @@ class RAFT(nn.Module):
         f2 = fmaps_to_nhwc(fm[1:], border=2) if views else None
         return ops.nchw_to_nhwc(net.contiguous()), ops.nchw_to_nhwc(inp.contiguous()), fmaps_to_nhwc(fm[:1])[0], f2
 
+    # ---------------------------------------------------------------- encoders with the first stage's cost volume underneath
+    PIPELINE_BUILD = True       # single-GPU fast path: build stage 0's per-view partial volumes on a second stream while later views are encoded
+
+    @staticmethod
+    def _batches(V):
+        nb = 2 if V >= 2 else 1           # (measured at 10 views: two batches 20.9 ms, three 20.95, no pipeline 21.1 - the two kernels share CUs badly)
+        base, rem = divmod(V, nb)
+        return [base + (1 if i < rem else 0) for i in range(nb)]
+
+    def _encode_pipelined(self, images, V, Pij, disp, D, incre, h, w):
+        """encode() for all V source views in batches; as soon as a batch's feature rows exist, a second HIP stream splits them to
+        f16 hi|lo and builds that batch's partial cost volumes (cer_cost_lines_views_f32) - a kernel bound by vector issue and LDS
+        latency that leaves the matrix pipe and most issue slots idle - while the main stream encodes the next batch (MFMA / HBM
+        bound).  Returns (net, inp, f1, f2, (f1s, f2s), event of the last build); the caller finishes the volume with ops.cost_lines_reduce."""
+        from .encoder_hip import HipEncoder
+        dev = images.device
+        if self._engines is None or self._engines[0] != dev:
+            self._engines = (dev, HipEncoder(self.fnet, dev), HipEncoder(self.cnet, dev))
+        _, eng_f, eng_c = self._engines
+        main = torch.cuda.current_stream()
+        side = _SIDE_STREAMS.get(str(dev))          # (module-level: streams / events must not end up in a deep copy of the model)
+        if side is None:
+            side = _SIDE_STREAMS[str(dev)] = torch.cuda.Stream(device=dev)
+        net, inp, _, _ = eng_c.context(images[0, :1], raw=True)
+        Pb = (h + 4) * (w + 4)
+        key = (V, h, w, str(dev))
+        buf = self._src_buf.get(key)
+        if buf is None:                        # border texels are written once (zeros) and never touched again
+            buf = torch.zeros(V, Pb, self.dim_fmap, device=dev, dtype=torch.float32)
+            self._src_buf = {key: buf}
+        f1s = torch.empty(h * w, 128, device=dev, dtype=torch.float16)
+        f2s = torch.empty(V, Pb, 128, device=dev, dtype=torch.float16)
+        f1, v0 = None, 0
+        for bi, nvb in enumerate(self._batches(V)):
+            if bi == 0:
+                ref, _, _, _ = eng_f.features(images[0, 0:1 + nvb], n_ref=1, border=2, scale=0.125, src_out=buf[0:nvb], raw=True)
+                f1 = ref[0]
+            else:
+                eng_f.features(images[0, 1 + v0:1 + v0 + nvb], n_ref=0, border=2, scale=0.125, src_out=buf[v0:v0 + nvb], raw=True)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                if bi == 0:
+                    ops.feat_split(f1, out=f1s)
+                ops.feat_split(buf[v0:v0 + nvb], out=f2s[v0:v0 + nvb])
+                ops.cost_lines_views(f1s, f2s, None, Pij, disp, V, v0, nvb, h, w, D, incre, True)
+            v0 += nvb
+        done = torch.cuda.Event()
+        done.record(side)                      # (the caller waits for it right before the view reduction: the hoisted convs run meanwhile)
+        return net, inp, f1, buf, (f1s, f2s), done
+
     # ---------------------------------------------------------------- forward
     def forward(self, images, poses, intrinsics, scale=None, do_report=False):
         if not images.is_cuda:
@@ -245,7 +300,16 @@ class RAFT(nn.Module):
         # (uploaded BEFORE the encoders are enqueued: a pageable H2D copy is stream-ordered and would block the host
         # until everything enqueued so far has finished)
         Pij = pij_matrices(poses[0], intrinsics[0], [0] * len(views), views).to(dev) if views else None
-        net_l, inp_l, f1, f2 = self.encode(images, views, raw=True)
+        disp = torch.zeros(P, device=dev, dtype=torch.float32)
+        (D0, incre0, _) = self.stages()[0]
+        from . import _lib as L
+        pipelined = (self.PIPELINE_BUILD and self.view_group is None and V >= 2 and self.encoder_backend == "hip" and self.precision == "fp32"
+                     and self.encoder_type == "HR" and self.dim_fmap == 64 and D0 <= 64 and L.load().cer_cost_build_algo(-1) != 1)
+        split = None
+        if pipelined:
+            net_l, inp_l, f1, f2, split, build_done = self._encode_pipelined(images, V, Pij, disp, D0, incre0, h, w)
+        else:
+            net_l, inp_l, f1, f2 = self.encode(images, views, raw=True)
         if ub.conv_mode == "s16":
             try:
                 for st_ in range(len(self.cascade)):
@@ -257,15 +321,18 @@ class RAFT(nn.Module):
         net_l = ub.prepare_net(net_l, h, w)
         del images
         # split-f16 operand rows of the cost volume's MFMA products (csrc/cost_lines.hip): the same for every stage
-        split = (ops.feat_split(f1), ops.feat_split(f2)) if (views and self.dim_fmap == 64) else None
+        if split is None:
+            split = (ops.feat_split(f1), ops.feat_split(f2)) if (views and self.dim_fmap == 64) else None
 
-        disp = torch.zeros(P, device=dev, dtype=torch.float32)
         hoisted_all = ub.hoist_all(inp_l, h, w, len(self.cascade))
         ws = ub.workspace(h, w, dev)
         for stage, (D, incre, T) in enumerate(self.stages()):
             hoisted = hoisted_all[stage]
             single = self.view_group is None   # no cross-rank sum between the build and the pooling: fuse them
-            if views:
+            if pipelined and stage == 0:          # the partial volumes were built under the encoders: only the view reduction is left
+                torch.cuda.current_stream().wait_event(build_done)
+                vol, origin = ops.cost_lines_reduce(disp, V, h, w, D, incre, True, ub.num_levels, pyramid_scale=1.0 / V)
+            elif views:
                 vol, origin = ops.cost_build(f1, f2, Pij, disp, D, incre, stage == 0, h, w, ub.num_levels, fold=True,
                                              pyramid_scale=(1.0 / V) if (single and D <= 64) else None, split=split)
             else:                      # more ranks than views: contribute zeros

@@ -131,6 +131,15 @@ int cer_cost_lines_f32(const void* fmap1_split, const void* fmap2_split, const i
                        float* vol, float* origin_out, void* workspace,
                        int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride,
                        double incre, int shift, int mode, int y0, int fuse_levels, float fuse_scale, void* stream);
+/* The two halves of cer_cost_lines_f32, for callers that build views as their features become available (RAFT.forward encodes the
+ * source views in batches and builds each batch's partial volumes on a second stream while the next batch is being encoded):
+ * _views_ writes the partial volumes of views v0 .. v0 + nv - 1 into the V-view workspace (Pij, view_slot, fmap2_split indexed by
+ * the absolute view number); _reduce_ sums all V partials in view order into vol (origin, scale, pooled levels as above). */
+int cer_cost_lines_views_f32(const void* fmap1_split, const void* fmap2_split, const int* view_slot, const float* Pij, const float* disp_in,
+                             void* workspace, int V, int v0, int nv, int h1, int w1, int h2, int w2, int C, int D,
+                             double incre, int shift, int y0, void* stream);
+int cer_cost_lines_reduce_f32(const void* workspace, const float* disp_in, float* vol, float* origin_out, int V, int h1, int w1, int D,
+                              int row_stride, double incre, int shift, int mode, int fuse_levels, float fuse_scale, void* stream);
 
 /* Correlation pyramid (reference: core/corr.py:94-97, F.avg_pool2d([1,2]) x (L-1)), in place on
  * rows laid out [level0 (D) | level1 (D/2) | level2 (D/4) | ... | pad]: first level0 *= scale
