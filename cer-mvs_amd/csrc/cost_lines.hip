@@ -189,13 +189,18 @@ struct ClArgs {
     int shift, y0, tpv;
 };
 
-__global__ __launch_bounds__(256, 3) void cost_lines_kernel(const ClArgs A) {
+// OCC = waves per SIMD the register allocation aims at: 3 (LDS: 16 KiB of dots + D x 33 descriptors <= 50 KiB per block; 134 VGPRs).
+// D <= 44 would fit 4 blocks per CU, but at 128 VGPRs the kernel spills and was measured slower (1.14 vs 1.04 ms)
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
     __shared__ __attribute__((aligned(16))) float prod[CL_T * 32];      // dots[texel of the chunk][pixel of the tile]
     // per (hypothesis, pixel): {packed cell, fraction along the band, fraction across it, value}
     //   packed: bits 0-15 band column of the cell + 4; bits 30-31 kind: 0 = samples through the band (bits 16-20 / 21-25: band row
     //   of the cell in its own / the next column), 1 = zero (outside the map / non-finite), 2 = direct path (bits 16-29: cell row + 4)
-    __shared__ __attribute__((aligned(16))) float desc[64 * CL_DP * 4];
+    extern __shared__ __attribute__((aligned(16))) float desc[];          // [D][CL_DP][4]
     __shared__ int pidx[32];                                             // pixel index of tile slot i, or -1
+    __shared__ int bandI[8];
+    __shared__ float bandF[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kg = lane >> 5;
@@ -263,8 +268,12 @@ __global__ __launch_bounds__(256, 3) void cost_lines_kernel(const ClArgs A) {
         return ok;
     };
 
-    // ---- band analysis (every wave computes the same wave-uniform values).  End points of every pixel's segment: lanes with
-    // kg = 0 project hypothesis 0, lanes with kg = 1 hypothesis D - 1, and the halves swap
+    // ---- band analysis, by wave 0 (the other waves wait for its nine numbers: ~600 instructions they do not have to issue).
+    // End points of every pixel's segment: lanes with kg = 0 project hypothesis 0, lanes with kg = 1 hypothesis D - 1, and the
+    // halves swap
+    int smaj = 0, nchunks = 0, R = 1, Wc = 1, cmin = 0, cmax = 0, dir = 1;
+    float bm = 0.f, bl0 = 0.f;                               // base row of band column c: floor(bl0 + bm * c)
+    if (wave == 0) {
     float ua, wa, ub, wb;
     bool part0;
     {
@@ -277,19 +286,14 @@ __global__ __launch_bounds__(256, 3) void cost_lines_kernel(const ClArgs A) {
         part0 = valid && oke && oko;
     }
     const unsigned long long pm0 = __ballot(part0);
-    int smaj = 0;                                            // 0: band runs along u (x of the source map), 1: along w
-    if (pm0) {
+    if (pm0) {                                               // smaj 0: band runs along u (x of the source map), 1: along w
         const float INF = 3e38f;
         const float mnu = cl_wmin(part0 ? fminf(ua, ub) : INF), mxu = cl_wmax(part0 ? fmaxf(ua, ub) : -INF);
         const float mnw = cl_wmin(part0 ? fminf(wa, wb) : INF), mxw = cl_wmax(part0 ? fmaxf(wa, wb) : -INF);
         smaj = (mxw - mnw) > (mxu - mnu) ? 1 : 0;
     }
     smaj = __builtin_amdgcn_readfirstlane(smaj);
-    const int Wmaj = smaj ? h2 : w2, Wmin = smaj ? w2 : h2;
-    const int wp = w2 + 4;
-    const int smajS = smaj ? wp : 1, sminS = smaj ? 1 : wp;      // texel strides of the padded source map along / across the band
-    int nchunks = 0, R = 1, Wc = 1, cmin = 0, cmax = 0, dir = 1;
-    float bm = 0.f, bl0 = 0.f;                               // base row of band column c: floor(bl0 + bm * c)
+    const int Wmaj = smaj ? h2 : w2;
     if (pm0) {
         const float ma = smaj ? wa : ua, na = smaj ? ua : wa, mb = smaj ? wb : ub, nb = smaj ? ub : wb;
         // clip the segment to the columns of the (padded) map: what lies beyond samples zeros and needs no band
@@ -336,6 +340,18 @@ __global__ __launch_bounds__(256, 3) void cost_lines_kernel(const ClArgs A) {
             }
         }
     }
+    if (lane == 0) {
+        bandI[0] = smaj; bandI[1] = nchunks; bandI[2] = R; bandI[3] = Wc; bandI[4] = cmin; bandI[5] = cmax; bandI[6] = dir;
+        bandF[0] = bm; bandF[1] = bl0;
+    }
+    }
+    __syncthreads();
+    smaj = bandI[0]; nchunks = bandI[1]; R = bandI[2]; Wc = bandI[3]; cmin = bandI[4]; cmax = bandI[5]; dir = bandI[6];
+    bm = bandF[0]; bl0 = bandF[1];
+    smaj = __builtin_amdgcn_readfirstlane(smaj);
+    const int Wmaj = smaj ? h2 : w2, Wmin = smaj ? w2 : h2;
+    const int wp = w2 + 4;
+    const int smajS = smaj ? wp : 1, sminS = smaj ? 1 : wp;      // texel strides of the padded source map along / across the band
     nchunks = __builtin_amdgcn_readfirstlane(nchunks);
     R = __builtin_amdgcn_readfirstlane(R);
     Wc = __builtin_amdgcn_readfirstlane(Wc);
@@ -587,7 +603,8 @@ extern "C" int cer_cost_lines_views_f32(const void* fmap1_split, const void* fma
     a.tpv = (int)(tx > ty ? tx : ty);
     const long nblk = (long)nv * a.tpv;
     if (nblk >= (1L << 31)) return CER_ESHAPE;
-    hipLaunchKernelGGL(cost_lines_kernel, dim3((unsigned)nblk), dim3(256), 0, st, a);
+    const size_t dyn = (size_t)D * CL_DP * 16;
+    hipLaunchKernelGGL(cost_lines_kernel<3>, dim3((unsigned)nblk), dim3(256), dyn, st, a);      // (<4>: 128 VGPRs with 6 spilled - measured slower at D = 44)
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }

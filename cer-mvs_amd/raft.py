@@ -184,7 +184,8 @@ class RAFT(nn.Module):
         return ops.nchw_to_nhwc(net.contiguous()), ops.nchw_to_nhwc(inp.contiguous()), fmaps_to_nhwc(fm[:1])[0], f2
 
     # ---------------------------------------------------------------- encoders with the first stage's cost volume underneath
-    PIPELINE_BUILD = True       # single-GPU fast path: build stage 0's per-view partial volumes on a second stream while later views are encoded
+    import os as _os
+    PIPELINE_BUILD = _os.environ.get("CER_PIPELINE", "1") != "0"       # single-GPU fast path: build stage 0's per-view partial volumes on a second stream while later views are encoded
 
     @staticmethod
     def _batches(V):

@@ -277,8 +277,16 @@ class UpdateBlock(nn.Module):
         """Scratch tensors of the loop for an h x w image (s16 path: m-tile-major layouts over whole m-tiles, ops.s16_pixels)."""
         P = h * w
         if self.conv_mode == "s16":
-            z = lambda c: torch.zeros(ops.s16_pixels(h, w), c, device=device, dtype=torch.float32)
-            return {"c1": z(64), "c2": z(64), "z": z(64), "rn": z(64), "T": torch.empty(2, 9, P, device=device, dtype=torch.float32)}
+            # persistent per (size, device): the padding pixels of the m-tile-major layouts are zero-filled once and never written
+            # (4 x 30 MB of memsets per forward otherwise); every data pixel is overwritten by the first iteration of a forward
+            key = (h, w, str(device))
+            cache = self.__dict__.setdefault("_ws_cache", {})
+            if key not in cache:
+                while len(cache) >= 8:            # (row slabs of different heights share a process in the simulated-rank tests)
+                    cache.pop(next(iter(cache)))
+                z = lambda c: torch.zeros(ops.s16_pixels(h, w), c, device=device, dtype=torch.float32)
+                cache[key] = {"c1": z(64), "c2": z(64), "z": z(64), "rn": z(64), "T": torch.empty(2, 9, P, device=device, dtype=torch.float32)}
+            return cache[key]
         e = lambda c: torch.empty(P, c, device=device, dtype=torch.float32)
         return {"c1": e(64), "c2": e(64), "z": e(64), "rn": e(64), "hid": e(256),
                 "T": torch.empty(2, 9, P, device=device, dtype=torch.float32)}
