@@ -40,11 +40,19 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define CL_ABL 0                            // ablation builds for timing attribution (variants/libcermvs_clabl<N>.so): wrong results
 #endif
 
-// ---- fp32 rows -> split-f16 rows: per texel 64 hi halves | 64 lo halves of x * 2^CL_LOG2S (hi = f16(xs), lo = f16(xs - hi))
-__global__ __launch_bounds__(256) void feat_split_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long n8, int* __restrict__ flag) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;    // one thread per 8 channels
-    if (i >= n8) return;
-    const float4 a = cer_ld4(src + i * 8), b = cer_ld4(src + i * 8 + 4);
+// ---- fp32 rows -> split-f16 operand planes.  Per block of `bt` texels (one source view, or the reference map):
+//   8 planes p = hl * 4 + ks (hl: 0 = hi, 1 = lo half of x * 2^CL_LOG2S; ks: 16-channel group), each [bt][16 halves]:
+//   halves of (block b, texel t, plane p, channel 16 ks + c) at  ((b * 8 + p) * bt + t) * 16 + c.
+// One MFMA fragment load (fixed plane) of a wave then reads 32 B per texel, and x-neighbouring texels are contiguous: a band chunk
+// of 8 columns x 4 rows touches 8 cache lines per load instruction instead of 32 with texel-major 256-B rows - the L1's line
+// rate, not its byte rate, bounded the kernel (1.65 -> see DESIGN.md).
+__global__ __launch_bounds__(256) void feat_split_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long bt, long n2, int* __restrict__ flag) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;    // (texel of the whole tensor, kg); blockIdx.y = ks
+    if (i >= n2) return;
+    const int ks = blockIdx.y, kg = (int)(i & 1);
+    const long texel = i >> 1, blk = texel / bt, t = texel - blk * bt;
+    const float* sp = src + texel * 64 + ks * 16 + kg * 8;
+    const float4 a = cer_ld4(sp), b = cer_ld4(sp + 4);
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     cer_h2 h[4], l[4];
     bool sat = false;
@@ -56,20 +64,19 @@ __global__ __launch_bounds__(256) void feat_split_kernel(const float* __restrict
         h[j] = __builtin_convertvector(x, cer_h2);
         l[j] = __builtin_convertvector(x - __builtin_convertvector(h[j], cer_f2), cer_h2);
     }
-    const long texel = i >> 3;
-    const int c8 = (int)(i & 7);
-    *reinterpret_cast<half8*>(dst + texel * 128 + c8 * 8) = (half8){h[0].x, h[0].y, h[1].x, h[1].y, h[2].x, h[2].y, h[3].x, h[3].y};
-    *reinterpret_cast<half8*>(dst + texel * 128 + 64 + c8 * 8) = (half8){l[0].x, l[0].y, l[1].x, l[1].y, l[2].x, l[2].y, l[3].x, l[3].y};
+    _Float16* dp = dst + ((blk * 8 + ks) * bt + t) * 16 + kg * 8;
+    *reinterpret_cast<half8*>(dp) = (half8){h[0].x, h[0].y, h[1].x, h[1].y, h[2].x, h[2].y, h[3].x, h[3].y};
+    *reinterpret_cast<half8*>(dp + 4 * bt * 16) = (half8){l[0].x, l[0].y, l[1].x, l[1].y, l[2].x, l[2].y, l[3].x, l[3].y};
     if (sat && flag) atomicOr(flag, 1);                     // sticky: a feature beyond +-1023 was clamped (or is not finite)
 }
 
-extern "C" int cer_feat_split_f16(const float* src, void* dst, long texels, int C, int* overflow_flag, void* stream) {
-    if (!src || !dst || texels <= 0) return CER_EINVAL;
+extern "C" int cer_feat_split_f16(const float* src, void* dst, long blocks, long block_texels, int C, int* overflow_flag, void* stream) {
+    if (!src || !dst || blocks <= 0 || block_texels <= 0) return CER_EINVAL;
     if (C != 64) return CER_ESHAPE;
     if (!cer_aligned16(src) || !cer_aligned16(dst)) return CER_EALIGN;
-    const long n8 = texels * 8;
-    hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst, n8,
-                       overflow_flag);
+    const long n2 = blocks * block_texels * 2;
+    hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((n2 + 255) / 256), 4), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst,
+                       block_texels, n2, overflow_flag);
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }
@@ -128,16 +135,18 @@ __device__ __forceinline__ float cl_wmax(float x) {
     return fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
 }
 
-// direct path: the four texel dots of one sample from the split rows in global memory (scaled by 2^(2 CL_LOG2S), like the MFMA path)
-__device__ __noinline__ float cl_direct(const _Float16* __restrict__ f1row, const _Float16* __restrict__ tex00, int smajS, int sminS,
+// direct path: the four texel dots of one sample from the split planes in global memory (scaled by 2^(2 CL_LOG2S), like the MFMA path).
+// f1t / t00: the (block, texel) base of plane 0 (hi, channels 0-15); ps1 / ps2: plane strides in halves of the two maps
+__device__ __noinline__ float cl_direct(const _Float16* __restrict__ f1t, long ps1, const _Float16* __restrict__ t00, long ps2, int smajS, int sminS,
                                         float wm0, float wm1, float wn0, float wn1) {
     float d[4] = {0.f, 0.f, 0.f, 0.f};
-    const _Float16* tp[4] = {tex00, tex00 + (long)smajS * 128, tex00 + (long)sminS * 128, tex00 + (long)(smajS + sminS) * 128};
+    const _Float16* tp[4] = {t00, t00 + (long)smajS * 16, t00 + (long)sminS * 16, t00 + (long)(smajS + sminS) * 16};
     for (int c8 = 0; c8 < 8; ++c8) {
-        const half8 ah = *reinterpret_cast<const half8*>(f1row + 8 * c8), al = *reinterpret_cast<const half8*>(f1row + 64 + 8 * c8);
+        const int ks = c8 >> 1, kg = c8 & 1;
+        const half8 ah = *reinterpret_cast<const half8*>(f1t + ks * ps1 + kg * 8), al = *reinterpret_cast<const half8*>(f1t + (4 + ks) * ps1 + kg * 8);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const half8 bh = *reinterpret_cast<const half8*>(tp[q] + 8 * c8), bl = *reinterpret_cast<const half8*>(tp[q] + 64 + 8 * c8);
+            const half8 bh = *reinterpret_cast<const half8*>(tp[q] + ks * ps2 + kg * 8), bl = *reinterpret_cast<const half8*>(tp[q] + (4 + ks) * ps2 + kg * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) d[q] = fmaf((float)ah[e] + (float)al[e], (float)bh[e] + (float)bl[e], d[q]);
         }
@@ -177,8 +186,8 @@ extern "C" int cer_cost_lines_trace(unsigned long long* host32, int reset) {
 #endif
 
 struct ClArgs {
-    const _Float16* f1s;      // [P][hi 64 | lo 64]   reference rows of this call's pixel grid
-    const _Float16* f2s;      // [V][(h2+4)*(w2+4)][hi 64 | lo 64]   zero border included
+    const _Float16* f1s;      // [8 planes][P][16]   reference map of this call's pixel grid (cer_feat_split_f16 layout)
+    const _Float16* f2s;      // [V][8 planes][(h2+4)*(w2+4)][16]   zero border included
     const float* Pij;         // [V][16]
     const float* params;      // [V][4]  cost_lines_setup_kernel
     const float* disp_in;     // [P]
@@ -240,12 +249,13 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
 
     // ---- B fragments: the tile's 32 reference rows (lane: pixel slot li, channels 16 ks + 8 kg .. + 7), held for the whole
     // tile-view; requested first: they arrive under the projections below
-    const _Float16* f1row = A.f1s + p_me * 128;
+    const long ps1 = (long)h1 * w1 * 16, ps2 = (long)(h2 + 4) * (w2 + 4) * 16;      // plane strides (halves) of the reference / source maps
+    const _Float16* f1t = A.f1s + p_me * 16;
     half8 bh[4], bl[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        bh[ks] = *reinterpret_cast<const half8*>(f1row + 8 * kg + 16 * ks);
-        bl[ks] = *reinterpret_cast<const half8*>(f1row + 8 * kg + 64 + 16 * ks);
+        bh[ks] = *reinterpret_cast<const half8*>(f1t + ks * ps1 + 8 * kg);
+        bl[ks] = *reinterpret_cast<const half8*>(f1t + (4 + ks) * ps1 + 8 * kg);
     }
 
     // ---- this lane's pixel: origin (core/corr.py:59-62) and ray (utils/projective_ops.py:26-28)
@@ -363,7 +373,7 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
     CL_STAMP(11);                                           // band analysis
     if (CL_ABL == 5) return;
 
-    const _Float16* f2v = A.f2s + (long)(A.slot ? A.slot[v] : v) * (long)(h2 + 4) * wp * 128;
+    const _Float16* f2v = A.f2s + (long)(A.slot ? A.slot[v] : v) * 8 * ps2;
 
     // ---- A fragments of a chunk: wave `wave` owns band texels 32 wave .. + 31 of the chunk (lane: texel li, channels as above)
     half8 ahf[4], alf[4];
@@ -371,14 +381,19 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
     const int colo = t_me / R, rowo = t_me - colo * R;
     const int cstep = dir * (Wc - 1), cb0 = dir > 0 ? cmin : cmax - (Wc - 1);      // chunk n covers band columns cb0 + n cstep .. + Wc - 1
     auto loadA = [&](int n) {
+        if (CL_ABL == 9) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { ahf[ks] = bh[ks]; alf[ks] = bl[ks]; }
+            return;
+        }
         const int col = cb0 + n * cstep + colo;
         const int row = (int)floorf(fmaf(bm, (float)col, bl0)) + rowo;
         const int cc = min(max(col, -2), Wmaj + 1), rc = min(max(row, -2), Wmin + 1);
-        const _Float16* tp = f2v + (long)((cc + 2) * smajS + (rc + 2) * sminS) * 128 + 8 * kg;
+        const _Float16* tp = f2v + (long)((cc + 2) * smajS + (rc + 2) * sminS) * 16 + 8 * kg;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            ahf[ks] = *reinterpret_cast<const half8*>(tp + 16 * ks);
-            alf[ks] = *reinterpret_cast<const half8*>(tp + 64 + 16 * ks);
+            ahf[ks] = *reinterpret_cast<const half8*>(tp + ks * ps2);
+            alf[ks] = *reinterpret_cast<const half8*>(tp + (4 + ks) * ps2);
         }
     };
     if (nchunks > 0) loadA(0);                              // arrives under the projections below
@@ -422,8 +437,8 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
     load_sample();
     auto direct_value = [&]() -> float {
         const int sc = (int)(pk & 0xFFFFu) - 4, sr = (int)((pk >> 16) & 0x3FFFu) - 4;
-        const _Float16* t00 = f2v + (long)((sc + 2) * smajS + (sr + 2) * sminS) * 128;
-        return cl_direct(f1row, t00, smajS, sminS, 1.0f - fm, fm, 1.0f - fn, fn);
+        const _Float16* t00 = f2v + (long)((sc + 2) * smajS + (sr + 2) * sminS) * 16;
+        return cl_direct(f1t, ps1, t00, ps2, smajS, sminS, 1.0f - fm, fm, 1.0f - fn, fn);
     };
 
     CL_COUNT(24, 1);
@@ -435,8 +450,12 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
         floatx16 acc0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
+        if (CL_ABL == 10) {
 #pragma unroll
-        for (int ks = 0; ks < (CL_ABL == 2 ? 0 : 4); ++ks) {
+            for (int ks = 0; ks < 4; ++ks) { acc0[ks] = (float)ahf[ks][0] + (float)alf[ks][1]; }
+        }
+#pragma unroll
+        for (int ks = 0; ks < ((CL_ABL == 2 || CL_ABL == 10) ? 0 : 4); ++ks) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahf[ks], bh[ks], acc0, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahf[ks], bl[ks], acc0, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alf[ks], bh[ks], acc0, 0, 0, 0);
@@ -444,10 +463,14 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
         CL_STAMP(1);                                        // wait for A + MFMA issue
         if (n + 1 < nchunks) loadA(n + 1);                  // in flight during the gather below
         // acc0[r]: texel row (r & 3) + 8 (r >> 2) + 4 kg of this wave's tile, pixel column li
+        if (CL_ABL == 11) {
+            asm volatile("" ::"v"(acc0));
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-            prod[row * 32 + li] = acc0[r];
+            for (int r = 0; r < 16; ++r) {
+                const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                prod[row * 32 + li] = acc0[r];
+            }
         }
         CL_STAMP(2);                                        // MFMA results + dot stores
         __syncthreads();
@@ -457,7 +480,7 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
         for (;;) {
             const unsigned kind = pk >> 30;
             const int scp = (int)(pk & 0xFFFFu);            // cell column + 4
-            const bool in = kind == 0 && scp >= cb + 4 && scp <= cbe + 4;
+            const bool in = kind == 0 && (CL_ABL == 8 || (scp >= cb + 4 && scp <= cbe + 4));
             const bool behind = kind == 0 && (dir > 0 ? scp < cb + 4 : scp > cbe + 4);
             const bool consume = in || behind || kind == 1 || kind == 2;
             if (__ballot(consume) == 0ull) break;
@@ -466,8 +489,9 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
             CL_COUNT(29, __popcll(__ballot(behind || kind == 2)));
             float val = 0.f;
             if (in) {
-                const int t0 = scp * R + (int)((pk >> 16) & 31u) - cbR - 8 * R;      // (scp - 4 - cb) R + r0  [cbR = (cb - 4) R]
-                const int t1 = t0 + R + (int)((pk >> 21) & 31u) - (int)((pk >> 16) & 31u);
+                int t0 = scp * R + (int)((pk >> 16) & 31u) - cbR - 8 * R;      // (scp - 4 - cb) R + r0  [cbR = (cb - 4) R]
+                int t1 = t0 + R + (int)((pk >> 21) & 31u) - (int)((pk >> 16) & 31u);
+                if (CL_ABL == 8) { t0 &= 63; t1 &= 63; }
                 const float* d0 = prod + t0 * 32 + li;
                 const float* d1 = prod + t1 * 32 + li;
                 const float wm1 = fm, wm0 = 1.0f - fm, wn1 = fn, wn0 = 1.0f - fn;

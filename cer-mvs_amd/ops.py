@@ -139,14 +139,14 @@ def overflow_poll(device):
 
 
 def feat_split(x, out=None):
-    """fp32 rows [..., 64] -> split-f16 rows (same shape in bytes: per row 64 hi | 64 lo halves of x * 2^6) for
-    ``cost_build(..., split=...)`` / cer_cost_lines_f32."""
-    if x.shape[-1] != 64:
-        raise RuntimeError("feat_split: rows of 64 channels only")
+    """fp32 rows [texels, 64] (one block: the reference map) or [blocks, texels, 64] (source views) -> the split-f16 operand
+    planes of ``cost_build(..., split=...)`` / cer_cost_lines_f32 (cer_mvs.h: per block 8 planes [texels][16], same bytes)."""
+    if x.shape[-1] != 64 or x.dim() not in (2, 3):
+        raise RuntimeError("feat_split: [texels, 64] or [blocks, texels, 64]")
+    blocks, texels = (1, x.shape[0]) if x.dim() == 2 else (x.shape[0], x.shape[1])
     if out is None:
         out = torch.empty(x.shape[:-1] + (128,), device=x.device, dtype=torch.float16)
-    n = x.numel() // 64
-    L.check(L.load().cer_feat_split_f16(L.dev_ptr(x, "x"), L.dev_ptr(out, "out", torch.float16), n, 64,
+    L.check(L.load().cer_feat_split_f16(L.dev_ptr(x, "x"), L.dev_ptr(out, "out", torch.float16), blocks, texels, 64,
                                         L.dev_ptr(overflow_flag(x.device), "flag", torch.int32), L.cur_stream()), "feat_split")
     return out
 

@@ -117,15 +117,16 @@ int cer_cost_build_algo(int algo);
  * and the treatment of out-of-map / non-finite samples are those of cer_cost_build_f32 (same fp32 expressions); results
  * agree to fp32 rounding of the 64-channel dot.
  *
- * cer_feat_split_f16: fp32 rows [texels, 64] -> split-f16 rows [texels][64 hi | 64 lo] of x * 2^6 (hi = f16(xs),
- *   lo = f16(xs - hi)); same bytes per texel.  |x| > 1023 saturates: *overflow_flag (device int, may be NULL) is or-ed with 1.
- *   Apply to fmap1 [P,64] and to the bordered fmap2 [V,(h2+4)*(w2+4),64] (the zero border stays zero).
+ * cer_feat_split_f16: fp32 rows [blocks, block_texels, 64] -> split-f16 operand planes, same bytes: per block 8 planes
+ *   p = hl * 4 + ks (hl 0 / 1: hi = f16(xs) / lo = f16(xs - hi) of xs = x * 2^6; ks: 16-channel group), each [block_texels][16];
+ *   a block = one view (block_texels = (h2+4)*(w2+4), zero border included and kept zero) or the reference map (h1*w1).
+ *   |x| > 1023 saturates: *overflow_flag (device int, may be NULL) is or-ed with 1.
  * cer_cost_lines_workspace: bytes of `workspace` (per-view partial volumes [V,P,D] + tile parameters).
  * cer_cost_lines_f32: arguments as cer_cost_build_f32 with the split rows in place of fmap1 / fmap2; mode 1 or 2 only.
  *   view_slot (device int [V], may be NULL = identity): view v's rows are block view_slot[v] of fmap2_split - the multi-GPU
  *   forward all-gathers every rank's split rows into one [G, ceil(V/G), ...] buffer and builds from it without a reordering copy.
  */
-int cer_feat_split_f16(const float* src, void* dst, long texels, int C, int* overflow_flag, void* stream);
+int cer_feat_split_f16(const float* src, void* dst, long blocks, long block_texels, int C, int* overflow_flag, void* stream);
 long cer_cost_lines_workspace(int V, int h1, int w1, int D);
 int cer_cost_lines_f32(const void* fmap1_split, const void* fmap2_split, const int* view_slot, const float* Pij, const float* disp_in,
                        float* vol, float* origin_out, void* workspace,

@@ -368,13 +368,13 @@ def test_s16_saturation_raises_the_overflow_flag(dev):
 
 
 def test_feat_split_roundtrip_and_overflow_flag(dev):
-    """cer_feat_split_f16: hi + lo reconstructs x * 64 to 2^-22 relative; a value beyond +-1023 saturates and raises the
+    """cer_feat_split_f16 (plane-major operand layout, cer_mvs.h): hi + lo reconstructs x * 64 to 2^-22 relative; a value beyond +-1023 saturates and raises the
     sticky overflow flag (saturation must not be silent)."""
     from cer_mvs_amd import ops
     x = hashed((500, 64), 881, -900.0, 900.0).to(dev)
     x[3, 5] = 1e-4
-    s = ops.feat_split(x).float()
-    rec = (s[:, :64] + s[:, 64:]) / 64.0
+    s = ops.feat_split(x).float().reshape(8, 500, 16)            # planes hl * 4 + ks, each [texel][16 channels of group ks]
+    rec = (s[:4] + s[4:]).permute(1, 0, 2).reshape(500, 64) / 64.0
     assert float(((rec - x).abs() / x.abs().clamp_min(1e-3)).max()) < 3e-7
     assert not ops.check_overflow(dev)
     x[7, 9] = 1500.0
