@@ -35,6 +35,9 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define CL_T 128                            // texels per chunk (one 32-texel MFMA row tile per wave)
 #define CL_DP 33                            // pitch (float2) of the [hypothesis][pixel] sample / output tile
 #define CL_LOG2S 6                          // operand scale of the split: features (already / 8) saturate at 65504 / 64
+#ifndef CL_LG
+#define CL_LG 16                            // lines per tile-order group
+#endif
 #define CL_RMAX 32                          // widest band (texels across) that still goes through the MFMA path
 #ifndef CL_ABL
 #define CL_ABL 0                            // ablation builds for timing attribution (variants/libcermvs_clabl<N>.so): wrong results
@@ -47,26 +50,29 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 // of 8 columns x 4 rows touches 8 cache lines per load instruction instead of 32 with texel-major 256-B rows - the L1's line
 // rate, not its byte rate, bounded the kernel (1.65 -> see DESIGN.md).
 __global__ __launch_bounds__(256) void feat_split_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long bt, long n2, int* __restrict__ flag) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;    // (texel of the whole tensor, kg); blockIdx.y = ks
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;    // (texel of the whole tensor, kg): a wave reads 32 whole 256-B rows
     if (i >= n2) return;
-    const int ks = blockIdx.y, kg = (int)(i & 1);
+    const int kg = (int)(i & 1);
     const long texel = i >> 1, blk = texel / bt, t = texel - blk * bt;
-    const float* sp = src + texel * 64 + ks * 16 + kg * 8;
-    const float4 a = cer_ld4(sp), b = cer_ld4(sp + 4);
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    cer_h2 h[4], l[4];
+    const float* sp = src + texel * 64 + kg * 8;
+    _Float16* dp = dst + (blk * 8 * bt + t) * 16 + kg * 8;
     bool sat = false;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        cer_f2 x = (cer_f2){v[2 * j], v[2 * j + 1]} * (float)(1 << CL_LOG2S);
-        sat |= !(fabsf(x.x) <= 65504.0f) || !(fabsf(x.y) <= 65504.0f);
-        x = __builtin_elementwise_min(__builtin_elementwise_max(x, (cer_f2){-65504.0f, -65504.0f}), (cer_f2){65504.0f, 65504.0f});
-        h[j] = __builtin_convertvector(x, cer_h2);
-        l[j] = __builtin_convertvector(x - __builtin_convertvector(h[j], cer_f2), cer_h2);
+    for (int ks = 0; ks < 4; ++ks) {
+        const float4 a = cer_ld4(sp + ks * 16), b = cer_ld4(sp + ks * 16 + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        cer_h2 h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cer_f2 x = (cer_f2){v[2 * j], v[2 * j + 1]} * (float)(1 << CL_LOG2S);
+            sat |= !(fabsf(x.x) <= 65504.0f) || !(fabsf(x.y) <= 65504.0f);
+            x = __builtin_elementwise_min(__builtin_elementwise_max(x, (cer_f2){-65504.0f, -65504.0f}), (cer_f2){65504.0f, 65504.0f});
+            h[j] = __builtin_convertvector(x, cer_h2);
+            l[j] = __builtin_convertvector(x - __builtin_convertvector(h[j], cer_f2), cer_h2);
+        }
+        *reinterpret_cast<half8*>(dp + ks * bt * 16) = (half8){h[0].x, h[0].y, h[1].x, h[1].y, h[2].x, h[2].y, h[3].x, h[3].y};
+        *reinterpret_cast<half8*>(dp + (4 + ks) * bt * 16) = (half8){l[0].x, l[0].y, l[1].x, l[1].y, l[2].x, l[2].y, l[3].x, l[3].y};
     }
-    _Float16* dp = dst + ((blk * 8 + ks) * bt + t) * 16 + kg * 8;
-    *reinterpret_cast<half8*>(dp) = (half8){h[0].x, h[0].y, h[1].x, h[1].y, h[2].x, h[2].y, h[3].x, h[3].y};
-    *reinterpret_cast<half8*>(dp + 4 * bt * 16) = (half8){l[0].x, l[0].y, l[1].x, l[1].y, l[2].x, l[2].y, l[3].x, l[3].y};
     if (sat && flag) atomicOr(flag, 1);                     // sticky: a feature beyond +-1023 was clamped (or is not finite)
 }
 
@@ -75,7 +81,7 @@ extern "C" int cer_feat_split_f16(const float* src, void* dst, long blocks, long
     if (C != 64) return CER_ESHAPE;
     if (!cer_aligned16(src) || !cer_aligned16(dst)) return CER_EALIGN;
     const long n2 = blocks * block_texels * 2;
-    hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((n2 + 255) / 256), 4), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst,
+    hipLaunchKernelGGL(feat_split_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst,
                        block_texels, n2, overflow_flag);
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
@@ -228,9 +234,12 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
     const int axis = (int)A.params[v * 4 + 0];
     const float shear = A.params[v * 4 + 1];
     const int La = axis ? h1 : w1, Hm = axis ? w1 : h1;     // extent along / across the tile axis
+    // tile order inside a view: groups of CL_LG lines x all segments, so that the ~100 tiles an XCD works on at a time cover a
+    // compact patch (16 lines x 6 segments: ~2 MB of band rows) instead of 100 lines of one segment (6 MB: its 4 MB L2 thrashed)
     const int njm = Hm + 32, nseg = (La + 31) >> 5;
-    const int seg = (int)((unsigned)rem / (unsigned)njm), jj = rem - seg * njm;
-    if (seg >= nseg) return;
+    const int lg = (int)((unsigned)rem / (unsigned)(nseg * CL_LG)), rem2 = rem - lg * nseg * CL_LG;
+    const int seg = rem2 / CL_LG, jj = lg * CL_LG + (rem2 - seg * CL_LG);
+    if (jj >= njm) return;
     const float cm = 0.5f * (float)La;
     const int a_first = seg * 32, a_last = min(seg * 32 + 31, La - 1);
     const int sh_f = (int)rintf(shear * ((float)a_first - cm)), sh_l = (int)rintf(shear * ((float)a_last - cm));
@@ -623,7 +632,7 @@ extern "C" int cer_cost_lines_views_f32(const void* fmap1_split, const void* fma
     a.lim = (float)((D / 2) * incre_d);
     a.shift = shift;
     a.y0 = y0;
-    const long tx = (long)((w1 + 31) / 32) * (h1 + 32), ty = (long)((h1 + 31) / 32) * (w1 + 32);
+    const long tx = (long)((w1 + 31) / 32) * ((h1 + 32 + CL_LG - 1) / CL_LG * CL_LG), ty = (long)((h1 + 31) / 32) * ((w1 + 32 + CL_LG - 1) / CL_LG * CL_LG);
     a.tpv = (int)(tx > ty ? tx : ty);
     const long nblk = (long)nv * a.tpv;
     if (nblk >= (1L << 31)) return CER_ESHAPE;
