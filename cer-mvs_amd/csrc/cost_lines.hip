@@ -7,26 +7,31 @@
 // texel dot products,
 //     <f1(p), bilerp(f2)(u, w)>  =  bilerp over the 4 texels of  <f1(p), f2(texel)>,
 // and all samples of a reference pixel lie on ONE line of the source image (its epipolar line); reference pixels on the same
-// reference epipolar line share that source line.  So the reference image is partitioned, per source view, into tiles of 64
-// pixels that follow the view's epipolar direction (digital lines: a shear of the pixel grid, chosen per view from Pij), and
-// per (view, tile):
-//   1. the tile's samples live in a thin band of the source map: `ncol` columns along the band's major axis x R texels
-//      across (R = 4..6 when the shear fits).  The band is processed in chunks of CL_T = 128 texels;
-//   2. per chunk, dots[texel][pixel] = <f2(texel), f1(pixel)> for ALL 128 x 64 pairs is one MFMA product per wave
-//      (32 texels x 64 pixels x 64 channels, split-f16: three f16 MFMAs into one fp32 accumulator, fp32-class - conv_s16.hip);
-//      operands arrive as pre-split hi|lo f16 rows (cer_feat_split_f16) straight from global memory in fragment order:
-//      every band texel is read once per tile (4 x fewer L1 bytes than there are samples x 16 B), nothing is staged;
-//   3. lane = pixel: each lane walks ITS hypotheses in order (a cursor), and for every sample whose cell lies in the chunk
-//      reads its 4 dots from LDS (16 B instead of 1 KiB), applies the bilinear weights and stores the value in the tile's
-//      [hypothesis][pixel] output tile; samples outside the source image are zeros (the walk's zero border);
+// reference epipolar line share that source line.  So the reference image is partitioned, per source view, into tiles of 32
+// pixels that follow the view's epipolar direction (digital lines: a shear of the pixel grid, chosen per view from Pij by
+// cost_lines_setup_kernel), and per (view, tile) - one 256-thread block:
+//   1. the tile's samples live in a thin band of the source map: columns along the band's major axis x R texels across
+//      (R = 4..6 when the shear fits; measured 3.9 / 3.6 on the bench scene).  Wave 0 derives the band (major axis, line,
+//      R, column range, travel direction) from the end points of every pixel's segment; the band is walked in chunks of
+//      CL_T = 128 texels (measured: 6.9 chunks per tile at stage 0, 2.8 at stage 1);
+//   2. per chunk, dots[texel][pixel] = <f2(texel), f1(pixel)> for ALL 128 x 32 pairs: each wave one MFMA tile of 32 texels x
+//      32 pixels x 64 channels (split-f16: three f16 MFMAs into one fp32 accumulator, fp32-class - conv_s16.hip).  Operands
+//      are pre-split hi|lo f16 PLANES (cer_feat_split_f16) read straight from global memory in fragment order, the next
+//      chunk's while the current one is gathered: every band texel is read once per tile, nothing is staged;
+//   3. every sample was projected ONCE, before the chunk loop, by straight-line code (two IEEE divisions, cell, fractions,
+//      band rows packed into 16 B of LDS per sample); in the loop lane (pixel, hypothesis phase) walks its samples in order
+//      (a cursor) and, for each one whose cell lies in the chunk, reads its 4 dots from LDS (16 B instead of 1 KiB),
+//      applies the bilinear weights and stores the value; samples outside the source image are zeros (the walk's zero border);
 //   4. anything the band analysis did not cover (projections blown apart near Z = 0, epipoles inside the image, rough
-//      per-pixel origins that break the cursor's monotonic order) takes a per-sample direct path: correct, slow, rare.
-// Views are independent (their tiles differ), so each (view, tile) writes its [64 px][D] result to a per-view partial
+//      per-pixel origins that break the cursor's monotonic order, bands wider than 29 texels) takes a per-sample direct path:
+//      correct, slow, rare.
+// Views are independent (their tiles differ), so each (view, tile) writes its [32 px][D] result to a per-view partial
 // volume; cost_lines_reduce_kernel sums the partials in view order (deterministic), applies the view-mean scale and emits
 // the pooled pyramid levels - the fused epilogue of the walk.
 //
 // The coordinate arithmetic (hypothesis, projection, IEEE divisions, clamps, floor, fractions) is expression-for-expression
-// that of cost_build.hip, so cells and weights are bit-identical to the walk; only the 64-channel dot differs in rounding.
+// that of cost_build.hip, so cells and weights are bit-identical to the walk; only the 64-channel dot differs in rounding
+// (4e-8 relative L1 on the bench scene).  Measured, what shaped it and what is left: DESIGN.md section 3e.
 #include "common.hpp"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -35,13 +40,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define CL_T 128                            // texels per chunk (one 32-texel MFMA row tile per wave)
 #define CL_DP 33                            // pitch (float2) of the [hypothesis][pixel] sample / output tile
 #define CL_LOG2S 6                          // operand scale of the split: features (already / 8) saturate at 65504 / 64
-#ifndef CL_LG
-#define CL_LG 16                            // lines per tile-order group
-#endif
+#define CL_LG 16                            // lines per tile-order group (4 .. 64 measured alike)
 #define CL_RMAX 32                          // widest band (texels across) that still goes through the MFMA path
-#ifndef CL_ABL
-#define CL_ABL 0                            // ablation builds for timing attribution (variants/libcermvs_clabl<N>.so): wrong results
-#endif
 
 // ---- fp32 rows -> split-f16 operand planes.  Per block of `bt` texels (one source view, or the reference map):
 //   8 planes p = hl * 4 + ks (hl: 0 = hi, 1 = lo half of x * 2^CL_LOG2S; ks: 16-channel group), each [bt][16 halves]:
@@ -160,37 +160,6 @@ __device__ __noinline__ float cl_direct(const _Float16* __restrict__ f1t, long p
     return d[0] * (wn0 * wm0) + d[1] * (wn0 * wm1) + d[2] * (wn1 * wm0) + d[3] * (wn1 * wm1);
 }
 
-// -DCL_TRACE=1 (variants/libcermvs_cltrace.so, tools/trace_lines.py): wave 0 of every block adds its cycle counts per phase
-// and a few event counts to a global table - where a tile's life goes.  Not compiled into the product library.
-#ifdef CL_TRACE
-__device__ unsigned long long cl_trace[32];
-extern "C" int cer_cost_lines_trace(unsigned long long* host32, int reset) {
-    if (reset) {
-        unsigned long long z[32] = {0};
-        return (int)hipMemcpyToSymbol(HIP_SYMBOL(cl_trace), z, sizeof(z));
-    }
-    return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(cl_trace), 32 * sizeof(unsigned long long));
-}
-#define CL_STAMP(slot)                                                 \
-    do {                                                               \
-        const unsigned long long now__ = __builtin_readcyclecounter(); \
-        tr_acc[slot] += now__ - tr_last;                               \
-        tr_last = now__;                                               \
-    } while (0)
-#define CL_COUNT(slot, n) do { tr_cnt[(slot) - 24] += (unsigned long long)(n); } while (0)
-#define CL_FLUSH()                                                                  \
-    do {                                                                            \
-        if (tid == 0) {                                                             \
-            for (int i__ = 0; i__ < 16; ++i__) atomicAdd(&cl_trace[i__], tr_acc[i__]);     \
-            for (int i__ = 0; i__ < 8; ++i__) atomicAdd(&cl_trace[24 + i__], tr_cnt[i__]); \
-        }                                                                           \
-    } while (0)
-#else
-#define CL_STAMP(slot) do { } while (0)
-#define CL_COUNT(slot, n) do { } while (0)
-#define CL_FLUSH() do { } while (0)
-#endif
-
 struct ClArgs {
     const _Float16* f1s;      // [8 planes][P][16]   reference map of this call's pixel grid (cer_feat_split_f16 layout)
     const _Float16* f2s;      // [V][8 planes][(h2+4)*(w2+4)][16]   zero border included
@@ -219,9 +188,6 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kg = lane >> 5;
-#ifdef CL_TRACE
-    unsigned long long tr_last = __builtin_readcyclecounter(), tr_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
     // XCD-aware order (blocks are dealt round-robin over the 8 XCDs): each XCD gets a contiguous range of (view, segment, line):
     // neighbouring lines share most of their band, which then stays in that XCD's L2
     unsigned o;
@@ -253,8 +219,6 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
     const int x_me = axis ? b_me : a_me, y_me = axis ? a_me : b_me;
     const long p_me = (long)min(max(y_me, 0), h1 - 1) * w1 + min(max(x_me, 0), w1 - 1);
     if (wave == 0 && lane < 32) pidx[lane] = valid ? (int)p_me : -1;
-    CL_STAMP(8);                                            // tile decode
-    if (CL_ABL == 4) return;
 
     // ---- B fragments: the tile's 32 reference rows (lane: pixel slot li, channels 16 ks + 8 kg .. + 7), held for the whole
     // tile-view; requested first: they arrive under the projections below
@@ -379,8 +343,6 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
     dir = __builtin_amdgcn_readfirstlane(dir);
     bm = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bm)));
     bl0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bl0)));
-    CL_STAMP(11);                                           // band analysis
-    if (CL_ABL == 5) return;
 
     const _Float16* f2v = A.f2s + (long)(A.slot ? A.slot[v] : v) * 8 * ps2;
 
@@ -390,11 +352,6 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
     const int colo = t_me / R, rowo = t_me - colo * R;
     const int cstep = dir * (Wc - 1), cb0 = dir > 0 ? cmin : cmax - (Wc - 1);      // chunk n covers band columns cb0 + n cstep .. + Wc - 1
     auto loadA = [&](int n) {
-        if (CL_ABL == 9) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) { ahf[ks] = bh[ks]; alf[ks] = bl[ks]; }
-            return;
-        }
         const int col = cb0 + n * cstep + colo;
         const int row = (int)floorf(fmaf(bm, (float)col, bl0)) + rowo;
         const int cc = min(max(col, -2), Wmaj + 1), rc = min(max(row, -2), Wmin + 1);
@@ -412,7 +369,6 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
     const int k0 = 2 * wave + kg;
 #pragma unroll 2
     for (int k = k0; k < D; k += 8) {
-        if (CL_ABL == 3) { *reinterpret_cast<float4*>(desc + (k * CL_DP + li) * 4) = make_float4(__uint_as_float(((unsigned)(cmin + 4 + (k * (cmax - cmin)) / D)) & 0xFFFFu), 0.5f, 0.5f, 0.f); continue; }
         float u, w;
         const bool ok = project(k, u, w);
         const float fu = floorf(u), fw = floorf(w);
@@ -429,8 +385,6 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
         const unsigned packed = (unsigned)(sc + 4) + ((unsigned)(hi14 & 0x3FFF) << 16) + ((unsigned)kind2 << 30);
         *reinterpret_cast<float4*>(desc + (k * CL_DP + li) * 4) = make_float4(__uint_as_float(packed), smaj ? dw : du, smaj ? du : dw, 0.f);
     }
-    CL_STAMP(9);                                            // projections
-    if (CL_ABL == 6) return;
 
     // ---- per-lane sample cursor
     int k = valid ? k0 : D;
@@ -439,7 +393,7 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
     auto load_sample = [&]() {                              // (a lane only ever reads descriptors it wrote itself)
         if (k >= D) { pk = 3u << 30; return; }
         const float4 d = *reinterpret_cast<const float4*>(desc + (k * CL_DP + li) * 4);
-        pk = CL_ABL == 1 ? (1u << 30) : __float_as_uint(d.x);
+        pk = __float_as_uint(d.x);
         fm = d.y;
         fn = d.z;
     };
@@ -450,63 +404,45 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
         return cl_direct(f1t, ps1, t00, ps2, smajS, sminS, 1.0f - fm, fm, 1.0f - fn, fn);
     };
 
-    CL_COUNT(24, 1);
-    CL_COUNT(25, nchunks);
-    CL_COUNT(26, R);
     for (int n = 0; n < nchunks; ++n) {
         const int cb = cb0 + n * cstep;
         // ---- dots of this wave's 32 texels with the 32 pixels: 12 MFMAs
         floatx16 acc0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
-        if (CL_ABL == 10) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) { acc0[ks] = (float)ahf[ks][0] + (float)alf[ks][1]; }
-        }
-#pragma unroll
-        for (int ks = 0; ks < ((CL_ABL == 2 || CL_ABL == 10) ? 0 : 4); ++ks) {
+        for (int ks = 0; ks < 4; ++ks) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahf[ks], bh[ks], acc0, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahf[ks], bl[ks], acc0, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alf[ks], bh[ks], acc0, 0, 0, 0);
         }
-        CL_STAMP(1);                                        // wait for A + MFMA issue
         if (n + 1 < nchunks) loadA(n + 1);                  // in flight during the gather below
         // acc0[r]: texel row (r & 3) + 8 (r >> 2) + 4 kg of this wave's tile, pixel column li
-        if (CL_ABL == 11) {
-            asm volatile("" ::"v"(acc0));
-        } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                prod[row * 32 + li] = acc0[r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            prod[row * 32 + li] = acc0[r];
         }
-        CL_STAMP(2);                                        // MFMA results + dot stores
         __syncthreads();
-        CL_STAMP(3);                                        // barrier 1
         // ---- gather: every lane consumes its samples whose cell lies in this chunk; zeros and direct-path samples as they come
         const int cbe = cb + Wc - 2, cbR = (cb - 4) * R;    // last cell column of the chunk; band index of (column c, row r) = c R + r - cb R
         for (;;) {
             const unsigned kind = pk >> 30;
             const int scp = (int)(pk & 0xFFFFu);            // cell column + 4
-            const bool in = kind == 0 && (CL_ABL == 8 || (scp >= cb + 4 && scp <= cbe + 4));
+            const bool in = kind == 0 && scp >= cb + 4 && scp <= cbe + 4;
             const bool behind = kind == 0 && (dir > 0 ? scp < cb + 4 : scp > cbe + 4);
             const bool consume = in || behind || kind == 1 || kind == 2;
             if (__ballot(consume) == 0ull) break;
-            CL_COUNT(27, 1);
-            CL_COUNT(28, __popcll(__ballot(consume)));
-            CL_COUNT(29, __popcll(__ballot(behind || kind == 2)));
             float val = 0.f;
             if (in) {
-                int t0 = scp * R + (int)((pk >> 16) & 31u) - cbR - 8 * R;      // (scp - 4 - cb) R + r0  [cbR = (cb - 4) R]
-                int t1 = t0 + R + (int)((pk >> 21) & 31u) - (int)((pk >> 16) & 31u);
-                if (CL_ABL == 8) { t0 &= 63; t1 &= 63; }
+                const int t0 = scp * R + (int)((pk >> 16) & 31u) - cbR - 8 * R;      // (scp - 4 - cb) R + r0  [cbR = (cb - 4) R]
+                const int t1 = t0 + R + (int)((pk >> 21) & 31u) - (int)((pk >> 16) & 31u);
                 const float* d0 = prod + t0 * 32 + li;
                 const float* d1 = prod + t1 * 32 + li;
                 const float wm1 = fm, wm0 = 1.0f - fm, wn1 = fn, wn0 = 1.0f - fn;
                 val = d0[0] * (wn0 * wm0) + d1[0] * (wn0 * wm1) + d0[32] * (wn1 * wm0) + d1[32] * (wn1 * wm1);
             }
-            if (CL_ABL != 7 && __ballot(behind || kind == 2) != 0ull) {    // rare: the wave-level test keeps the call off the hot path
+            if (__ballot(behind || kind == 2) != 0ull) {    // rare: the wave-level test keeps the call off the hot path
                 if (behind || kind == 2) {
                     if (kind == 0) {                        // re-pack a band sample as a direct one: its cell row from the band row
                         const int sc = scp - 4;
@@ -522,13 +458,10 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
                 load_sample();
             }
         }
-        CL_STAMP(4);                                        // gather
         __syncthreads();
-        CL_STAMP(5);                                        // barrier 2
     }
     // ---- what the chunks did not cover (no band, samples out of order): direct path
     while (__ballot((pk >> 30) != 3u) != 0ull) {
-        CL_COUNT(30, __popcll(__ballot((pk >> 30) != 3u && (pk >> 30) != 1u)));
         if ((pk >> 30) != 3u) {
             float val = 0.f;
             if ((pk >> 30) != 1u) {
@@ -544,7 +477,6 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
             load_sample();
         }
     }
-    CL_STAMP(6);                                            // leftovers
     __syncthreads();
     // ---- rows out: wave w writes pixel slots w, w + 4, ...; lane = hypothesis (one coalesced D-float row per store)
     float* pv = A.part + (long)v * ((long)h1 * w1) * D;
@@ -552,8 +484,6 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
         const int p = pidx[i];
         if (p >= 0 && lane < D) pv[(long)p * D + lane] = desc[(lane * CL_DP + i) * 4 + 3];
     }
-    CL_STAMP(7);                                            // rows out
-    CL_FLUSH();
 }
 
 // ---- sum of the per-view partials (view order: deterministic) * scale, origin, pooled levels: wave per pixel, lane = hypothesis

@@ -315,6 +315,32 @@ def test_cost_lines_matches_walk(dev, D, stage0, geom):
     assert not ops.check_overflow(dev)
 
 
+def test_pipelined_build_is_bit_identical(dev, golden):
+    """RAFT.PIPELINE_BUILD (stage-0 partial volumes built per view batch on a second stream under the encoders,
+    cer_cost_lines_views_f32 + cer_cost_lines_reduce_f32) computes exactly what the one-call build computes."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.synthetic import fill_state_dict
+    g = golden("e2e_cfg1")
+    cascade = [tuple(int(x) for x in c) for c in g["cascade"]]
+    model = RAFT(cascade=cascade, test_mode=True)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(g["weight_seed"])))
+    model = model.to(dev).eval()
+    images, poses, intr, scale = cached_scene(int(g["H"]), int(g["W"]), int(g["V"]), int(g["scene_seed"]))
+    args = (images.to(dev), poses.to(dev), intr.to(dev))
+    prev = RAFT.PIPELINE_BUILD
+    try:
+        with torch.no_grad():
+            RAFT.PIPELINE_BUILD = False
+            a = model(*args, scale=scale)
+            RAFT.PIPELINE_BUILD = True
+            b = model(*args, scale=scale)
+            c = model(*args, scale=scale)
+    finally:
+        RAFT.PIPELINE_BUILD = prev
+    assert torch.equal(a, b) and torch.equal(b, c)
+    assert rel_l1(a.cpu(), torch.from_numpy(g["disp"])) < TOL
+
+
 def test_encoder_type_lr_matches_reference_capture(dev, golden):
     """encoder_type="LR" (core/extractor.py:87-90,151: a third residual stage, features at 1/8 resolution, core/raft.py:38) end to
     end against the reference's own output (tests/golden/e2e_lr.npz) - fast path and literal path."""
