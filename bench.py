@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--mode", default="both", choices=["both", "shard", "views", "replica"],
                     help="N > 1: both = time the view-shard scheme (north_star's) AND the row-slab scheme, headline = row-slab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent depth maps kept in flight per GPU (cer-mvs_amd/pipeline.py: the product's inference() default is 2); "
+                         "1 = one at a time.  Sharded N > 1 modes always run one depth map at a time")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1: nccl (= RCCL over xGMI, the product path) or gloo (validation "
                          "of the multi-rank code path on a box with fewer GPUs than ranks: ranks share devices)")
@@ -200,16 +203,41 @@ def main():
         seed = 0 if (shard or world == 1) else rank          # replicas: a different reference frame per rank
         images, poses, intr, scale = synthetic_scene(H, W, V, seed=seed)
         inputs = (images.to(dev), poses.to(dev), intr.to(dev))
+        S = 1 if shard else max(1, args.streams)
+        lat = None
         with torch.no_grad():
-            for _ in range(args.warmup):
-                out = model(*inputs, scale=scale)
-            sync()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                out = model(*inputs, scale=scale)
-            sync()
-            elapsed = time.perf_counter() - t0
+            if S == 1:
+                for _ in range(args.warmup):
+                    out = model(*inputs, scale=scale)
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    out = model(*inputs, scale=scale)
+                sync()
+                elapsed = time.perf_counter() - t0
+            else:
+                # S depth maps in flight (DepthMapPipeline: one model replica + one HIP stream each, submitted round-robin): every
+                # step is a complete forward; the steps overlap on the GPU.  One-at-a-time time first, for the record.
+                from cer_mvs_amd.pipeline import DepthMapPipeline
+                pipe = DepthMapPipeline(model, streams=S)
+                for _ in range(max(args.warmup, S)):
+                    out = pipe.result(pipe.submit(*inputs, scale), wait_on_host=False)
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(min(args.steps, 3)):
+                    out = model(*inputs, scale=scale)
+                torch.cuda.synchronize()
+                lat = (time.perf_counter() - t0) / min(args.steps, 3)
+                sync()
+                t0 = time.perf_counter()
+                handles = [pipe.submit(*inputs, scale) for _ in range(args.steps)]
+                out = pipe.result(handles[-1], wait_on_host=False)
+                sync()
+                elapsed = time.perf_counter() - t0
+                assert all(torch.equal(pipe.result(h_), out) for h_ in handles)      # (same input every step: same output every step)
         assert torch.isfinite(out).all()
+        timed_run.one_at_a_time_ms = None if lat is None else 1e3 * lat
+        timed_run.streams = S
         if world > 1:
             import torch.distributed as dist
             tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -375,12 +403,21 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "image": f"{W}x{H}", "src_views": V, "cascade": cascade,
                        "gru_iters": sum(c[2] for c in cascade),
+                       "depth_maps_in_flight": getattr(timed_run, "streams", 1),
                        "parallelism": "single" if world == 1 else (
                            (f"row-slab x{world}: source-feature all-gather (overlapped with the reference encode) + 7-row halo exchanged "
                             f"point-to-point with the 2 neighbours per GRU iteration" if args.mode == "shard"
                             else f"view-shard x{world} + all-reduce/stage") if shard else f"replica x{world}"),
                        **({"backend": "gloo (validation run, ranks may share a GPU)"} if (world > 1 and args.backend == "gloo") else {})},
             **({"modes": modes} if modes is not None else {}),
+            **({"one_at_a_time": {"ms_per_depth_map": timed_run.one_at_a_time_ms, "value": 1e3 / timed_run.one_at_a_time_ms,
+                                  "note": "the same forward with ONE depth map in flight (--streams 1): the latency of a depth map, and what "
+                                          "`value` was in rounds 1-2.  `value` / `ms_per_step` above are the throughput with "
+                                          f"{timed_run.streams} independent depth maps in flight on {timed_run.streams} HIP streams "
+                                          "(cer-mvs_amd/pipeline.py, the product's inference() default): every step is a complete "
+                                          "forward, the steps overlap and fill each other's partially filled last waves of tiles.  The "
+                                          "roofline / kernels entries below come from a one-at-a-time instrumented pass"}}
+               if getattr(timed_run, "one_at_a_time_ms", None) else {}),
             "roofline": roofline, "roofline_hbm_kernel": hbm, "inner_loop": inner, "kernels": kern,
             "instrumented_pass": {"wall_ms": inst_wall_ms, "sum_of_kernels_ms": sum(t for _, t in rec.values()),
                                   "note": "one extra forward after the timed region with HIP events around every library launch and "

@@ -154,9 +154,14 @@ def feat_split(x, out=None):
 _LINES_WS = {}
 
 
+def lines_workspace(V, h1, w1, D, device):
+    """The (persistent, per device and stream) workspace of the epipolar-line-tile cost volume: partial volumes + tile parameters."""
+    return _lines_workspace(V, h1, w1, D, device)
+
+
 def _lines_workspace(V, h1, w1, D, device):
     need = int(L.load().cer_cost_lines_workspace(V, h1, w1, D))
-    key = str(device)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)       # per stream: forwards on different streams overlap
     ws = _LINES_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, device=device, dtype=torch.uint8)
@@ -233,18 +238,19 @@ def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, 
     return vol, origin
 
 
-def cost_lines_views(f1s, f2s, slots, Pij, disp_in, V, v0, nv, h1, w1, D, incre, shift, src_hw=None, y0=0):
+def cost_lines_views(f1s, f2s, slots, Pij, disp_in, V, v0, nv, h1, w1, D, incre, shift, src_hw=None, y0=0, ws=None):
     """First half of the epipolar-line-tile cost volume for views v0 .. v0 + nv - 1 of V: their partial volumes go to the device's
     lines workspace (cer_cost_lines_views_f32).  ``cost_lines_reduce`` finishes the volume once every view has been built."""
     h2, w2 = src_hw if src_hw is not None else (h1, w1)
-    ws = _lines_workspace(V, h1, w1, D, f1s.device)
+    if ws is None:                                           # (callers that split the two halves over streams pass one workspace to both)
+        ws = _lines_workspace(V, h1, w1, D, f1s.device)
     L.check(L.load().cer_cost_lines_views_f32(L.dev_ptr(f1s, "fmap1_split", torch.float16), L.dev_ptr(f2s, "fmap2_split", torch.float16),
                                               L.dev_ptr(slots, "view_slot", torch.int32), L.dev_ptr(Pij, "Pij"), L.dev_ptr(disp_in, "disp_in"),
                                               L.dev_ptr(ws, "workspace", torch.uint8), V, int(v0), int(nv), h1, w1, h2, w2, 64, D, float(incre),
                                               int(bool(shift)), int(y0), L.cur_stream()), "cost_lines_views")
 
 
-def cost_lines_reduce(disp_in, V, h1, w1, D, incre, shift, num_levels, pyramid_scale=None, vol=None, accumulate=False):
+def cost_lines_reduce(disp_in, V, h1, w1, D, incre, shift, num_levels, pyramid_scale=None, vol=None, accumulate=False, ws=None):
     """Second half: sum of the V partial volumes -> (vol [P, rs], origin [P]) with the fused view-mean scale + pooled levels when
     ``pyramid_scale`` is given (as ``cost_build``)."""
     P = h1 * w1
@@ -258,7 +264,8 @@ def cost_lines_reduce(disp_in, V, h1, w1, D, incre, shift, num_levels, pyramid_s
             if offs[-1] + lens[-1] < rs:
                 vol[..., offs[-1] + lens[-1]:] = 0
     origin = torch.empty(P, device=dev, dtype=torch.float32)
-    ws = _lines_workspace(V, h1, w1, D, dev)
+    if ws is None:
+        ws = _lines_workspace(V, h1, w1, D, dev)
     L.check(L.load().cer_cost_lines_reduce_f32(L.dev_ptr(ws, "workspace", torch.uint8), L.dev_ptr(disp_in, "disp_in"), L.dev_ptr(vol, "vol"),
                                                L.dev_ptr(origin, "origin"), V, h1, w1, D, rs, float(incre), int(bool(shift)),
                                                2 if accumulate else 1, num_levels if fuse else 0, float(pyramid_scale) if fuse else 1.0,

@@ -1,0 +1,76 @@
+"""Several independent depth maps in flight on one GPU.
+
+The reference's ``inference.py`` runs its loader one reference view at a time; every forward here is ~200 dependent kernel
+launches, and each launch ends with a partially filled last wave of tiles (the z|r gate convolution: 925 tiles on 512 block
+slots - 99 of the 256 CUs idle for the last fifth of the launch).  Two forwards on two HIP streams fill each other's tails:
+measured at DTU 1600x1184 x 10 views x 32 iterations 18.3 ms per depth map against 20.8 ms one at a time (tools/exp_streams.py;
+three streams: 18.0), outputs bit-identical.  ``DepthMapPipeline`` keeps ``streams`` forwards in flight: one replica of the model
+per stream (a deep copy - the packed weights, feature buffers and workspaces of a forward are per replica, the library itself is
+stateless), round-robin submission from one host thread."""
+import collections
+import copy
+
+import torch
+
+
+class DepthMapPipeline:
+    def __init__(self, model, streams=2, device=None):
+        if streams < 1:
+            raise ValueError("DepthMapPipeline: streams must be >= 1")
+        dev = device if device is not None else next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("DepthMapPipeline: the model must live on a GPU (there is no CPU path)")
+        self.device = dev
+        self.models = [model] + [copy.deepcopy(model) for _ in range(streams - 1)]
+        for m in self.models:
+            m.eval()
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(streams)]
+        self._next = 0
+
+    def __len__(self):
+        return len(self.streams)
+
+    def submit(self, images, poses, intrinsics, scale, **kw):
+        """Enqueue one test-mode forward on the next stream; returns a handle for ``result``.  The inputs must stay alive and
+        unmodified until the result has been taken."""
+        k = self._next % len(self.streams)
+        self._next += 1
+        st = self.streams[k]
+        st.wait_stream(torch.cuda.current_stream(self.device))       # inputs produced on the caller's stream
+        with torch.cuda.stream(st), torch.no_grad():
+            out = self.models[k](images, poses, intrinsics, scale=scale, **kw)
+            done = torch.cuda.Event()
+            done.record(st)
+        for t in (images, poses, intrinsics):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(st)
+        return out, done, st
+
+    @staticmethod
+    def result(handle, wait_on_host=True):
+        """The disparity of a submitted forward.  ``wait_on_host``: block until it is ready (read-back follows); otherwise only the
+        caller's current stream is made to wait for it."""
+        out, done, st = handle
+        if wait_on_host:
+            done.synchronize()
+        else:
+            torch.cuda.current_stream(out.device).wait_event(done)
+        out.record_stream(torch.cuda.current_stream(out.device))
+        return out
+
+    def map(self, items, **kw):
+        """items: iterable of (images, poses, intrinsics, scale) -> yields the disparities in order, ``len(self)`` forwards in flight."""
+        pending = collections.deque()
+        for it in items:
+            pending.append(self.submit(*it, **kw))
+            if len(pending) >= len(self.streams):
+                yield self.result(pending.popleft())
+        while pending:
+            yield self.result(pending.popleft())
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
+
+    def check_overflow(self, raise_error=True):
+        return self.models[0].check_overflow(self.device, raise_error=raise_error)

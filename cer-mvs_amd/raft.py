@@ -218,6 +218,7 @@ class RAFT(nn.Module):
         if buf is None:                        # border texels are written once (zeros) and never touched again
             buf = torch.zeros(V, Pb, self.dim_fmap, device=dev, dtype=torch.float32)
             self._src_buf = {key: buf}
+        lws = ops.lines_workspace(V, h, w, D, dev)           # (this stream's: both halves of the build use it)
         f1s = torch.empty(h * w, 128, device=dev, dtype=torch.float16)
         f2s = torch.empty(V, Pb, 128, device=dev, dtype=torch.float16)
         f1, v0 = None, 0
@@ -234,11 +235,11 @@ class RAFT(nn.Module):
                 if bi == 0:
                     ops.feat_split(f1, out=f1s)
                 ops.feat_split(buf[v0:v0 + nvb], out=f2s[v0:v0 + nvb])
-                ops.cost_lines_views(f1s, f2s, None, Pij, disp, V, v0, nvb, h, w, D, incre, True)
+                ops.cost_lines_views(f1s, f2s, None, Pij, disp, V, v0, nvb, h, w, D, incre, True, ws=lws)
             v0 += nvb
         done = torch.cuda.Event()
         done.record(side)                      # (the caller waits for it right before the view reduction: the hoisted convs run meanwhile)
-        return net, inp, f1, buf, (f1s, f2s), done
+        return net, inp, f1, buf, (f1s, f2s), (done, lws)
 
     # ---------------------------------------------------------------- forward
     def forward(self, images, poses, intrinsics, scale=None, do_report=False):
@@ -335,8 +336,8 @@ class RAFT(nn.Module):
             hoisted = hoisted_all[stage]
             single = self.view_group is None   # no cross-rank sum between the build and the pooling: fuse them
             if pipelined and stage == 0:          # the partial volumes were built under the encoders: only the view reduction is left
-                torch.cuda.current_stream().wait_event(build_done)
-                vol, origin = ops.cost_lines_reduce(disp, V, h, w, D, incre, True, ub.num_levels, pyramid_scale=1.0 / V)
+                torch.cuda.current_stream().wait_event(build_done[0])
+                vol, origin = ops.cost_lines_reduce(disp, V, h, w, D, incre, True, ub.num_levels, pyramid_scale=1.0 / V, ws=build_done[1])
             elif views:
                 vol, origin = ops.cost_build(f1, f2, Pij, disp, D, incre, stage == 0, h, w, ub.num_levels, fold=True,
                                              pyramid_scale=(1.0 / V) if (single and D <= 64) else None, split=split)

@@ -315,6 +315,30 @@ def test_cost_lines_matches_walk(dev, D, stage0, geom):
     assert not ops.check_overflow(dev)
 
 
+def test_depth_map_pipeline_two_streams(dev, golden):
+    """pipeline.DepthMapPipeline: two independent depth maps in flight on two HIP streams (a model replica each) give, in order,
+    exactly the disparities of one-at-a-time forwards - alternating between two different scenes."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.pipeline import DepthMapPipeline
+    from cer_mvs_amd.synthetic import fill_state_dict
+    g = golden("e2e_cfg1")
+    cascade = [tuple(int(x) for x in c) for c in g["cascade"]]
+    model = RAFT(cascade=cascade, test_mode=True)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(g["weight_seed"])))
+    model = model.to(dev).eval()
+    scenes = []
+    for seed in (int(g["scene_seed"]), 17):
+        images, poses, intr, scale = cached_scene(int(g["H"]), int(g["W"]), int(g["V"]), seed)
+        scenes.append((images.to(dev), poses.to(dev), intr.to(dev), scale))
+    with torch.no_grad():
+        want = [model(*s_[:3], scale=s_[3]).clone() for s_ in scenes]
+    assert rel_l1(want[0].cpu(), torch.from_numpy(g["disp"])) < TOL and not torch.equal(want[0], want[1])
+    pipe = DepthMapPipeline(model, streams=2)
+    got = list(pipe.map([scenes[i % 2] for i in range(7)]))
+    assert len(got) == 7 and all(torch.equal(o, want[i % 2]) for i, o in enumerate(got))
+    assert pipe.check_overflow() == 0
+
+
 def test_pipelined_build_is_bit_identical(dev, golden):
     """RAFT.PIPELINE_BUILD (stage-0 partial volumes built per view batch on a second stream under the encoders,
     cer_cost_lines_views_f32 + cer_cost_lines_reduce_f32) computes exactly what the one-call build computes."""
