@@ -330,6 +330,15 @@ def main():
                 if "note" in a_:
                     e["note"] = a_["note"]
             kern[k] = e
+        try:                                                      # HBM traffic of the cost-volume kernel from the committed PMC passes
+            with open(os.path.join(REPO, "profiles", "r03_pmc_traffic.json")) as f:
+                pm = json.load(f).get("cost_lines_kernel", {})
+            for k in kern:
+                if k.startswith("cost_build_stage") and "traffic_bytes" in pm:
+                    kern[k]["pmc_traffic_bytes_avg_of_both_stages"] = pm["traffic_bytes"]
+                    kern[k]["pmc_source"] = "profiles/r03_pmc_traffic.json (cost_lines_kernel, mean of the stage-0 and stage-1 launches)"
+        except Exception:
+            pass
         enc = [(k, v) for k, v in rec.items() if k.startswith("enc_")]
         enc_ms = 0.0
         if enc and world == 1:
@@ -365,7 +374,7 @@ def main():
         else:
             kname = "conv3x3_kernel<2,2,4,4,GATES> (z|r gates, 3x3, K=177, N=128; exact fp32 MFMA)"
         traffic, traffic_src = None, None                        # HBM bytes per launch from the committed PMC passes
-        for cand in ("r02_pmc_traffic.json",):
+        for cand in ("r02_pmc_traffic.json", "r03_pmc_traffic.json"):       # (the later file wins)
             try:
                 with open(os.path.join(REPO, "profiles", cand)) as f:
                     traffic = json.load(f)["conv3x3_gates_zr"]["traffic_bytes"] if args.gru_precision == "s16" else None

@@ -14,7 +14,7 @@ model = model.to(dev).eval()
 images, poses, intr, scale = synthetic_scene(H, W, V, seed=0)
 x = (images.to(dev), poses.to(dev), intr.to(dev))
 n = 12
-for S in (1, 2, 3, 1, 2):
+for S in (2, 3, 4, 2, 3, 4):
     models = [model] + [copy.deepcopy(model) for _ in range(S - 1)]
     streams = [torch.cuda.Stream() for _ in range(S)]
     outs = [None] * S

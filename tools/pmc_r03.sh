@@ -13,3 +13,9 @@ for re in "cost_lines_kernel" "cost_lines_reduce_kernel" "feat_split_kernel"; do
     tools/pmc.sh "$out/$re/$tag" "$re" "$set" -- python tools/prof_build.py | sed "s/^/$re /"
   done
 done | tee "$out/counters.txt"
+# the roofline kernel (z|r gate convolution, unchanged since round 2) and the lookup, launched alone at the bench shapes
+for set in "${SETS[@]}"; do
+  tag=$(echo $set | tr ' ' '_')
+  tools/pmc.sh "$out/conv3x3_gates_zr/$tag" "conv3x3_s16_kernel<1, 4, 4, 2>" "$set" -- python tools/bench_conv_s16.py --only "z|r" --rounds 1 --reps 1 | sed "s/^/conv3x3_gates_zr /"
+  tools/pmc.sh "$out/lookup_encode/$tag" "lookup_encode" "$set" -- python tools/prof_conv.py lookup --reps 1 | sed "s/^/lookup_encode /"
+done | tee -a "$out/counters.txt"
