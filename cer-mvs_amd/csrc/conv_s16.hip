@@ -43,9 +43,6 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define SX_DTW 24                          // disparity tile columns (halo + 3 each side)
 #define SX_EPI_DELTA 4
 #define SX_HID_LOG2 4                      // scale of the delta head's hidden activations (relu outputs)
-#ifndef SX_ABL
-#define SX_ABL 0     // profiling ablations (variant builds only): 1 no tensor staging, 2 weights always from step 0 (L1 hits), 4 no epilogue
-#endif               // stores, 8 no barriers in the main loop, 16 no MFMA, 32 no activation fragment reads
 #ifndef SX_TRACE
 #define SX_TRACE 0   // variant builds only (tools/trace_s16.py): per wave cycle stamps + HW_ID written to `aux2` (GATES: unused there)
 #endif
@@ -267,7 +264,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
     // generate the disparity group); the barrier follows before tap 8
     auto stage_tap = [&](const SxStage& st, int bufoff, int t) {
         if (st.kind == 2) {
-            if (SX_ABL & 1) return;
             if (t == 0) stage_load(st, 0);
             if (t == 3) { stage_store(bufoff, 0); stage_load(st, 1); }
             if (t == 6) stage_store(bufoff, 1);
@@ -278,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
     };
     auto barrier = [&]() {
         __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): this wave's LDS writes have landed, its reads returned
-        if (!(SX_ABL & 8)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
     };
 
     // ---- the group sequence: tensors chunk by chunk (two half-chunk groups of 9 taps), then the disparity source
@@ -304,13 +300,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
     XFrag fx;                                              // activation fragments of the CURRENT step; each m-tile's pair is re-loaded
     WFrag fw[3];                                           // for the next step as soon as its last MFMA of this step has issued
     auto load_w = [&](WFrag& f, int step) {
-        const char* p = wlane + ((SX_ABL & 2) ? 0L : (long)min(step, nsteps - 1) * wstep);
+        const char* p = wlane + (long)min(step, nsteps - 1) * wstep;
         f.h = *reinterpret_cast<const half8*>(p);
         f.l = *reinterpret_cast<const half8*>(p + 1024);
     };
     const SxStage st0 = describe(0);
     uint4 raw0[ITEMS];
-    if (st0.kind == 2 && !(SX_ABL & 1)) {
+    if (st0.kind == 2) {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const int pk = st_pk[i];
@@ -356,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
             if (tid + 256 * i < DROWS * SX_DTW) ldsD[tid + 256 * i] = dval[i];
     }
     if (st0.kind == 2) {
-        if (!(SX_ABL & 1)) {
+        {
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
                 const int pk = st_pk[i];
@@ -379,7 +375,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
         for (int r = 0; r < 16; ++r) acc[m][r] *= a.S;
 
     auto load_x = [&](XFrag& f, int ph, int pl, int rowoff) {      // rowoff: compile-time (dy rows)
-        if (SX_ABL & 32) return;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             f.h[m] = *reinterpret_cast<const half8*>(sx_smem + ph + (2 * m) * SX_ROWB + rowoff);
@@ -388,14 +383,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
     };
     // one step: 3 * MT MFMAs (consecutive MFMAs hit different accumulators), and the next step's fragments rolled in behind them
     auto mma_roll = [&](const WFrag& w, int ph, int pl, int rowoff) {
-        if (SX_ABL & 16) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(fx.h[m]), "v"(fx.l[m]), "v"(w.h), "v"(w.l));
-#endif
-            load_x(fx, ph, pl, rowoff);
-            return;
-        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h, fx.h[m], acc[m], 0, 0, 0);
         // the hi fragments are needed first in the next step: roll them in during the SECOND term (2 * MT - 1 MFMAs of slack for the
@@ -403,13 +390,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.l, fx.h[m], acc[m], 0, 0, 0);
-            if (!(SX_ABL & 32)) fx.h[m] = *reinterpret_cast<const half8*>(sx_smem + ph + (2 * m) * SX_ROWB + rowoff);
+            fx.h[m] = *reinterpret_cast<const half8*>(sx_smem + ph + (2 * m) * SX_ROWB + rowoff);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h, fx.l[m], acc[m], 0, 0, 0);
-            if (!(SX_ABL & 32)) fx.l[m] = *reinterpret_cast<const half8*>(sx_smem + pl + (2 * m) * SX_ROWB + rowoff);
+            fx.l[m] = *reinterpret_cast<const half8*>(sx_smem + pl + (2 * m) * SX_ROWB + rowoff);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -515,13 +502,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
         }
     }
     const int half = a.cout >> 1;
-    if (SX_ABL & 4) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(acc[m]));
-#endif
-        return;
-    }
     if constexpr (EPI == SX_EPI_DELTA) {
         // delta head, fused (core/update.py:68-71): hid = relu(conv) stays in registers; its hi|lo halves ARE B fragments of the
         // projection  T[tap][p] = sum_c w2[tap][c] * hid[p][c]  over this wave's 32 channels (2 k16-steps x 3 MFMAs per m-tile);
