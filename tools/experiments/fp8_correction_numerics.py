@@ -36,9 +36,18 @@ def q8(t):
     return (t * s).to(torch.float8_e4m3fn).to(torch.float32) / s
 
 
+ONLY = None      # restrict the emulation to convs with this weight shape[:2] (others: f16x3)
+
+
 def conv_emul(x, w, b=None, **kw):
     if MODE == "fp32" or w.shape[-1] != 3 or w.shape[1] < 64:
         return real_conv2d(x, w, b, **kw)
+    if ONLY is not None and tuple(w.shape[:2]) != ONLY:
+        return conv_mode(x, w, b, "f16x3", **kw)
+    return conv_mode(x, w, b, MODE, **kw)
+
+
+def conv_mode(x, w, b, MODE, **kw):
     sx, sw = pow2_scale(x, 16384.0), pow2_scale(w, 16384.0)
     xs, ws = x * sx, w * sw
     xh, wh = q16(xs), q16(ws)
@@ -47,6 +56,10 @@ def conv_emul(x, w, b=None, **kw):
     main = real_conv2d(xh.to(d), wh.to(d), None, **kw)
     if MODE == "f16":
         corr = 0
+    elif MODE == "xh_w2":        # activations f16 (hi only), weights hi + lo: 2 MFMAs
+        corr = real_conv2d(xh.to(d), wl.to(d), None, **kw)
+    elif MODE == "x2_wh":        # activations hi + lo, weights f16 (hi only): 2 MFMAs
+        corr = real_conv2d(xl.to(d), wh.to(d), None, **kw)
     elif MODE == "f16x3":
         corr = real_conv2d(xh.to(d), wl.to(d), None, **kw) + real_conv2d(xl.to(d), wh.to(d), None, **kw)
     else:
@@ -67,7 +80,7 @@ def main():
     outs = {}
     O.F.conv2d = conv_emul
     try:
-        for mode in ("fp32", "f16x3", "fp8c", "f16"):
+        for mode in ("fp32", "f16x3", "fp8c", "xh_w2", "x2_wh", "f16"):
             MODE = mode
             t0 = time.time()
             with torch.no_grad():
@@ -76,7 +89,18 @@ def main():
     finally:
         O.F.conv2d = real_conv2d
     ref = outs["fp32"]
-    for mode in ("f16x3", "fp8c", "f16"):
+    global ONLY
+    O.F.conv2d = conv_emul
+    try:
+        for shape in ((64, 64), (64, 241), (256, 64), (1, 256)):
+            ONLY, MODE = shape, "xh_w2"
+            with torch.no_grad():
+                o = O.raft_forward(sd, images, poses, intr, scale, cascade=cascade).double()
+            print(f"xh_w2 only in convs {shape}: rel-L1 vs fp32 {float((o - ref).abs().sum() / ref.abs().sum()):.3e}", flush=True)
+    finally:
+        O.F.conv2d = real_conv2d
+        ONLY = None
+    for mode in ("f16x3", "fp8c", "xh_w2", "x2_wh", "f16"):
         print(f"{mode:6s} rel-L1 vs fp32: {float((outs[mode] - ref).abs().sum() / ref.abs().sum()):.3e}")
 
 
