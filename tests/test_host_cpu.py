@@ -44,6 +44,34 @@ def test_argument_errors_without_device():
     misaligned = ctypes.c_void_p(0x1004)
     assert lib.cer_alt_corr_forward_f32(misaligned, fake, fake, fake, 1, 1, 4, 4, 4, 4, 64, 0, null) == -3
     assert b"CER_ESHAPE" in lib.cer_error_string(-2)
+    # round-3 entry points: the epipolar-line-tile cost volume and its operand split (argument checks only - nothing is launched)
+    dbl = ctypes.c_double(0.1)
+    assert lib.cer_feat_split_f16(null, null, 1, 10, 64, null, null) == -1
+    assert lib.cer_feat_split_f16(fake, fake, 1, 10, 32, null, null) == -2                                     # C != 64
+    assert lib.cer_feat_split_f16(misaligned, fake, 1, 10, 64, null, null) == -3
+    assert lib.cer_cost_lines_workspace(10, 296, 400, 64) == 10 * 296 * 400 * 64 * 4 + 10 * 16 + 256 and lib.cer_cost_lines_workspace(0, 1, 1, 1) == -1
+    args = (1, 4, 4, 4, 4, 64, 64, 112, dbl, 1)
+    assert lib.cer_cost_lines_f32(null, null, null, null, null, null, null, null, *args, 1, 0, 0, 1.0, null) == -1
+    assert lib.cer_cost_lines_f32(fake, fake, null, fake, fake, fake, fake, fake, *args, 0, 0, 0, 1.0, null) == -1      # mode 0: per-view volumes are the walk's
+    assert lib.cer_cost_lines_f32(fake, fake, null, fake, fake, fake, fake, fake, 1, 4, 4, 4, 4, 64, 80, 144, dbl, 1, 1, 0, 0, 1.0, null) == -2   # D > 64
+    assert lib.cer_cost_lines_f32(fake, fake, null, fake, fake, fake, fake, fake, 1, 4, 4, 4, 4, 128, 64, 112, dbl, 1, 1, 0, 0, 1.0, null) == -2  # C != 64
+    assert lib.cer_cost_lines_views_f32(fake, fake, null, fake, fake, fake, 4, 3, 2, 4, 4, 4, 4, 64, 64, dbl, 1, 0, null) == -1      # views 3..4 of 4
+    assert lib.cer_cost_lines_reduce_f32(fake, fake, fake, null, 2, 4, 4, 64, 60, dbl, 1, 1, 0, 1.0, null) == -1           # row shorter than D
+    assert lib.cer_cost_lines_reduce_f32(fake, fake, fake, null, 2, 4, 4, 64, 112, dbl, 1, 2, 3, 1.0, null) == -1          # fused pyramid needs mode 1
+    assert lib.cer_f16_scan_overflow(fake, 24, fake, 4, null) == -1 and lib.cer_f16_scan_overflow(misaligned, 32, fake, 4, null) == -3
+    assert lib.cer_overflow_flag(null) == 0 and lib.cer_cost_build_algo(-1) in (0, 1)
+
+
+def test_depth_map_pipeline_argument_checks():
+    """pipeline.DepthMapPipeline refuses a CPU model (there is no CPU path) and a stream count below one."""
+    import pytest, torch
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.pipeline import DepthMapPipeline
+    model = RAFT(cascade=[(64, 64, 1), (-1, 320, 1)], test_mode=True)
+    with pytest.raises(RuntimeError, match="GPU"):
+        DepthMapPipeline(model, streams=2)
+    with pytest.raises(ValueError):
+        DepthMapPipeline(model, streams=0)
 
 
 def test_argument_errors_of_the_conv_and_encoder_entry_points():
