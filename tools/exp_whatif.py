@@ -64,3 +64,21 @@ def fake_encode(self, images, views, raw=False, parts="all"):
     return net.clone(), inp, f1, f2
 RAFT.encode = fake_encode
 run("encoders free", 1); run("encoders free", 2)
+
+RAFT.encode = real_encode
+# ---- inner-loop kernels made free one class at a time (raw C-ABI level: replayed launch plans call the library directly)
+from cer_mvs_amd import _lib as L
+import ctypes
+lib = L.load()
+def free_symbol(name):
+    real = getattr(lib, name)
+    class Fake:
+        def __call__(self, *a):
+            return 0
+    setattr(lib, name, Fake())
+    return real
+for names, label in ((("cer_lookup_encode_f32",), "lookup free"), (("cer_delta_sum_f32",), "delta_sum free")):
+    reals = {n_: free_symbol(n_) for n_ in names}
+    run(label, 1); run(label, 2)
+    for n_, r_ in reals.items():
+        setattr(lib, n_, r_)
