@@ -146,6 +146,8 @@ def feat_split(x, out=None):
     blocks, texels = (1, x.shape[0]) if x.dim() == 2 else (x.shape[0], x.shape[1])
     if out is None:
         out = torch.empty(x.shape[:-1] + (128,), device=x.device, dtype=torch.float16)
+    elif out.numel() != 2 * x.numel() or out.device != x.device:
+        raise RuntimeError(f"feat_split: out must hold {2 * x.numel()} halves on {x.device} (got {out.numel()} on {out.device})")
     L.check(L.load().cer_feat_split_f16(L.dev_ptr(x, "x"), L.dev_ptr(out, "out", torch.float16), blocks, texels, 64,
                                         L.dev_ptr(overflow_flag(x.device), "flag", torch.int32), L.cur_stream()), "feat_split")
     return out

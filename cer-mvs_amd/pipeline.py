@@ -6,7 +6,8 @@ slots - 99 of the 256 CUs idle for the last fifth of the launch).  Two forwards 
 measured at DTU 1600x1184 x 10 views x 32 iterations 18.3 ms per depth map against 20.8 ms one at a time (tools/exp_streams.py;
 three streams: 18.0), outputs bit-identical.  ``DepthMapPipeline`` keeps ``streams`` forwards in flight: one replica of the model
 per stream (a deep copy - the packed weights, feature buffers and workspaces of a forward are per replica, the library itself is
-stateless), round-robin submission from one host thread."""
+stateless; ``refresh_weights`` re-synchronises the replicas after the original's parameters changed), round-robin submission from
+one host thread."""
 import collections
 import copy
 
@@ -29,6 +30,13 @@ class DepthMapPipeline:
 
     def __len__(self):
         return len(self.streams)
+
+    def refresh_weights(self):
+        """Copy the first model's parameters into the replicas (after fine-tuning / load_state_dict on the original); the replicas'
+        packed weights follow through RAFT's own parameter-version check on their next forward."""
+        sd = self.models[0].state_dict()
+        for m in self.models[1:]:
+            m.load_state_dict(sd)
 
     def submit(self, images, poses, intrinsics, scale, **kw):
         """Enqueue one test-mode forward on the next stream; returns a handle for ``result``.  The inputs must stay alive and

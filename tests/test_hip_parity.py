@@ -337,6 +337,13 @@ def test_depth_map_pipeline_two_streams(dev, golden):
     got = list(pipe.map([scenes[i % 2] for i in range(7)]))
     assert len(got) == 7 and all(torch.equal(o, want[i % 2]) for i, o in enumerate(got))
     assert pipe.check_overflow() == 0
+    # new weights on the original reach the replica through refresh_weights()
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=99))
+    pipe.refresh_weights()
+    with torch.no_grad():
+        want2 = model(*scenes[0][:3], scale=scenes[0][3]).clone()
+    got2 = list(pipe.map([scenes[0]] * 2))
+    assert not torch.equal(want2, want[0]) and all(torch.equal(o, want2) for o in got2)
 
 
 def test_pipelined_build_is_bit_identical(dev, golden):

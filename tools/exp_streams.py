@@ -13,8 +13,8 @@ model.load_state_dict(fill_state_dict(model.state_dict(), seed=5))
 model = model.to(dev).eval()
 images, poses, intr, scale = synthetic_scene(H, W, V, seed=0)
 x = (images.to(dev), poses.to(dev), intr.to(dev))
-n = 12
-for S in (2, 3, 4, 2, 3, 4):
+n = 24
+for S in (4, 6, 8, 4, 6, 8):
     models = [model] + [copy.deepcopy(model) for _ in range(S - 1)]
     streams = [torch.cuda.Stream() for _ in range(S)]
     outs = [None] * S
