@@ -15,6 +15,7 @@ _LAZY = {
     "BasicEncoder": ("extractor", "BasicEncoder"),
     "alt_cuda_corr": ("alt_cuda_corr", None),
     "inference": ("inference", "inference"),
+    "DepthMapPipeline": ("pipeline", "DepthMapPipeline"),
 }
 
 
