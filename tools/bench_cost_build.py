@@ -26,7 +26,7 @@ with torch.no_grad():
         for _ in range(reps): fn()
         e1.record(); torch.cuda.synchronize()
         return 1e3 * e0.elapsed_time(e1) / reps
-    for algo, name in ((1, "walk"), (2, "band gemm")):
+    for algo, name in ((1, "walk"), (0, "line tiles")):
         lib.cer_cost_build_algo(algo)
         us = t(lambda: ops.cost_build(f1, f2, Pij, disp0, D0, i0, True, h, w, 3, fold=True, pyramid_scale=0.1))
         print(f"stage0 {name:10s} {us:8.1f} us")
