@@ -701,7 +701,7 @@ static double sx_w9(const float* w, int Cin, int co, int c, int sidx) {
 
 // log2 of the product scale S shared by all sources: the largest power of two that keeps every scaled weight
 // |w| * S / 2^log2sx(src) below 2^14 (f16 max 65504), for the literal and the collapsed packing alike.  Returns CER_ESHAPE
-// (as a value < -1000) if some source's largest scaled weight would then fall below 2 (its lo half would lose bits).
+// (as a value < -1000) if some source's largest scaled weight would then fall below 2^-3 (its lo halves go subnormal: fewer than 22 bits).
 extern "C" int cer_conv3x3_s16_scale(const float* w, int Cout, int Cin, const int* ch, const int* kind, const int* log2sx, int nsrc) {
     if (!w || !ch || !kind || !log2sx || nsrc <= 0 || nsrc > CER_CONV_MAX_SRC) return -100000;
     double wmax[CER_CONV_MAX_SRC];
@@ -741,10 +741,11 @@ extern "C" int cer_conv3x3_s16_scale(const float* w, int Cout, int Cin, const in
         best = k < best ? k : best;
     }
     if (best == 1000) best = 14;
-    // the shared scale is set by the source with the largest weights; a source whose largest scaled weight then falls below 2 keeps
-    // fewer than 22 bits (its lo halves go subnormal): refuse, the caller falls back to the f16x3 kernels (per-tensor splits)
+    // the shared scale is set by the source with the largest weights.  A source's lo halves are f16 residuals of magnitude <= 2^-11 of
+    // its scaled weights; once they fall into the f16 subnormal range (spacing 2^-24) the source keeps fewer than 22 bits relative to
+    // its own largest weight when that weight, scaled, is below 2^-3: refuse, the caller falls back to the f16x3 kernels (per-tensor splits)
     for (int s = 0; s < nsrc; ++s)
-        if (wmax[s] > 0.0 && ldexp(wmax[s], best - log2sx[s]) < 2.0) return -100000 + CER_ESHAPE;
+        if (wmax[s] > 0.0 && ldexp(wmax[s], best - log2sx[s]) < 0.125) return -100000 + CER_ESHAPE;
     return best;
 }
 
