@@ -338,3 +338,31 @@ def test_pfm_and_ply_io(tmp_path):
                                        lib_null, lib_null, lib_null) == -1
     assert lib.cer_geo_consistency_f32(fake, fake, fake, 11, 8, 8, 4.0, 1300.0, lib_null, lib_null, lib_null, lib_null, lib_null, lib_null,
                                        lib_null, lib_null, lib_null) == -2      # the reference's vote indexes at most 9 masks
+
+
+def test_s16_shared_scale_bounds():
+    """cer_conv3x3_s16_scale (host): the shared product scale keeps the largest scaled weight below 2^14 and refuses weight
+    tensors in which a source's largest scaled weight would fall below 2^-3 (its lo halves would go subnormal)."""
+    from importlib import import_module
+    lib = import_module("cer-mvs_amd._lib").load()
+    I3 = ctypes.c_int * 2
+    ch, kind, sx = I3(32, 32), I3(0, 0), I3(6, 6)
+    g = np.random.default_rng(3)
+    w = g.standard_normal((64, 64, 3, 3)).astype(np.float32) * 0.05
+    k = lib.cer_conv3x3_s16_scale(w.ctypes.data, 64, 64, ch, kind, sx, 2)
+    assert k > -1000
+    assert np.abs(w).max() * 2.0 ** (k - 6) < 2 ** 14 <= np.abs(w).max() * 2.0 ** (k + 1 - 6)
+    # second source 2^-19 of the first: 2^14 * 2^-19 = 2^-5 < 2^-3 -> refused
+    w2 = w.copy()
+    w2[:, 32:] *= 2.0 ** -19
+    assert lib.cer_conv3x3_s16_scale(w2.ctypes.data, 64, 64, ch, kind, sx, 2) < -1000
+    # 2^-15 of the first still fits (2^13 .. 2^14 scaled maximum times 2^-15 >= 2^-2)
+    w3 = w.copy()
+    w3[:, 32:] *= 2.0 ** -15
+    assert lib.cer_conv3x3_s16_scale(w3.ctypes.data, 64, 64, ch, kind, sx, 2) == k
+    # an all-zero source is not a reason to refuse
+    w4 = w.copy()
+    w4[:, 32:] = 0
+    assert lib.cer_conv3x3_s16_scale(w4.ctypes.data, 64, 64, ch, kind, sx, 2) == k
+    # channel counts must add up to Cin
+    assert lib.cer_conv3x3_s16_scale(w.ctypes.data, 64, 64, I3(32, 16), kind, sx, 2) < -1000
