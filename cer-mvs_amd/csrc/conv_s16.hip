@@ -30,16 +30,19 @@
 //   * the hoisted `init` term / bias is the accumulators' initial value (16-byte loads in the prologue).
 #include "common.hpp"
 #include <math.h>
+#include <type_traits>
 #include <stdlib.h>
 #include <string.h>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef int intx8 __attribute__((ext_vector_type(8)));
 
 #define SX_TW 16                           // tile width in pixels
 #define SX_HW 18                           // halo columns
 #define SX_PITCH 20                        // LDS pixels per halo row (pitch % 4 == 0 keeps (q % 4) == (col % 4))
 #define SX_ROWB (SX_PITCH * 64)            // LDS bytes per halo row
+#define SX_ROWB8 (SX_PITCH * 128)          // ... of a 32-channel chunk in the fp8-correction form
 #define SX_DTW 24                          // disparity tile columns (halo + 3 each side)
 #define SX_EPI_DELTA 4
 #define SX_HID_LOG2 4                      // scale of the delta head's hidden activations (relu outputs)
@@ -100,11 +103,12 @@ struct SxStage {                           // what to put into the NEXT activati
     int g;                                 // disparity group index
 };
 
-template <int WM_, int WN_, int MT, int EPI>
+template <int WM_, int WN_, int MT, int EPI, int F8>
 __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
     constexpr int TH = WM_ * 2 * MT, HR = TH + 2;
-    constexpr int ABUF = HR * SX_ROWB;
+    constexpr int ABUF = HR * (F8 ? SX_ROWB8 : SX_ROWB);
     constexpr int NPIX = HR * SX_HW, NITEM = NPIX * 4, ITEMS = (NITEM + 255) / 256;
+    constexpr int NITEM8 = NPIX * 4, ITEMS8 = F8 ? (NITEM8 + 255) / 256 : 1;
     constexpr int NB = WN_ * 32;
     constexpr int DROWS = HR + 6;
     extern __shared__ __attribute__((aligned(16))) char sx_smem[];
@@ -145,9 +149,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
     const bool coll = dsrc && a.wpk_c && (interior || a.edge);
     int nsteps = 0;
     for (int s = 0; s < ntens; ++s) nsteps += (a.ch[s] >> 4) * 9;
+    const int nsteps_t = nsteps;           // steps of the tensor sources (F8: two of them form one 32-channel chunk step of 4 KiB)
     if (dsrc) nsteps += coll ? 6 : 36;
     const char* wlane = reinterpret_cast<const char*>(coll ? a.wpk_c : a.wpk) + ((long)(nb0 >> 5) + wn) * 2048 + lane * 16;
     const long wstep = (long)NT * 2048;    // bytes per step
+    // F8: [chunk step][n-tile][f16 hi of half-chunk 0 | of half-chunk 1 | fp8 bytes 0-15 | fp8 bytes 16-31][lane][16 B]
+    const char* wlane8 = reinterpret_cast<const char*>(coll ? a.wpk_c : a.wpk) + ((long)(nb0 >> 5) + wn) * 4096 + lane * 16;
 
     // ---- per-lane LDS addresses of the activation fragments: pixel (row 2*(wm*MT+m) + (li>>4) + dy, col (li&15) + dx) of the
     // halo tile; 16-byte slot kg (hi) / kg ^ 2 (lo), XOR-swizzled with ((col >> 2) & 3)
@@ -208,6 +215,83 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
             if (pk & (1 << 28)) *reinterpret_cast<uint4*>(sx_smem + bufoff + (r * SX_PITCH + c) * 64 + (it & 3) * 16) = v;
         }
     };
+    // ---- fp8-correction form (F8): a 32-channel chunk per buffer, 128 B per halo pixel in eight 16-byte slots:
+    //   2 kg + hc (0-3): f16 hi halves of the 8 channels (half-chunk hc, kg) - the B fragments of the main term;
+    //   4 + 2 kg + hc:   8 fp8 bytes of those channels' hi halves * 2^-8 | 8 fp8 bytes of their lo halves * 2^3:
+    //   slots 4 + 2 kg and 5 + 2 kg are the lane's 32-byte B operand of v_mfma_scale_f32_32x32x64_f8f6f4 (K = [xh | xl] of half-chunk 0,
+    //   then of half-chunk 1; the weights carry [wl | wh] in the same positions).  Physical slot = logical ^ ((col >> 1) & 7): the 16
+    //   pixels of a quarter wave land in 16 different 16-byte columns of the 256-byte bank line for every tap.  A lane's four
+    //   fragments of a pixel are at xa ^ {0, 16, 64, 80}.
+    int xa[3];
+    if constexpr (F8) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int col = (li & 15) + dx;
+            xa[dx] = (2 * wm * MT + (li >> 4)) * SX_ROWB8 + col * 128 + (((2 * kg) ^ ((col >> 1) & 7)) << 4);
+        }
+    }
+    // staging items: (halo pixel n, hc, kg) = 8 channels: their hi and lo pieces (two 16-byte loads 1 KiB apart) become one f16 slot
+    // (the hi piece as it is) and one fp8 slot (v_cvt_scalef32_pk_fp8_f16 divides by its scale operand: hi / 2^8 | lo / 2^-3)
+    int st8_pk[ITEMS8];                    // m-tile | li << 20 | valid << 28 | in-range << 29
+    if constexpr (F8) {
+#pragma unroll
+        for (int i = 0; i < ITEMS8; ++i) {
+            const int it = tid + 256 * i;
+            const int n = min(it >> 2, NPIX - 1);
+            const int r = n / SX_HW, c = n - r * SX_HW;
+            const int gy = ty0 + r - 1, gx = tx0 + c - 1;
+            const bool valid = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+            const int cy = min(max(gy, 0), a.h - 1), cx = min(max(gx, 0), a.w - 1);
+            st8_pk[i] = ((cy >> 1) * a.mtx + (cx >> 4)) | ((((cy & 1) << 4) | (cx & 15)) << 20) | ((valid ? 1 : 0) << 28) | ((it < NITEM8 ? 1 : 0) << 29);
+        }
+    }
+    constexpr int IB8 = (ITEMS8 + 2) / 3;  // items per batch; three batches per chunk (taps 0 -> 2, 2 -> 4, 4 -> 6)
+    uint4 raw8[IB8][2];
+    auto stage8_addr = [&](const SxStage& st, int pk, int it) {
+        return st.base + (long)(pk & 0xFFFFF) * st.mtb + (((it >> 1) & 1) * 2048 + (it & 1) * 512 + ((pk >> 20) & 31) * 16);
+    };
+    auto stage8_put = [&](int bufoff, int pk, int it, uint4 vh, uint4 vl) {
+        const unsigned m = (pk & (1 << 28)) ? 0xFFFFFFFFu : 0u;                // zero padding of the feature map
+        vh.x &= m; vh.y &= m; vh.z &= m; vh.w &= m;
+        vl.x &= m; vl.y &= m; vl.z &= m; vl.w &= m;
+        const int n = it >> 2, r = (n * 3641) >> 16, c = n - r * SX_HW;         // n / 18 for n < 3641
+        const int hc = (it >> 1) & 1, kgs = it & 1, key = (c >> 1) & 7;
+        char* px = sx_smem + bufoff + (r * SX_PITCH + c) * 128;
+        union { uint4 u; cer_h2 h[4]; } ch, cl;
+        ch.u = vh; cl.u = vl;
+        typedef short short2_t __attribute__((ext_vector_type(2)));
+        union { uint4 u; short2_t s[4]; } q;
+        q.s[0] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16((short2_t){0, 0}, ch.h[0], 256.0f, false);
+        q.s[0] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q.s[0], ch.h[1], 256.0f, true);
+        q.s[1] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16((short2_t){0, 0}, ch.h[2], 256.0f, false);
+        q.s[1] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q.s[1], ch.h[3], 256.0f, true);
+        q.s[2] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16((short2_t){0, 0}, cl.h[0], 0.125f, false);
+        q.s[2] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q.s[2], cl.h[1], 0.125f, true);
+        q.s[3] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16((short2_t){0, 0}, cl.h[2], 0.125f, false);
+        q.s[3] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q.s[3], cl.h[3], 0.125f, true);
+        if (pk & (1 << 29)) {
+            *reinterpret_cast<uint4*>(px + (((2 * kgs + hc) ^ key) << 4)) = vh;
+            *reinterpret_cast<uint4*>(px + (((4 + 2 * kgs + hc) ^ key) << 4)) = q.u;
+        }
+    };
+    auto stage8_load = [&](const SxStage& st, int batch) {
+#pragma unroll
+        for (int k = 0; k < IB8; ++k) {
+            const int i = batch * IB8 + k;
+            if (i >= ITEMS8) break;
+            const char* p = stage8_addr(st, st8_pk[i] ^ vary, (tid ^ vary) + 256 * i);
+            raw8[k][0] = *reinterpret_cast<const uint4*>(p);
+            raw8[k][1] = *reinterpret_cast<const uint4*>(p + 1024);
+        }
+    };
+    auto stage8_store = [&](int bufoff, int batch) {
+#pragma unroll
+        for (int k = 0; k < IB8; ++k) {
+            const int i = batch * IB8 + k;
+            if (i >= ITEMS8) break;
+            stage8_put(bufoff, st8_pk[i] ^ vary, (tid ^ vary) + 256 * i, raw8[k][0], raw8[k][1]);
+        }
+    };
     // literal disparity features, group g (channels 16g .. 16g+15 of 100 * (unfold7x7(d) - d), core/update.py:80-85,97)
     auto gen_literal = [&](int g, int bufoff) {
         for (int n = tid ^ vary; n < NPIX; n += 256) {
@@ -236,51 +320,68 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
     };
     // collapsed disparity features, group g: channel s = (sy, sx) of the 9x9 window holds 100 * (d[p + s - 4] - d[p]); only the
     // tile's own pixels (the centre tap) are read
+    // (Waves 0 and 1 generate, as in round 2.  Spreading the two channel halves over the wave pairs - waves 0, 1: channels 0-7,
+    // waves 2, 3: channels 8-15, a wave-uniform branch - produced intermittently wrong last tile rows on the MI355X, 6 launches of 8,
+    // with nothing wrong in the generated code that we could find; this form and a lane-interleaved four-wave form: 0 of 1 200.)
     auto gen_collapsed = [&](int g, int bufoff) {
-        for (int n = tid ^ vary; n < TH * SX_TW; n += 256) {
+        // one half unit = (pixel, 8 of the group's 16 channels): the window offsets are compile-time constants and fold into the
+        // ds_read offsets (the section was bound by the generators' address arithmetic: 11.0 k -> 7.3 k cycles for its six steps)
+        auto half_unit = [&](auto kh_tag, int n) {
+            constexpr int kh = decltype(kh_tag)::value;
             const int pr = n >> 4, pc = n & 15;
-            const float ctr = ldsD[(pr + 4) * SX_DTW + pc + 4];
-            float v[16];
+            const float* dp = ldsD + pr * SX_DTW + pc;
+            const float ctr = dp[4 * SX_DTW + 4];
+            float v[8];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int s = 16 * g + k;
+            for (int k = 0; k < 8; ++k) {
+                const int s = 16 * g + 8 * kh + k;
                 const int sy = (s * 57) >> 9, sx = s - 9 * sy;                  // s / 9, s % 9 for s < 96
-                v[k] = (s < 81) ? 100.0f * (ldsD[(pr + sy) * SX_DTW + pc + sx] - ctr) : 0.f;
+                v[k] = (s < 81) ? 100.0f * (dp[sy * SX_DTW + sx] - ctr) : 0.f;
             }
             const int c = pc + 1;
             char* px = sx_smem + bufoff + ((pr + 1) * SX_PITCH + c) * 64;
             const int key = (c >> 2) & 3;
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh) {
-                const float u[8] = {v[8 * kh], v[8 * kh + 1], v[8 * kh + 2], v[8 * kh + 3], v[8 * kh + 4], v[8 * kh + 5], v[8 * kh + 6], v[8 * kh + 7]};
-                half8 hi, lo;
-                sx_split8(u, a.disp_scale, hi, lo);
-                *reinterpret_cast<half8*>(px + ((kh ^ key) * 16)) = hi;
-                *reinterpret_cast<half8*>(px + (((2 + kh) ^ key) * 16)) = lo;
-            }
+            half8 hi, lo;
+            sx_split8(v, a.disp_scale, hi, lo);
+            *reinterpret_cast<half8*>(px + ((kh ^ key) * 16)) = hi;
+            *reinterpret_cast<half8*>(px + (((2 + kh) ^ key) * 16)) = lo;
+        };
+        for (int u = tid ^ vary; u < TH * SX_TW; u += 256) {
+            half_unit(std::integral_constant<int, 0>{}, u);
+            half_unit(std::integral_constant<int, 1>{}, u);
         }
     };
     // staging schedule inside a 9-tap group: tap 0 load batch 0; tap 3 write batch 0, load batch 1; tap 6 write batch 1 (or
     // generate the disparity group); the barrier follows before tap 8
     auto stage_tap = [&](const SxStage& st, int bufoff, int t) {
         if (st.kind == 2) {
-            if (t == 0) stage_load(st, 0);
-            if (t == 3) { stage_store(bufoff, 0); stage_load(st, 1); }
-            if (t == 6) stage_store(bufoff, 1);
+            if constexpr (F8) {
+                if (t == 0) stage8_load(st, 0);
+                if (t == 2) { stage8_store(bufoff, 0); stage8_load(st, 1); }
+                if (t == 4) { stage8_store(bufoff, 1); stage8_load(st, 2); }
+                if (t == 6) stage8_store(bufoff, 2);
+            } else {
+                if (t == 0) stage_load(st, 0);
+                if (t == 3) { stage_store(bufoff, 0); stage_load(st, 1); }
+                if (t == 6) stage_store(bufoff, 1);
+            }
         } else if (t == 6) {
             if (st.kind == 1) gen_literal(st.g, bufoff);
             else if (st.kind == 3) gen_collapsed(st.g, bufoff);
         }
     };
+    // LDS-only release / acquire around the barrier: the bare s_barrier builtin orders nothing for the compiler (a generator's last
+    // ds_write was once sunk below it), a full __syncthreads() would also wait for the weight and staging loads in flight (vmcnt)
     auto barrier = [&]() {
-        __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): this wave's LDS writes have landed, its reads returned
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");        // s_waitcnt lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     };
 
     // ---- the group sequence: tensors chunk by chunk (two half-chunk groups of 9 taps), then the disparity source
     // stage descriptor of group number `gi` (or kind 0 past the end)
-    int ngroups_t = 0;
-    for (int s = 0; s < ntens; ++s) ngroups_t += a.ch[s] >> 4;
+    int ngroups_t = 0;                     // (F8: 32-channel chunks)
+    for (int s = 0; s < ntens; ++s) ngroups_t += a.ch[s] >> (F8 ? 5 : 4);
     const int ngroups = ngroups_t + (dsrc ? (coll ? 6 : 4) : 0);
     auto describe = [&](int gi) {
         SxStage st;
@@ -288,8 +389,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
         if (gi >= ngroups) return st;
         if (gi >= ngroups_t) { st.kind = coll ? 3 : 1; st.g = gi - ngroups_t; return st; }
         int s = 0, g = gi;
-        while (g >= (a.ch[s] >> 4)) { g -= a.ch[s] >> 4; ++s; }
-        st.kind = 2; st.base = a.src[s] + g * 2048; st.mtb = (long)(a.ch[s] >> 4) * 2048;
+        while (g >= (a.ch[s] >> (F8 ? 5 : 4))) { g -= a.ch[s] >> (F8 ? 5 : 4); ++s; }
+        st.kind = 2; st.base = a.src[s] + g * (F8 ? 4096 : 2048); st.mtb = (long)(a.ch[s] >> 4) * 2048;
         return st;
     };
 
@@ -305,12 +406,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
         f.l = *reinterpret_cast<const half8*>(p + 1024);
     };
     const SxStage st0 = describe(0);
-    uint4 raw0[ITEMS];
+    uint4 raw0[F8 ? 2 * ITEMS8 : ITEMS];
     if (st0.kind == 2) {
+        if constexpr (F8) {
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const int pk = st_pk[i];
-            raw0[i] = *reinterpret_cast<const uint4*>(st0.base + (long)(pk & 0xFFFFF) * st0.mtb + (((pk >> 25) & 3) * 512 + ((pk >> 20) & 31) * 16));
+            for (int i = 0; i < ITEMS8; ++i) {
+                const char* p = stage8_addr(st0, st8_pk[i], tid + 256 * i);
+                raw0[2 * i] = *reinterpret_cast<const uint4*>(p);
+                raw0[2 * i + 1] = *reinterpret_cast<const uint4*>(p + 1024);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const int pk = st_pk[i];
+                raw0[i] = *reinterpret_cast<const uint4*>(st0.base + (long)(pk & 0xFFFFF) * st0.mtb + (((pk >> 25) & 3) * 512 + ((pk >> 20) & 31) * 16));
+            }
         }
     }
     constexpr int DITEMS = (DROWS * SX_DTW + 255) / 256;
@@ -324,8 +434,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
             dval[i] = (idx < DROWS * SX_DTW && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) ? dsrc[(long)gy * a.w + gx] : 0.f;
         }
     }
-    load_w(fw[0], 0);
-    load_w(fw[1], 1);
+    struct W8 { half8 h0, h1; union { intx8 v; uint4 q[2]; } q; };
+    W8 w8[2];                                              // F8: weights of the current and the next chunk step
+    auto load_w8 = [&](W8& f, int cstep) {                 // (clamped: the steps past the tensors are never multiplied)
+        const char* p = wlane8 + (long)min(cstep, (nsteps_t >> 1) - 1) * (2 * wstep);
+        f.h0 = *reinterpret_cast<const half8*>(p);
+        f.h1 = *reinterpret_cast<const half8*>(p + 1024);
+        f.q.q[0] = *reinterpret_cast<const uint4*>(p + 2048);
+        f.q.q[1] = *reinterpret_cast<const uint4*>(p + 3072);
+    };
+    // the steps of the disparity source follow the tensors' (same bytes per 16-channel step in both forms)
+    if (F8 && ngroups_t > 0) {
+        load_w8(w8[0], 0);
+    } else {
+        load_w(fw[0], 0);
+        load_w(fw[1], 1);
+    }
     // m-tile m of this wave: m-tile row (ty0 >> 1) + wm*MT + m, column tile_x (tiles are whole m-tiles; rows past the image's
     // last m-tile row do not exist in the tensors)
     const int mrow0 = (ty0 >> 1) + wm * MT;
@@ -352,7 +476,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
             if (tid + 256 * i < DROWS * SX_DTW) ldsD[tid + 256 * i] = dval[i];
     }
     if (st0.kind == 2) {
-        {
+        if constexpr (F8) {
+#pragma unroll
+            for (int i = 0; i < ITEMS8; ++i) stage8_put(0, st8_pk[i], tid + 256 * i, raw0[2 * i], raw0[2 * i + 1]);
+        } else {
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
                 const int pk = st_pk[i];
@@ -403,13 +530,94 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
 
     // first tap of group gi inside its buffer: tap 0 (dy = dx = 0), or the centre tap for a collapsed disparity group
     const bool first_is_centre0 = st0.kind == 3;
-    if (first_is_centre0) load_x(fx, xh[1], xl[1], SX_ROWB);
+    union F8Frag { intx8 v; uint4 q[2]; };
+    F8Frag f8[F8 ? MT : 1];                                // F8: fx.h / fx.l hold the f16 hi halves of half-chunk 0 / 1, f8 the fp8 operand
+    if (F8 && st0.kind == 2) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            fx.h[m] = *reinterpret_cast<const half8*>(sx_smem + xa[0] + (2 * m) * SX_ROWB8);
+            fx.l[m] = *reinterpret_cast<const half8*>(sx_smem + (xa[0] ^ 16) + (2 * m) * SX_ROWB8);
+            f8[m].q[0] = *reinterpret_cast<const uint4*>(sx_smem + (xa[0] ^ 64) + (2 * m) * SX_ROWB8);
+            f8[m].q[1] = *reinterpret_cast<const uint4*>(sx_smem + (xa[0] ^ 80) + (2 * m) * SX_ROWB8);
+        }
+    } else if (first_is_centre0) load_x(fx, xh[1], xl[1], SX_ROWB);
     else load_x(fx, xh[0], xl[0], 0);
 
     SX_STAMP();                                            // [1] prologue done
     int step = 0, gi = 0;                                  // gi: group of the current step; its buffer is (gi & 1) * ABUF
+    // ---- F8: the tensor sources in 32-channel chunks of 9 taps; per tap and m-tile two f16 MFMAs (xh * wh of both half-chunks) and one
+    // fp8 MFMA with K = 64 = both correction terms of both half-chunks:  [xh | xl] * 2^(-8 | 3)  against  [wl | wh] * 2^(5 | -6),
+    // the instruction's E8M0 block scale 2^3 puts the products on the accumulator's scale S.  64 + 64 matrix-pipe cycles per m-tile
+    // and 32 channels instead of 6 x 32.
+    if constexpr (F8) {
+        auto mma8_roll = [&](const W8& w, int pa, int rowoff) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h0, fx.h[m], acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h1, fx.l[m], acc[m], 0, 0, 0);
+                fx.h[m] = *reinterpret_cast<const half8*>(sx_smem + pa + (2 * m) * SX_ROWB8 + rowoff);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w.q.v, f8[m].v, acc[m], 0, 0, 0, 127, 0, 130);
+                fx.l[m] = *reinterpret_cast<const half8*>(sx_smem + (pa ^ 16) + (2 * m) * SX_ROWB8 + rowoff);
+                f8[m].q[0] = *reinterpret_cast<const uint4*>(sx_smem + (pa ^ 64) + (2 * m) * SX_ROWB8 + rowoff);
+                f8[m].q[1] = *reinterpret_cast<const uint4*>(sx_smem + (pa ^ 80) + (2 * m) * SX_ROWB8 + rowoff);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // the last tap of the last chunk rolls in the first operands of the disparity section (16-channel layout, f16 hi | lo)
+        auto mma8_last = [&](const W8& w, int ph, int pl, int rowoff) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h0, fx.h[m], acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h1, fx.l[m], acc[m], 0, 0, 0);
+                fx.h[m] = *reinterpret_cast<const half8*>(sx_smem + ph + (2 * m) * SX_ROWB + rowoff);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w.q.v, f8[m].v, acc[m], 0, 0, 0, 127, 0, 130);
+                fx.l[m] = *reinterpret_cast<const half8*>(sx_smem + pl + (2 * m) * SX_ROWB + rowoff);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // one chunk; `last` (compile time): the chunk after which the disparity section (or the epilogue) follows
+        auto chunk = [&](auto last_tag) {
+            constexpr bool last = decltype(last_tag)::value;
+            vary = (gi >> 28) * 0x11111111;
+            const SxStage nx = describe(gi + 1);
+            const int bufC = (gi & 1) * ABUF, bufN = ABUF - bufC;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (nx.kind == 2 ? (t == 0 || t == 2 || t == 4 || t == 6) : t == 6) stage_tap(nx, bufN, t);
+                if (t == 8) barrier();
+                // weights one chunk step ahead (a chunk step lasts as long as two 16-channel steps); before the last chunk's last taps
+                // the first two slices of the disparity section instead
+                W8& wc = w8[t & 1];
+                W8& wn = w8[(t + 1) & 1];
+                if (t < 8 || !last) load_w8(wn, gi * 9 + t + 1);
+                if (t == 8 && last) { load_w(fw[0], nsteps_t); load_w(fw[1], nsteps_t + 1); }     // (the free weight slot's registers)
+                __builtin_amdgcn_sched_barrier(0);
+                if (t < 8) mma8_roll(wc, (xa[(t + 1) % 3] ^ vary) + bufC, ((t + 1) / 3) * SX_ROWB8);
+                else if (!last) mma8_roll(wc, (xa[0] ^ vary) + bufN, 0);
+                else mma8_last(wc, xh[1] + bufN, xl[1] + bufN, SX_ROWB);       // (collapsed disparity group or nothing: see the launcher)
+            }
+            if (!last) {   // nine taps per chunk: the slot that holds the next step's weights becomes slot 0 again
+                const W8 tmp = w8[0]; w8[0] = w8[1]; w8[1] = tmp;
+            }
+            SX_STAMP();
+            ++gi;
+        };
+        while (gi + 1 < ngroups_t) chunk(std::false_type{});
+        if (gi < ngroups_t) chunk(std::true_type{});
+        step = nsteps_t;
+    }
     // ---- tensor half-chunks and literal disparity groups: 9 taps each
-    const int ngroups9 = ngroups_t + ((dsrc && !coll) ? 4 : 0);
+    const int ngroups9 = F8 ? 0 : ngroups_t + ((dsrc && !coll) ? 4 : 0);      // (F8: tensors in chunks above, disparity collapsed only)
     for (; gi < ngroups9; ++gi, step += 9) {
         vary = (gi >> 28) * 0x11111111;
         const SxStage nx = describe(gi + 1);
@@ -678,6 +886,7 @@ extern "C" long cer_conv3x3_s16_packed_size(int Cout, const int* ch, const int* 
         if (kind[s] == 1) { ++nd; if (ch[s] != 49) return CER_ESHAPE; }
         else if (ch[s] % 32) return CER_ESHAPE;
     }
+    collapsed &= 1;                                        // (bit 1 = fp8-correction form: same size)
     if (nd > 1 || (collapsed && nd == 0)) return CER_ESHAPE;
     return sx_steps(ch, kind, nsrc, collapsed) * (Cout / 32) * 1024;        // in halves
 }
@@ -819,9 +1028,50 @@ static void sx_pack_slice(_Float16* packed, long step, int NT, int nt, const dou
 // OIHW fp32 -> [step][ntile32][hi|lo][lane][8] halves of w * 2^(log2S - log2sx(src)); steps: tensors in source order
 // (32-channel chunk, 16-channel half, tap), then the disparity source (collapsed: 6 single-tap groups of the 81-tap filter;
 // literal: 4 groups x 9 taps of the 49 unfold channels)
+// e4m3 (OCP: bias 7, subnormals, no infinities, largest finite 448), round to nearest even, saturating
+static unsigned char sx_e4m3(double v) {
+    const unsigned sgn = v < 0 ? 0x80u : 0u;
+    double a = fabs(v);
+    if (!(a == a)) return 0x7f;
+    if (a >= 448.0) return (unsigned char)(sgn | 0x7e);
+    if (a < ldexp(1.0, -10)) return (unsigned char)sgn;    // below half the smallest subnormal (ties to even: 0)
+    int e;
+    frexp(a, &e);                                          // a = m * 2^e, m in [0.5, 1)
+    int E = e - 1;                                         // a in [2^E, 2^(E+1))
+    if (E < -6) E = -6;                                    // subnormal range: spacing 2^-9
+    const double q = nearbyint(ldexp(a, 3 - E));           // in units of 2^(E-3) (nearbyint: ties to even in the default mode)
+    int M = (int)q;                                        // 8..16 for normals, 0..8 for subnormals
+    int Eb = E + 7;
+    if (a < ldexp(1.0, -6)) { Eb = 0; if (M == 8) { Eb = 1; M = 0; } }
+    else { if (M == 16) { M = 0; ++Eb; } else M -= 8; }
+    if (Eb > 15 || (Eb == 15 && M > 6)) return (unsigned char)(sgn | 0x7e);
+    return (unsigned char)(sgn | (Eb << 3) | M);
+}
+
+// fp8-correction form of a tensor chunk step (32 channels, one tap): 4 KiB per n-tile = f16 hi halves of half-chunk 0 | of half-chunk 1
+// (each [lane][8], as in sx_pack_slice) | the A operand of v_mfma_scale_f32_32x32x64_f8f6f4, bytes 0-15 | bytes 16-31 of every lane:
+// lane (co = lane & 31, kg = lane >> 5): [wl * 2^5 (8) | wh * 2^-6 (8)] of half-chunk 0's channels 8kg..8kg+7, then the same of half-chunk 1
+static void sx_pack_chunk8(_Float16* packed, long cstep, int NT, int nt, const double* col /* [32 k][32 co] */, double scale) {
+    char* base = reinterpret_cast<char*>(packed) + (cstep * NT + nt) * 4096;
+    for (int lane = 0; lane < 64; ++lane)
+        for (int hc = 0; hc < 2; ++hc)
+            for (int e = 0; e < 8; ++e) {
+                float v = (float)(col[(hc * 16 + (lane >> 5) * 8 + e) * 32 + (lane & 31)] * scale);
+                v = v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v);
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                reinterpret_cast<_Float16*>(base + hc * 1024)[lane * 8 + e] = hi;
+                unsigned char* q = reinterpret_cast<unsigned char*>(base + 2048 + hc * 1024 + lane * 16);
+                q[e] = sx_e4m3(ldexp((double)(float)lo, 5));
+                q[8 + e] = sx_e4m3(ldexp((double)(float)hi, -6));
+            }
+}
+
 extern "C" int cer_conv3x3_s16_pack(const float* w, void* packed_v, int Cout, int Cin, const int* ch, const int* kind, const int* log2sx,
                                     int nsrc, int collapsed, int log2S) {
     if (!w || !packed_v || !ch || !kind || !log2sx) return CER_EINVAL;
+    const int fp8 = (collapsed & 2) != 0;                   // tensor sources in the fp8-correction form (CER_EPI_CORR_FP8 launches)
+    collapsed &= 1;
     if (cer_conv3x3_s16_packed_size(Cout, ch, kind, nsrc, collapsed) < 0) return CER_ESHAPE;
     int order[CER_CONV_MAX_SRC], c0[CER_CONV_MAX_SRC];
     sx_order(kind, nsrc, order);
@@ -835,7 +1085,16 @@ extern "C" int cer_conv3x3_s16_pack(const float* w, void* packed_v, int Cout, in
     for (int oi = 0; oi < nsrc; ++oi) {
         const int s = order[oi];
         const double scale = ldexp(1.0, log2S - log2sx[s]);
-        if (kind[s] != 1) {
+        if (kind[s] != 1 && fp8) {
+            double col32[32 * 32];
+            for (int c32 = 0; c32 < ch[s] / 32; ++c32)
+                for (int tap = 0; tap < 9; ++tap, step += 2)
+                    for (int nt = 0; nt < NT; ++nt) {
+                        for (int k = 0; k < 32; ++k)
+                            for (int j = 0; j < 32; ++j) col32[k * 32 + j] = w[((long)(nt * 32 + j) * Cin + c0[s] + c32 * 32 + k) * 9 + tap];
+                        sx_pack_chunk8(packed, step / 2, NT, nt, col32, scale);
+                    }
+        } else if (kind[s] != 1) {
             for (int g = 0; g < ch[s] / 16; ++g)
                 for (int tap = 0; tap < 9; ++tap, ++step)
                     for (int nt = 0; nt < NT; ++nt) {
@@ -893,10 +1152,10 @@ extern "C" int cer_delta_proj_s16_pack(const float* w2, void* packed_v, int C, i
     return CER_OK;
 }
 
-template <int WM_, int WN_, int MT>
+template <int WM_, int WN_, int MT, int F8>
 static int sx_launch(S16Args& a, int epi, hipStream_t st) {
     constexpr int TH = WM_ * 2 * MT, HR = TH + 2;
-    const size_t smem = 2 * HR * SX_ROWB + (HR + 6) * SX_DTW * 4;
+    const size_t smem = 2 * HR * (F8 ? SX_ROWB8 : SX_ROWB) + (HR + 6) * SX_DTW * 4;
     const int tiles_y = (a.h + TH - 1) / TH;
     a.tiles_x = (a.w + SX_TW - 1) / SX_TW;
     a.mtx = a.tiles_x;
@@ -905,14 +1164,39 @@ static int sx_launch(S16Args& a, int epi, hipStream_t st) {
     a.ntiles = a.tiles_x * tiles_y;
     a.ny = a.cout / (WN_ * 32);
     dim3 grid((unsigned)(a.ntiles * a.ny)), block(256);
+    if (smem > 64 * 1024) {                                // (two blocks per CU still fit: 2 x 74 KiB at most)
+        static bool raised[5] = {false, false, false, false, false};
+        const void* fn = nullptr;
+        switch (epi) {
+            case CER_EPI_LINEAR: fn = (const void*)conv3x3_s16_kernel<WM_, WN_, MT, CER_EPI_LINEAR, F8>; break;
+            case CER_EPI_RELU: fn = (const void*)conv3x3_s16_kernel<WM_, WN_, MT, CER_EPI_RELU, F8>; break;
+            case CER_EPI_GRU: fn = (const void*)conv3x3_s16_kernel<WM_, WN_, MT, CER_EPI_GRU, F8>; break;
+            default: break;
+        }
+        if constexpr (WM_ == 1) {
+            if (epi == CER_EPI_GATES) fn = (const void*)conv3x3_s16_kernel<WM_, WN_, MT, CER_EPI_GATES, F8>;
+            if (epi == SX_EPI_DELTA) fn = (const void*)conv3x3_s16_kernel<WM_, WN_, MT, SX_EPI_DELTA, F8>;
+        }
+        if (!fn || epi < 0 || epi > 4) return CER_EINVAL;
+        if (!raised[epi]) {
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return CER_EINVAL;
+            raised[epi] = true;
+        }
+    }
     switch (epi) {
-        case CER_EPI_LINEAR: hipLaunchKernelGGL((conv3x3_s16_kernel<WM_, WN_, MT, CER_EPI_LINEAR>), grid, block, smem, st, a); break;
-        case CER_EPI_RELU: hipLaunchKernelGGL((conv3x3_s16_kernel<WM_, WN_, MT, CER_EPI_RELU>), grid, block, smem, st, a); break;
-        case CER_EPI_GATES: hipLaunchKernelGGL((conv3x3_s16_kernel<WM_, WN_, MT, CER_EPI_GATES>), grid, block, smem, st, a); break;
-        case CER_EPI_GRU: hipLaunchKernelGGL((conv3x3_s16_kernel<WM_, WN_, MT, CER_EPI_GRU>), grid, block, smem, st, a); break;
+        case CER_EPI_LINEAR: hipLaunchKernelGGL((conv3x3_s16_kernel<WM_, WN_, MT, CER_EPI_LINEAR, F8>), grid, block, smem, st, a); break;
+        case CER_EPI_RELU: hipLaunchKernelGGL((conv3x3_s16_kernel<WM_, WN_, MT, CER_EPI_RELU, F8>), grid, block, smem, st, a); break;
+        case CER_EPI_GRU: hipLaunchKernelGGL((conv3x3_s16_kernel<WM_, WN_, MT, CER_EPI_GRU, F8>), grid, block, smem, st, a); break;
+        case CER_EPI_GATES:
+            if constexpr (WM_ == 1) {
+                hipLaunchKernelGGL((conv3x3_s16_kernel<WM_, WN_, MT, CER_EPI_GATES, F8>), grid, block, smem, st, a);
+                break;
+            } else {
+                return CER_ESHAPE;
+            }
         case SX_EPI_DELTA:
             if constexpr (WM_ == 1) {
-                hipLaunchKernelGGL((conv3x3_s16_kernel<WM_, WN_, MT, SX_EPI_DELTA>), grid, block, smem, st, a);
+                hipLaunchKernelGGL((conv3x3_s16_kernel<WM_, WN_, MT, SX_EPI_DELTA, F8>), grid, block, smem, st, a);
                 break;
             } else {
                 return CER_ESHAPE;
@@ -940,7 +1224,8 @@ extern "C" int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, con
     if (!in || !log2sx || !packed_w || !out || h <= 0 || w <= 0 || Cout <= 0) return CER_EINVAL;
     if (in->nsrc <= 0 || in->nsrc > CER_CONV_MAX_SRC) return CER_EINVAL;
     const int out_split = (epi & CER_EPI_OUT_SPLIT) != 0;
-    epi &= ~(CER_EPI_OUT_SPLIT | CER_EPI_AUX_SPLIT);
+    const int corr_fp8 = (epi & CER_EPI_CORR_FP8) != 0;
+    epi &= ~(CER_EPI_OUT_SPLIT | CER_EPI_AUX_SPLIT | CER_EPI_CORR_FP8);
     if (epi == CER_EPI_GATES && (!out2 || !aux || Cout != 128)) return CER_EINVAL;
     if (epi == CER_EPI_GRU && (!aux || !aux2)) return CER_EINVAL;
     if (epi == SX_EPI_DELTA && (!aux || Cout % 128 != 0)) return CER_EINVAL;
@@ -1003,15 +1288,23 @@ extern "C" int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, con
         }
         return best_mt;
     };
+    // the fp8-correction kernels evaluate a disparity source in the collapsed form with the rim correction only
+    if (corr_fp8 && nd == 1 && !(packed_collapsed && edge_w)) return CER_ESHAPE;
     if (Cout % 128 == 0) {
         int mt = tile_mt;
         if (mt != 2 && mt != 4) mt = pick(2, 2, 4, Cout / 128) == 2 ? 2 : 4;
-        return mt == 2 ? sx_launch<1, 4, 2>(a, epi, st) : sx_launch<1, 4, 4>(a, epi, st);
+        if (corr_fp8) return mt == 2 ? sx_launch<1, 4, 2, 1>(a, epi, st) : sx_launch<1, 4, 4, 1>(a, epi, st);
+        return mt == 2 ? sx_launch<1, 4, 2, 0>(a, epi, st) : sx_launch<1, 4, 4, 0>(a, epi, st);
     }
     if (epi == SX_EPI_DELTA || epi == CER_EPI_GATES) return CER_ESHAPE;
     int mt = tile_mt;
+    if (corr_fp8) {
+        // (the 32-channel chunk buffers of a 16-row tile - 2 x 46 KiB - would leave room for one block per CU: 12 rows at most)
+        if (mt < 2 || mt > 3) mt = pick(4, 2, 3, Cout / 64);
+        return mt == 2 ? sx_launch<2, 2, 2, 1>(a, epi, st) : sx_launch<2, 2, 3, 1>(a, epi, st);
+    }
     if (mt < 2 || mt > 4) mt = pick(4, 2, 4, Cout / 64);
-    return mt == 2 ? sx_launch<2, 2, 2>(a, epi, st) : mt == 3 ? sx_launch<2, 2, 3>(a, epi, st) : sx_launch<2, 2, 4>(a, epi, st);
+    return mt == 2 ? sx_launch<2, 2, 2, 0>(a, epi, st) : mt == 3 ? sx_launch<2, 2, 3, 0>(a, epi, st) : sx_launch<2, 2, 4, 0>(a, epi, st);
 }
 
 // ---- layout conversion (model load / API boundaries / tests): plain fp32 [h*w, C] <-> the m-tile-major layouts of the s16 convs.

@@ -159,7 +159,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void enc_conv_kernel(
             if (NBUF >= 3 && younger >= 1) __builtin_amdgcn_s_waitcnt(0x0F70 | DMA_PER_WAVE);
             else __builtin_amdgcn_s_waitcnt(0x0F70);
             __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");    // (the bare builtin does not order LDS accesses for the compiler)
             __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             if (step + NBUF - 1 < nsteps)
                 ec_issue_B<NB, NWAVES>(ldsB + ((step + NBUF - 1) % NBUF) * B_BYTES, wbase + (long)(step + NBUF - 1) * NT * 2048);
             const char* B = ldsB + (step % NBUF) * B_BYTES;

@@ -400,7 +400,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void conv3x3_f16x3_ke
                 if (NBUF >= 3 && younger >= 1) __builtin_amdgcn_s_waitcnt(0x0F70 | DMA_PER_WAVE);
                 else __builtin_amdgcn_s_waitcnt(0x0F70);
                 __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): this wave's LDS writes (A tile) are done
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");    // (the bare builtin does not order LDS accesses for the compiler)
                 if (!(HX_ABL & 2)) __builtin_amdgcn_s_barrier();   // all shares of B[step] + A visible; slot of B[step-1] free
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
                 HX_STAMP(1);
                 if (step + NBUF - 1 < nsteps && !(HX_ABL & 16))
                     hx_issue_B<NB, NWAVES>(ldsB + ((step + NBUF - 1) % NBUF) * B_BYTES, wbase + (long)(step + NBUF - 1) * NT * 2048);

@@ -45,7 +45,8 @@ class RAFT(nn.Module):
         self.fnet = BasicEncoder(output_dim=dim_fmap, norm_fn="instance", type=encoder_type)
         self.cnet = BasicEncoder(output_dim=dim_net + dim_inp, norm_fn="none", type=encoder_type)
         self.update_block = UpdateBlock(cascade=self.cascade, dim_net=dim_net, dim_inp=dim_inp)
-        self.update_block.conv_mode = gru_precision
+        self.update_block.conv_mode = "s16" if gru_precision == "s16f8" else gru_precision
+        self.update_block.corr_fp8 = gru_precision == "s16f8"
         self.encoder_backend = encoder_backend      # "hip": channels-last engine (csrc/enc_conv.hip); "miopen": PyTorch-ROCm convs
         self._engines = None
         self._src_buf = {}

@@ -127,7 +127,8 @@ class UpdateBlock(nn.Module):
 
     def packed(self, stage, device):
         """Packed weights for ``stage`` on ``device`` (built once, cached)."""
-        key = (stage, str(device), self.conv_mode)      # (the dict's contents depend on the arithmetic mode: s16 packs exist only for "s16")
+        f8 = bool(self.corr_fp8)
+        key = (stage, str(device), self.conv_mode, f8)  # (the dict's contents depend on the arithmetic mode: s16 packs exist only for "s16")
         if key in self._packed:
             return self._packed[key]
         cn, gn, dn = self._names(stage)
@@ -159,12 +160,12 @@ class UpdateBlock(nn.Module):
             # weights of one conv do not fit a shared scale (cer_conv3x3_s16_scale): callers of ``packed`` see that error and may
             # switch ``conv_mode`` to "f16x3" (RAFT does, with a warning).
             U, R, Dp = L.S16_UNIT, L.S16_RELU, L.S16_DISP
-            p["s_corr2"] = ops.PackedConvS16(ce[2].weight, ce[2].bias, [(64, 2, R)], device)
-            p["s_zr"] = ops.PackedConvS16(wzr[:, rest], None, [(dn_, 2, U), (49, 1, Dp), (64, 2, R)], device)
-            p["s_q"] = ops.PackedConvS16(wq[:, rest], None, [(dn_, 2, U), (49, 1, Dp), (64, 2, R)], device)
-            p["s_zr_inp"] = ops.PackedConvS16(wzr[:, s_inp], bzr, [(di, 2, R)], device)
-            p["s_q_inp"] = ops.PackedConvS16(wq[:, s_inp], bq, [(di, 2, R)], device)
-            p["s_d1"] = ops.PackedConvS16(de[0].weight, de[0].bias, [(dn_, 2, U)], device)
+            p["s_corr2"] = ops.PackedConvS16(ce[2].weight, ce[2].bias, [(64, 2, R)], device, corr_fp8=f8)
+            p["s_zr"] = ops.PackedConvS16(wzr[:, rest], None, [(dn_, 2, U), (49, 1, Dp), (64, 2, R)], device, corr_fp8=f8)
+            p["s_q"] = ops.PackedConvS16(wq[:, rest], None, [(dn_, 2, U), (49, 1, Dp), (64, 2, R)], device, corr_fp8=f8)
+            p["s_zr_inp"] = ops.PackedConvS16(wzr[:, s_inp], bzr, [(di, 2, R)], device, corr_fp8=f8)
+            p["s_q_inp"] = ops.PackedConvS16(wq[:, s_inp], bq, [(di, 2, R)], device, corr_fp8=f8)
+            p["s_d1"] = ops.PackedConvS16(de[0].weight, de[0].bias, [(dn_, 2, U)], device, corr_fp8=f8)
             p["s_d2proj"] = ops.delta_proj_pack_s16(de[2].weight, device)
         p["d2w"] = f32(de[2].weight[0].permute(1, 2, 0).reshape(9, -1))    # [tap, C]
         p["d2proj"] = ops.delta_proj_pack(de[2].weight, device)
@@ -195,6 +196,9 @@ class UpdateBlock(nn.Module):
     # with plain 16-byte copies instead of re-splitting them (staging was ~10 % of the conv time, VALU-bound).  The hidden
     # state is therefore carried at 2^-22 relative resolution (the resolution the f16x3 products see anyway).
     SPLIT_ACTS = True
+    # s16 path: the two correction terms of the split-f16 product (2^-11 of the main term) of every tensor source on the block-scaled
+    # fp8 matrix instruction (twice the f16 rate): gru_precision="s16f8".  End to end 4e-6 instead of 2e-7 relative L1 from fp32.
+    corr_fp8 = False
     CHECK_OVERFLOW = True       # s16 path: scan the ReLU-class activation tensors for saturation once per stage (ops.check_overflow reads the flag)
 
     def split_acts(self):

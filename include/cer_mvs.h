@@ -211,6 +211,9 @@ int cer_lookup_encode_f32(const float* vol, const float* origin, const float* di
  * hidden state `aux` of the GATES / GRU epilogues (reconstructed as hi + 2^-11 lo).  cer_split32_f32 converts. */
 #define CER_EPI_OUT_SPLIT 0x100
 #define CER_EPI_AUX_SPLIT 0x200
+/* cer_conv3x3_s16 only: the weights were packed with `collapsed | 2` and the two correction terms of the split-f16 product of the
+ * TENSOR sources (xh*wl + xl*wh, 2^-11 of the main term) run on the block-scaled fp8 matrix instruction (twice the f16 rate). */
+#define CER_EPI_CORR_FP8 0x400
 #define CER_EPI_DELTA 4   /* cer_conv3x3_f16x3 only - see cer_delta_proj_pack */
 
 typedef struct {

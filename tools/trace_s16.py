@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--size", default="296x400")
     ap.add_argument("--mt", type=int, default=4)
     ap.add_argument("--conv", default="zr", choices=["zr", "q"])
+    ap.add_argument("--f8", action="store_true", help="fp8-correction form (CER_EPI_CORR_FP8): stamps after every 32-channel chunk")
     args = ap.parse_args()
     h, w = (int(x) for x in args.size.split("x"))
     P = h * w
@@ -29,7 +30,7 @@ def main():
     net = ops.to_frag16(torch.tanh(rnd(P, 64, lo=-2, hi=2)).to(dev), h, w, U)
     c2 = ops.to_frag16(torch.relu(rnd(P, 64, lo=-1, hi=2)).to(dev), h, w, R)
     disp = rnd(P, lo=0.0005, hi=0.0025).to(dev)
-    pc = ops.PackedConvS16(rnd(128, 177, 3, 3, lo=-0.05, hi=0.05), None, [(64, 2, U), (49, 1, Dp), (64, 2, R)], dev)
+    pc = ops.PackedConvS16(rnd(128, 177, 3, 3, lo=-0.05, hi=0.05), None, [(64, 2, U), (49, 1, Dp), (64, 2, R)], dev, corr_fp8=args.f8)
     init = ops.s16_layout(rnd(P, 128, lo=-0.3, hi=0.3).to(dev), h, w, L.S16_ACC32)
     PP = ops.s16_pixels(h, w)
     th = 2 * args.mt * (1 if args.conv == "zr" else 2)
@@ -40,7 +41,7 @@ def main():
     if args.conv == "zr":
         run = lambda: ops.conv3x3_s16(pc, [net, disp, c2], h, w, L.EPI_GATES, out=z, out2=rn, aux=net, aux2=trace, init=init, log2s_out=U, log2s_aux=U)
     else:
-        pq = ops.PackedConvS16(rnd(64, 177, 3, 3, lo=-0.05, hi=0.05), None, [(64, 2, U), (49, 1, Dp), (64, 2, R)], dev)
+        pq = ops.PackedConvS16(rnd(64, 177, 3, 3, lo=-0.05, hi=0.05), None, [(64, 2, U), (49, 1, Dp), (64, 2, R)], dev, corr_fp8=args.f8)
         initq = ops.s16_layout(rnd(P, 64, lo=-0.3, hi=0.3).to(dev), h, w, L.S16_ACC32)
         net2 = torch.empty(PP, 64, device=dev)
         run = lambda: ops.conv3x3_s16(pq, [net, disp, c2], h, w, L.EPI_GRU, out=net2, out2=trace, aux=net, aux2=z, init=initq, log2s_out=U, log2s_aux=U)
@@ -112,8 +113,11 @@ def main():
     print("K-loop cycles/step  round 1      ", q(np.array(r1)))
     print("K-loop cycles/step  round 2 (CUs with 4 blocks)", q(np.array(r2)))
     print("K-loop cycles/step  round 2 (CUs with 3 blocks: runs alone)", q(np.array(r2lone)))
-    g = np.diff(stamps[:, 0, 1:1 + 9], axis=1)                   # the 8 tensor groups of wave 0
+    ng = 4 if args.f8 else 8
+    g = np.diff(stamps[:, 0, 1:1 + ng + 1], axis=1)             # the tensor groups (f8: 32-channel chunks) of wave 0
     print("cycles per 9-tap group, by group index (p50): ", [int(np.percentile(g[:, k][g[:, k] > 0], 50)) for k in range(g.shape[1])])
+    tail = stamps[:, 0, 1 + ng + 1] - stamps[:, 0, 1 + ng]
+    print("disparity section (6 steps)", q(tail))
 
 
 if __name__ == "__main__":
