@@ -64,9 +64,9 @@ def parse():
                          "of the multi-rank code path on a box with fewer GPUs than ranks: ranks share devices)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "amp"])
     ap.add_argument("--encoder", default="hip", choices=["hip", "miopen"], help="encoder backend: channels-last HIP engine or PyTorch-ROCm (MIOpen)")
-    ap.add_argument("--gru-precision", default="s16", choices=["s16", "f16x3", "fp32"],
-                    help="arithmetic of the update block's 3x3 convs: split-f16 MFMA with fp32-class accuracy (s16: round-2 kernels, one "
-                         "accumulator; f16x3: round-1 kernels), or exact fp32 MFMA")
+    ap.add_argument("--gru-precision", default="s16f8", choices=["s16f8", "s16", "f16x3", "fp32"],
+                    help="arithmetic of the update block's 3x3 convs: split-f16 MFMA (s16f8: correction terms on the fp8 matrix instruction, "
+                         "4e-6 from fp32; s16: all-f16, fp32-class, one accumulator; f16x3: round-1 kernels), or exact fp32 MFMA")
     return ap.parse_args()
 
 
@@ -295,8 +295,11 @@ def main():
         Vloc = V if not (shard and args.mode == "views") else (V + world - 1) // world
         C, L_, r_ = 64, 3, 5
         stages = model.stages()
-        split = args.gru_precision in ("s16", "f16x3")
-        mfma_peak = F16_MFMA_PEAK_TFLOPS / 3 if split else FP32_MFMA_PEAK_TFLOPS
+        split = args.gru_precision in ("s16f8", "s16", "f16x3")
+        mfma_peak = F16_MFMA_PEAK_TFLOPS / 3 if split else FP32_MFMA_PEAK_TFLOPS      # encoders, and the 3-term update-block convs
+        # update-block convs in the fp8-correction form: per 16-channel tap step one f16 MFMA (32 cycles) + half of one fp8 K = 64
+        # MFMA (64 cycles for two steps) = 2 f16-MFMA times of matrix-pipe occupancy per fp32 product instead of 3
+        gru_peak = F16_MFMA_PEAK_TFLOPS / 2 if args.gru_precision == "s16f8" else mfma_peak
         # ---- algorithmic work per launch, SURVEY.md 8(d) (fp32, view-mean folded):
         #   build(s): bytes 4[P C (V+1) + P] + 4 P 1.75 D_s, flops 512 V P D_s;  lookup: 284 P bytes per iteration;
         #   GRU convs: 2 * 9 * K * N * P flops with the hoisted `inp` slice and the collapsed encoder NOT credited (K = the
@@ -324,7 +327,7 @@ def main():
                     if "bytes_fused" in a_:
                         e.update(GBps_fused=a_["bytes_fused"] / sec / 1e9, frac_hbm_fused=a_["bytes_fused"] / sec / 1e9 / HBM_PEAK_GBS)
                 if "flops" in a_:
-                    pk = mfma_peak if a_["bound"] == "mfma" else FP32_MFMA_PEAK_TFLOPS
+                    pk = (gru_peak if k.startswith("conv3x3") else mfma_peak) if a_["bound"] == "mfma" else FP32_MFMA_PEAK_TFLOPS
                     e.update(alg_flops=a_["flops"], TFLOPs=a_["flops"] / sec / 1e12, frac_flops=a_["flops"] / sec / 1e12 / pk, flops_peak=pk)
                 e["bound"] = a_["bound"]
                 if "note" in a_:
@@ -367,7 +370,10 @@ def main():
         n_zr, t_zr = rec["conv3x3_gates_zr"]
         flops_zr = alg["conv3x3_gates_zr"]["flops"]
         achieved = flops_zr / (t_zr / n_zr * 1e-3) / 1e12
-        if args.gru_precision == "s16":
+        if args.gru_precision == "s16f8":
+            kname = ("conv3x3_s16_kernel<1,4,4,GATES,F8> (z|r gates, 3x3, K=177, N=128; per fp32 product one f16 MFMA + the two 2^-11 "
+                     "correction terms on the block-scaled fp8 MFMA, one accumulator)")
+        elif args.gru_precision == "s16":
             kname = "conv3x3_s16_kernel<1,4,4,GATES> (z|r gates, 3x3, K=177, N=128; 3 f16 MFMAs per fp32 product, one accumulator)"
         elif args.gru_precision == "f16x3":
             kname = "conv3x3_f16x3_kernel<4,2,1,2,3,4,GATES> (z|r gates, 3x3, K=177, N=128; 3 f16 MFMAs per fp32 product)"
@@ -377,15 +383,19 @@ def main():
         for cand in ("r02_pmc_traffic.json", "r03_pmc_traffic.json"):       # (the later file wins)
             try:
                 with open(os.path.join(REPO, "profiles", cand)) as f:
-                    traffic = json.load(f)["conv3x3_gates_zr"]["traffic_bytes"] if args.gru_precision == "s16" else None
+                    traffic = json.load(f)["conv3x3_gates_zr"]["traffic_bytes"] if args.gru_precision in ("s16", "s16f8") else None
                 traffic_src = f"profiles/{cand} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2x FETCH correction)"
             except Exception:
                 pass
-        roofline = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": mfma_peak, "unit": "TFLOP/s", "frac": achieved / mfma_peak,
+        roofline = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": gru_peak, "unit": "TFLOP/s", "frac": achieved / gru_peak,
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": 1e3 * t_zr / n_zr, "launches": n_zr,
                     "flops_per_launch": flops_zr,
-                    "peak_note": ("fp32-equivalent ceiling = 2500 TF dense f16 MFMA / 3" if split else "fp32 MFMA dense peak"),
-                    "frac_of_raw_f16_peak": (3 * achieved / F16_MFMA_PEAK_TFLOPS) if split else None}
+                    "peak_note": ("fp32-equivalent ceiling = matrix-pipe time of one f16 MFMA (2500 TF dense) + half an fp8 K=64 MFMA (5000 TF "
+                                  "dense) per 16-channel tap step = 2500 / 2; against the all-f16 form's ceiling (2500 / 3, rounds 2-3) the "
+                                  "same launch is at frac_of_three_term_ceiling" if args.gru_precision == "s16f8" else
+                                  "fp32-equivalent ceiling = 2500 TF dense f16 MFMA / 3" if split else "fp32 MFMA dense peak"),
+                    "frac_of_three_term_ceiling": (achieved / (F16_MFMA_PEAK_TFLOPS / 3)) if split else None,
+                    "frac_of_raw_f16_peak": ((2 if args.gru_precision == "s16f8" else 3) * achieved / F16_MFMA_PEAK_TFLOPS) if split else None}
         hbm = None
         if "lookup_encode_f32" in kern:
             lk = kern["lookup_encode_f32"]
@@ -399,7 +409,7 @@ def main():
         inner = {"ms_per_depth_map": loop_ms, "us_per_iteration": 1e3 * loop_ms / iters,
                  "alg_bytes_per_iteration": (284.0 + 908.0) * P, "alg_flops_per_iteration": 1210368.0 * P,
                  "frac_hbm": (284.0 + 908.0) * P * iters / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "frac_mfma": 1210368.0 * P * iters / (loop_ms * 1e-3) / 1e12 / mfma_peak,
+                 "frac_mfma": 1210368.0 * P * iters / (loop_ms * 1e-3) / 1e12 / gru_peak,
                  "note": "correlation + GRU inner loop against both rooflines with SURVEY.md 8(d)'s unreduced per-iteration figures "
                          "(1.21 MFLOP and 1192 B per pixel): the loop is MFMA-bound, not HBM-bound (SURVEY.md 7, hard part 1)"}
         result = {
@@ -408,7 +418,10 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong" if (shard or world == 1) else "weak", "vs_baseline": None,
             "dtype": ("f32" if args.precision == "fp32" else "f32 (encoders f16 autocast)")
-                     + (" [dense convs: f32 operands split into 2 x f16, 3 MFMAs per product, f32 accumulate - fp32-class]" if split else ""),
+                     + (" [dense convs: f32 operands split into 2 x f16, f32 accumulate; encoders 3 f16 MFMAs per product (fp32-class), "
+                        "update-block convs f16 main term + the two 2^-11 correction terms in e4m3 on the fp8 MFMA: 4e-6 relative L1 from fp32 "
+                        "end to end, bar 1e-4]" if args.gru_precision == "s16f8" else
+                        " [dense convs: f32 operands split into 2 x f16, 3 MFMAs per product, f32 accumulate - fp32-class]" if split else ""),
             "data": "synthetic",
             "config": {"workload": args.workload, "image": f"{W}x{H}", "src_views": V, "cascade": cascade,
                        "gru_iters": sum(c[2] for c in cascade),

@@ -10,8 +10,10 @@ reference that a caller can observe, all deliberate (SURVEY.md §8(a) "quirks"):
   * computation is fp32 end to end by default (``precision="fp32"``); the reference's GPU path runs
     encoders + GRU under fp16 autocast (raft.py:9,55), selectable with ``precision="amp"`` for the
     encoders only.  ``gru_precision`` picks the arithmetic of the update block's 3x3 convolutions:
-    "s16" (default: split-f16 MFMA into one fp32 accumulator, fp32-class accuracy, the barrier-light kernels of
-    csrc/conv_s16.hip), "f16x3" (round-1 kernels: two fp32 accumulators) or "fp32" (exact v_mfma_f32_16x16x4_f32).
+    "s16f8" (default: split-f16 operands, x*w = xh*wh + (xh*wl + xl*wh) into one fp32 accumulator with the main term on the f16
+    matrix instruction and the two 2^-11 correction terms on the block-scaled fp8 one - 4e-6 relative L1 from fp32 end to end,
+    csrc/conv_s16.hip), "s16" (all three terms in f16: fp32-class, 2e-7), "f16x3" (round-1 kernels: two fp32 accumulators) or
+    "fp32" (exact v_mfma_f32_16x16x4_f32).
 Multi-GPU: ``view_group`` = a torch.distributed process group (one rank per GPU, RCCL over xGMI).  ``shard="slab"``
 (default): source views are sharded for the encoders (all-gather of the feature maps), image rows are sharded for the cost
 volume and the GRU loop with a 7-row halo exchange per iteration (slab.py) - strong scaling of one depth map;
@@ -33,7 +35,7 @@ _SIDE_STREAMS = {}
 
 class RAFT(nn.Module):
     def __init__(self, cascade=[(64, 64, 8), (-1, 320, 8)], encoder_type="HR", dim_fmap=64, dim_net=64, dim_inp=64,
-                 test_mode=False, precision="fp32", view_group=None, gru_precision="s16", encoder_backend="hip", shard="slab"):
+                 test_mode=False, precision="fp32", view_group=None, gru_precision="s16f8", encoder_backend="hip", shard="slab"):
         super().__init__()
         self.cascade = [tuple(c) for c in cascade]
         self.encoder_type = encoder_type

@@ -737,7 +737,7 @@ def test_large_configs_run(dev):
 
 
 # ------------------------------------------------------------------------------------ end to end
-def _run_e2e(dev, golden, name, literal=False, gru_precision="s16"):
+def _run_e2e(dev, golden, name, literal=False, gru_precision="s16f8"):
     from cer_mvs_amd import RAFT
     from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene, tensor_checksum
     g = golden(name)
@@ -774,7 +774,7 @@ def test_end_to_end_tiny_literal_api(dev, golden):
     assert e_disp < TOL and e_depth < TOL
 
 
-@pytest.mark.parametrize("gru_precision", ["s16", "f16x3", "fp32"])
+@pytest.mark.parametrize("gru_precision", ["s16f8", "s16", "f16x3", "fp32"])
 def test_end_to_end_cfg1(dev, golden, gru_precision):
     """BASELINE.json configs[0] shape: 640x480, 1 ref + 2 src views, 4 GRU iterations."""
     e_disp, e_depth = _run_e2e(dev, golden, "e2e_cfg1", gru_precision=gru_precision)
@@ -900,7 +900,7 @@ def test_slab_forward_over_rccl_single_rank(dev, golden):
     assert rel_l1(out.cpu(), torch.from_numpy(g["disp"])) < TOL
 
 
-@pytest.mark.parametrize("gru_precision", ["s16", "f16x3", "fp32"])
+@pytest.mark.parametrize("gru_precision", ["s16f8", "s16", "f16x3", "fp32"])
 def test_odd_image_size_vs_oracle(dev, gru_precision):
     """h1, w1 not multiples of the 8x16 conv tile, V = 1; every arithmetic mode of the update block."""
     from cer_mvs_amd import RAFT
