@@ -383,7 +383,9 @@ def main():
         for cand in ("r02_pmc_traffic.json", "r03_pmc_traffic.json"):       # (the later file wins)
             try:
                 with open(os.path.join(REPO, "profiles", cand)) as f:
-                    traffic = json.load(f)["conv3x3_gates_zr"]["traffic_bytes"] if args.gru_precision in ("s16", "s16f8") else None
+                    pm_ = json.load(f)
+                    traffic = (pm_["conv3x3_gates_zr_f8"]["traffic_bytes"] if args.gru_precision == "s16f8" else
+                               pm_["conv3x3_gates_zr"]["traffic_bytes"] if args.gru_precision == "s16" else None)
                 traffic_src = f"profiles/{cand} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2x FETCH correction)"
             except Exception:
                 pass

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--json", default="")
     ap.add_argument("--no-init", action="store_true", help="experiment: run the gate / GRU convs without the hoisted init term")
+    ap.add_argument("--f8", action="store_true", help="the s16 side in the fp8-correction form (CER_EPI_CORR_FP8: gru_precision='s16f8')")
     args = ap.parse_args()
     h, w = (int(x) for x in args.size.split("x"))
     P = h * w
@@ -39,8 +40,9 @@ def main():
     w2 = rnd(1, 256, 3, 3, lo=-0.05, hi=0.05)
     initzr, initq = rnd(P, 128, lo=-0.3, hi=0.3).to(dev), rnd(P, 64, lo=-0.3, hi=0.3).to(dev)
     src_s = [(64, 2, U), (49, 1, Dp), (64, 2, R)]
-    s = {"corr2": ops.PackedConvS16(wc, bc, [(64, 2, R)], dev), "zr": ops.PackedConvS16(wzr, None, src_s, dev),
-         "q": ops.PackedConvS16(wq, None, src_s, dev), "d1": ops.PackedConvS16(w1, b1, [(64, 2, U)], dev)}
+    f8 = args.f8
+    s = {"corr2": ops.PackedConvS16(wc, bc, [(64, 2, R)], dev, corr_fp8=f8), "zr": ops.PackedConvS16(wzr, None, src_s, dev, corr_fp8=f8),
+         "q": ops.PackedConvS16(wq, None, src_s, dev, corr_fp8=f8), "d1": ops.PackedConvS16(w1, b1, [(64, 2, U)], dev, corr_fp8=f8)}
     proj_s = ops.delta_proj_pack_s16(w2, dev)
     src_o = [(64, 0), (49, 1), (64, 0)]
     o = {"corr2": ops.PackedConv3x3(wc, bc, [(64, 0)], dev), "zr": ops.PackedConv3x3(wzr, None, src_o, dev),
