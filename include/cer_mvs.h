@@ -277,7 +277,11 @@ int cer_conv3x3_f16x3(const cer_conv_inputs* in, const void* packed_w, const voi
  * input-channel order; the packing reorders steps itself (tensors first, disparity last).
  * cer_conv3x3_s16_scale returns log2S for a weight tensor (< -1000 on error); cer_conv3x3_s16_pack builds the literal
  * (collapsed = 0) or collapsed (= 1, needs a kind-1 source; used by interior tiles) packing, size in 2-byte halves from
- * cer_conv3x3_s16_packed_size.  HOST pointers.
+ * cer_conv3x3_s16_packed_size.  HOST pointers.  `collapsed | 2`: the tensor sources' steps in the fp8-correction form (for launches
+ * with CER_EPI_CORR_FP8: per 32-channel tap and 32 output channels 4 KiB = f16 hi halves of the two 16-channel halves | the e4m3
+ * A operand of v_mfma_scale_f32_32x32x64_f8f6f4: [lo * 2^5 | hi * 2^-6] of each half); same size.  A launch with CER_EPI_CORR_FP8
+ * and a kind-1 source needs packed_collapsed AND edge_w (the fp8 kernels evaluate the disparity source in the collapsed form with
+ * the rim correction only; CER_ESHAPE otherwise); tile_mt = 4 is not available for Cout = 64 in that form (3 is used).
  * cer_conv3x3_s16: bias (fp32 [Cout], plain) or init (acc32 [., Cout]) - at most one - seed the accumulators; epilogues:
  *   LINEAR: out acc32 [., Cout];  with CER_EPI_OUT_SPLIT or'ed in, and RELU always: out frag16 with scale 2^log2s_out;
  *   GATES (Cout = 128): out = z f32x8 [., 64], out2 = r * h frag16 (2^log2s_out), aux = h frag16 (2^log2s_aux);
