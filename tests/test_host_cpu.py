@@ -366,3 +366,40 @@ def test_s16_shared_scale_bounds():
     assert lib.cer_conv3x3_s16_scale(w4.ctypes.data, 64, 64, ch, kind, sx, 2) == k
     # channel counts must add up to Cin
     assert lib.cer_conv3x3_s16_scale(w.ctypes.data, 64, 64, I3(32, 16), kind, sx, 2) < -1000
+
+
+def test_fp8_correction_weight_packing():
+    """cer_conv3x3_s16_pack(collapsed | 2) (host): per (32-channel tap step, 32 output channels) 4 KiB = f16 hi halves of both
+    16-channel halves, then the e4m3 A operand of the fp8 matrix instruction: [lo * 2^5 | hi * 2^-6] per half, bytes 0-15 and 16-31
+    of every lane 1 KiB apart.  The library's e4m3 encoder must agree with torch's (round to nearest even, subnormals)."""
+    from importlib import import_module
+    lib = import_module("cer-mvs_amd._lib").load()
+    I1 = ctypes.c_int * 1
+    ch, kind, sx = I1(64), I1(2), I1(14)
+    Cout, Cin = 64, 64
+    g = torch.Generator().manual_seed(11)
+    w = (torch.rand(Cout, Cin, 3, 3, generator=g) - 0.5) * torch.logspace(-4, 0, Cin).view(1, Cin, 1, 1)     # small and large weights
+    w = w.contiguous()
+    log2S = lib.cer_conv3x3_s16_scale(ctypes.c_void_p(w.data_ptr()), Cout, Cin, ch, kind, sx, 1)
+    assert log2S > -1000
+    size = lib.cer_conv3x3_s16_packed_size(Cout, ch, kind, 1, 2)
+    assert size == lib.cer_conv3x3_s16_packed_size(Cout, ch, kind, 1, 0) == 2 * 9 * 2 * 2048
+    packed = torch.zeros(size, dtype=torch.float16)
+    assert lib.cer_conv3x3_s16_pack(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(packed.data_ptr()), Cout, Cin, ch, kind, sx, 1, 2, log2S) == 0
+    raw = packed.view(torch.uint8).reshape(2 * 9, 2, 4, 64, 16)                  # [chunk step][n-tile][h0 | h1 | q0 | q1][lane][16 B]
+    ws = (w.double() * 2.0 ** (log2S - 14)).float()
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+    lane = torch.arange(64)
+    co, kg = lane & 31, lane >> 5
+    for c32, tap, nt in ((0, 0, 0), (1, 4, 1), (1, 8, 0), (0, 7, 1)):
+        blk = raw[c32 * 9 + tap, nt]
+        for hc in range(2):
+            cin = c32 * 32 + hc * 16 + kg[:, None] * 8 + torch.arange(8)[None, :]                  # [lane, e]
+            cout = (nt * 32 + co)[:, None].expand(64, 8)
+            h_ref = hi[cout, cin, tap // 3, tap % 3]
+            l_ref = lo[cout, cin, tap // 3, tap % 3]
+            assert torch.equal(blk[hc].contiguous().view(torch.float16).reshape(64, 8), h_ref)
+            q = blk[2 + hc]                                                                             # [lane][16]: wl * 2^5 | wh * 2^-6
+            assert torch.equal(q[:, :8], (l_ref.float() * 32).to(torch.float8_e4m3fn).view(torch.uint8))
+            assert torch.equal(q[:, 8:], (h_ref.float() / 64).to(torch.float8_e4m3fn).view(torch.uint8))
