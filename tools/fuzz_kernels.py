@@ -65,6 +65,39 @@ def main():
             else:
                 out = ops.conv3x3(pc, srcs, h, w, epi, init=to_l(init))
                 note("conv_relu", rel(out, torch.relu(ref)[0].permute(1, 2, 0).reshape(P, 64)), 5e-6, (h, w))
+        # ---- the same convs on the default kernels (csrc/conv_s16.hip) in both arithmetic forms: all three terms in f16, and the
+        # correction terms on the fp8 matrix instruction (gru_precision="s16f8"); tile height chosen at random
+        U, R, Dp = L.S16_UNIT, L.S16_RELU, L.S16_DISP
+        fr = lambda t, k: ops.to_frag16(to_l(t), h, w, k)
+        unf = lambda t, k: ops.from_frag16(t, h, w, k)
+        for f8 in (False, True):
+            bar = 5e-5 if f8 else 5e-6
+            tag = "f8" if f8 else "s16"
+            ops.TILE_MT = [0, 2, 3, 4][ri(0, 3)]
+            try:
+                for cout, epi in ((128, L.EPI_GATES), (64, L.EPI_GRU), (64, L.EPI_RELU)):
+                    wt = rn(cout, 177, 3, 3) * 0.04
+                    init = rn(1, cout, h, w) * 0.3
+                    ref = F.conv2d(torch.cat([net, feat, c2], 1).double(), wt.double(), None, padding=1) + init.double()
+                    pc = ops.PackedConvS16(wt, None, [(64, 2, U), (49, 1, Dp), (64, 2, R)], dev, corr_fp8=f8)
+                    srcs = [fr(net, U), disp.reshape(-1).to(dev), fr(c2, R)]
+                    ini = ops.s16_layout(to_l(init), h, w, L.S16_ACC32)
+                    if epi == L.EPI_GATES:
+                        z, rh = ops.conv3x3_s16(pc, srcs, h, w, epi, aux=srcs[0], init=ini, log2s_out=U, log2s_aux=U)
+                        sg = torch.sigmoid(ref)
+                        note(f"{tag}_gates_z", rel(ops.s16_layout(z, h, w, L.S16_F32X8, inverse=True), sg[0, :64].permute(1, 2, 0).reshape(P, 64)), bar, (h, w))
+                        note(f"{tag}_gates_rh", rel(unf(rh, U), (sg[0, 64:] * net[0].double()).permute(1, 2, 0).reshape(P, 64)), bar, (h, w))
+                    elif epi == L.EPI_GRU:
+                        zz = torch.sigmoid(rn(1, 64, h, w))
+                        out = ops.conv3x3_s16(pc, srcs, h, w, epi, aux=srcs[0], aux2=ops.s16_layout(to_l(zz), h, w, L.S16_F32X8), init=ini,
+                                              log2s_out=U, log2s_aux=U)
+                        exp = (1 - zz.double()) * net.double() + zz.double() * torch.tanh(ref)
+                        note(f"{tag}_gru", rel(unf(out, U), exp[0].permute(1, 2, 0).reshape(P, 64)), bar, (h, w))
+                    else:
+                        out = ops.conv3x3_s16(pc, srcs, h, w, epi, init=ini, log2s_out=R)
+                        note(f"{tag}_relu", rel(unf(out, R), torch.relu(ref)[0].permute(1, 2, 0).reshape(P, 64)), bar, (h, w))
+            finally:
+                ops.TILE_MT = 0
         # ---- cost volume + fused pyramid + lookup against the C oracle path (torch oracle)
         h1, w1, V, D = ri(2, 14), ri(2, 22), ri(1, 4), [64, 44, 20, 8][ri(0, 3)]
         fm = rn(V + 1, 64, h1, w1)
