@@ -56,8 +56,8 @@ def parse():
     ap.add_argument("--mode", default="both", choices=["both", "shard", "views", "replica"],
                     help="N > 1: both = time the view-shard scheme (north_star's) AND the row-slab scheme, headline = row-slab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="independent depth maps kept in flight per GPU (cer-mvs_amd/pipeline.py: the product's inference() default is 2); "
+    ap.add_argument("--streams", type=int, default=3,
+                    help="independent depth maps kept in flight per GPU (cer-mvs_amd/pipeline.py: the product's inference() default is 3); "
                          "1 = one at a time.  Sharded N > 1 modes always run one depth map at a time")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1: nccl (= RCCL over xGMI, the product path) or gloo (validation "

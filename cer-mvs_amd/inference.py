@@ -64,7 +64,7 @@ def write_pfm(file, image, scale=1):
 
 
 def inference(test_loader, ckpt, output_folder, rescale=1, crop=None, do_report=False, write_min_depth=None,
-              model=None, num_frames=None, streams=2):
+              model=None, num_frames=None, streams=3):
     """Reference signature (inference.py:19-27) plus ``model`` (pre-built RAFT), ``num_frames`` (the reference reads
     test_loader.dataset.num_frames for the file name) and ``streams``: reference views kept in flight on the GPU
     (pipeline.DepthMapPipeline: 2 = +14 % depth maps per second at DTU size; 1 = the reference's one-at-a-time loop;
