@@ -50,7 +50,7 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="dtu_1600x1184_v10_it32", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="both", choices=["both", "shard", "views", "replica"],
