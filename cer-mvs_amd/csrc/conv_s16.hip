@@ -46,11 +46,9 @@ typedef int intx8 __attribute__((ext_vector_type(8)));
 #define SX_DTW 24                          // disparity tile columns (halo + 3 each side)
 #define SX_EPI_DELTA 4
 #define SX_HID_LOG2 4                      // scale of the delta head's hidden activations (relu outputs)
-// Wait states behind the 16-byte LDS stores of the disparity generators: hipcc (ROCm 7.2) schedules VALU writes to a store's data
-// registers directly behind ds_write_b128, and with LDS reads queued in front of the store its last lanes (48-63) then picked up the
-// new value in one generator variant (gen_collapsed below has the measurement).  The statement only spaces the code out - the compiler
-// may still move arithmetic between a store and the asm; tools/check_lds_store_hazard.py lists what is left in the generated code (the
-// staging stores among them: never seen to fail in 7e7 blocks, left as they are).
+// Wait states (and a compiler memory barrier) behind the 16-byte LDS stores of the disparity generators: an EMPIRICAL margin.  One
+// generator variant produced intermittently wrong last tile rows and became clean with them; the cause was not identified (DESIGN.md 3g:
+// two candidate hardware hazards were excluded by micro-tests).  The form that ships never failed with or without them.
 #define SX_LDS_STORE_WAIT() asm volatile("s_nop 3" ::: "memory")
 #ifndef SX_TRACE
 #define SX_TRACE 0   // variant builds only (tools/trace_s16.py): per wave cycle stamps + HW_ID written to `aux2` (GATES: unused there)
@@ -329,11 +327,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
     // collapsed disparity features, group g: channel s = (sy, sx) of the 9x9 window holds 100 * (d[p + s - 4] - d[p]); only the
     // tile's own pixels (the centre tap) are read
     // (Waves 0 and 1 generate, as in round 2.  Spreading the two channel halves over the wave pairs - waves 0, 1: channels 0-7,
-    // waves 2, 3: channels 8-15, a wave-uniform branch - produced intermittently wrong LAST tile rows (lanes 48-63 of the stores) on
-    // the MI355X in 74-99 % of the launches; with `s_nop 3` behind each ds_write_b128 of the generator: 0 of 400.  hipcc had placed a
-    // VALU write to the store's first data register directly behind the store; the same pattern exists elsewhere in the library
-    // (tools/check_lds_store_hazard.py lists the sites) without ever failing, so the trigger also needs LDS traffic queued in front of
-    // the store - here the eight fragment reads of the multiply step just issued.  This form: 0 of 1 600 launches.)
+    // waves 2, 3: channels 8-15, a wave-uniform branch - produced intermittently wrong LAST tile rows on the MI355X in 74-99 % of the
+    // launches, 0 of 400 with `s_nop 3` behind the generator's stores; cause not identified, DESIGN.md 3g.  This form: 0 of 1 600.)
     auto gen_collapsed = [&](int g, int bufoff) {
         // one half unit = (pixel, 8 of the group's 16 channels): the window offsets are compile-time constants and fold into the
         // ds_read offsets (the section was bound by the generators' address arithmetic: 11.0 k -> 7.3 k cycles for its six steps)
