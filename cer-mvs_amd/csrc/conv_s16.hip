@@ -69,6 +69,7 @@ struct S16Args {
     const float* aux2;
     const void* edge;                      // rim-correction filters of the collapsed disparity form (cer_conv3x3_s16_edge_pack) or null
     int h, w, cout, tiles_x, ntiles, ny, mtx, mty;
+    int border_first;                      // tiles on the image rim are given to the first blocks launched (see the kernel)
     float S, invS;                         // accumulator = S * conv
     float out_scale;                       // frag16 outputs
     float aux_inv;                         // 1 / scale of the frag16 hidden state read by GATES / GRU
@@ -132,13 +133,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
 
     // ---- block -> (tile, channel block): consecutive virtual ids stay on one XCD (blocks are dealt round-robin over the 8
     // XCDs), so neighbouring tiles - which share halo lines - and the channel blocks of one tile meet in the same L2
-    int vid;
-    {
-        const int nblk = gridDim.x, bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
-        vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    auto xcd_order = [](int n, int j) {                    // j-th block of n (dealt round-robin) -> virtual id, contiguous per XCD
+        const int q = n >> 3, r = n & 7, xcd = j & 7, k = j >> 3;
+        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    };
+    int tile, by;
+    int tile_y, tile_x;
+    if (a.border_first) {
+        // convs with a disparity source: tiles on the image rim run the rim correction (left / right column + 24 % block life, top / bottom row
+        // + 5 %), and in row-major order the slowest tiles of the last rows were the launch's tail.  Rim tiles go to the FIRST blocks launched
+        // (columns, then rows; spread over the XCDs by the launch order itself), the interior follows in the XCD-contiguous order.  (ny = 1)
+        const int bid = blockIdx.x, tys = a.ntiles / a.tiles_x, nbord = 2 * tys + 2 * (a.tiles_x - 2);
+        if (bid < 2 * tys) {
+            tile_y = bid >> 1; tile_x = (bid & 1) ? a.tiles_x - 1 : 0;
+        } else if (bid < nbord) {
+            const int r2 = bid - 2 * tys;
+            tile_y = (r2 & 1) ? tys - 1 : 0; tile_x = 1 + (r2 >> 1);
+        } else {
+            const int i = xcd_order(a.ntiles - nbord, bid - nbord);
+            tile_y = 1 + i / (a.tiles_x - 2); tile_x = 1 + i - (tile_y - 1) * (a.tiles_x - 2);
+        }
+        tile = tile_y * a.tiles_x + tile_x;
+        by = 0;
+    } else {
+        const int vid = xcd_order((int)gridDim.x, (int)blockIdx.x);
+        tile = vid / a.ny; by = vid - tile * a.ny;
+        tile_y = tile / a.tiles_x; tile_x = tile - tile_y * a.tiles_x;
     }
-    const int tile = vid / a.ny, by = vid - tile * a.ny;
-    const int tile_y = tile / a.tiles_x, tile_x = tile - tile_y * a.tiles_x;
     const int ty0 = tile_y * TH, tx0 = tile_x * SX_TW;
     const int nb0 = by * NB;
     const int NT = a.cout >> 5;
@@ -1172,6 +1193,7 @@ static int sx_launch(S16Args& a, int epi, hipStream_t st) {
     if ((long)a.mtx * a.mty >= (1L << 20)) return CER_ESHAPE;
     a.ntiles = a.tiles_x * tiles_y;
     a.ny = a.cout / (WN_ * 32);
+    a.border_first = a.edge && a.wpk_c && a.nsrc > 0 && a.kind[a.nsrc - 1] == 1 && a.ny == 1 && a.tiles_x >= 3 && tiles_y >= 3;
     dim3 grid((unsigned)(a.ntiles * a.ny)), block(256);
     if (smem > 64 * 1024) {                                // (two blocks per CU still fit: 2 x 74 KiB at most)
         static bool raised[5] = {false, false, false, false, false};

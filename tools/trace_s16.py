@@ -113,6 +113,27 @@ def main():
     print("K-loop cycles/step  round 1      ", q(np.array(r1)))
     print("K-loop cycles/step  round 2 (CUs with 4 blocks)", q(np.array(r2)))
     print("K-loop cycles/step  round 2 (CUs with 3 blocks: runs alone)", q(np.array(r2lone)))
+    # lifetimes by tile position (border tiles run the rim correction) and by launch order
+    if args.conv == "zr":
+        tx = (w + 15) // 16
+        ty = (h + th - 1) // th
+        bid = np.arange(nblk)
+
+        def xcd_order(n, j):
+            qq, rr, xcd_b, kk = n >> 3, n & 7, j & 7, j >> 3
+            return np.where(xcd_b < rr, xcd_b * (qq + 1), rr * (qq + 1) + (xcd_b - rr) * qq) + kk
+        # the kernel's block -> tile map for convs with a disparity source: rim tiles first (columns, then rows), interior in XCD order
+        nbord = 2 * ty + 2 * (tx - 2)
+        i_int = xcd_order(nblk - nbord, np.maximum(bid - nbord, 0))
+        r2 = bid - 2 * ty
+        tyi = np.where(bid < 2 * ty, bid >> 1, np.where(bid < nbord, np.where(r2 & 1, ty - 1, 0), 1 + i_int // (tx - 2)))
+        txi = np.where(bid < 2 * ty, np.where(bid & 1, tx - 1, 0), np.where(bid < nbord, 1 + (r2 >> 1), 1 + i_int % (tx - 2)))
+        lf = life[:, 0]
+        started = t0[:, 0]
+        for name, m in (("top row", tyi == 0), ("bottom row", tyi == ty - 1), ("left / right column", ((txi == 0) | (txi == tx - 1)) & (tyi > 0) & (tyi < ty - 1)),
+                        ("interior", (tyi > 0) & (tyi < ty - 1) & (txi > 0) & (txi < tx - 1))):
+            print(f"   {name:22s} {int(m.sum()):4d} blocks: life p50 {np.percentile(lf[m], 50):.0f} p90 {np.percentile(lf[m], 90):.0f}; start p50 {np.percentile(started[m], 50):.0f}")
+        print(f"   last finishing blocks (tile rows): {sorted(tyi[np.argsort(t_exit[:, 0])[-12:]].tolist())}")
     ng = 4 if args.f8 else 8
     g = np.diff(stamps[:, 0, 1:1 + ng + 1], axis=1)             # the tensor groups (f8: 32-channel chunks) of wave 0
     print("cycles per 9-tap group, by group index (p50): ", [int(np.percentile(g[:, k][g[:, k] > 0], 50)) for k in range(g.shape[1])])
