@@ -67,7 +67,7 @@ def inference(test_loader, ckpt, output_folder, rescale=1, crop=None, do_report=
               model=None, num_frames=None, streams=3):
     """Reference signature (inference.py:19-27) plus ``model`` (pre-built RAFT), ``num_frames`` (the reference reads
     test_loader.dataset.num_frames for the file name) and ``streams``: reference views kept in flight on the GPU
-    (pipeline.DepthMapPipeline: 2 = +14 % depth maps per second at DTU size; 1 = the reference's one-at-a-time loop;
+    (pipeline.DepthMapPipeline: 3 = +12-16 % depth maps per second at DTU size; 1 = the reference's one-at-a-time loop;
     ``do_report`` forces 1 so that the per-view time it prints means what it says).  Same files either way."""
     if model is None:
         model = RAFT(test_mode=True).cuda()
