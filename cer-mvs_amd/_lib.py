@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CER_MVS_LIB") or os.path.join(_HERE, "csrc", "libcermvs.so")
-ABI_VERSION = 1032
+ABI_VERSION = 1040
 CONV_MAX_SRC = 4
 EPI_LINEAR, EPI_RELU, EPI_GATES, EPI_GRU, EPI_DELTA = 0, 1, 2, 3, 4
 EPI_OUT_SPLIT, EPI_AUX_SPLIT = 0x100, 0x200       # cer_mvs.h: split32 activation layout flags, or-ed into `epi`
@@ -83,6 +83,9 @@ _SIGNATURES = {
     "cer_enc_conv_f16x3": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "cer_enc_stats_reduce_f32": (_I, [_P, _P, _I, _I, _I, _L, _F, _P]),
     "cer_enc_merge_f32": (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _P]),
+    "cer_enc_pc_supported": (_I, [_I, _I, _I, _I, _I]),
+    "cer_enc_pc_tiles": (_I, [_I, _I, _I, _I, _I]),
+    "cer_enc_pc_conv": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "cer_plane_stats_f32": (_I, [_P, _P, _L, _L, _F, _P]),
     "cer_norm_act_f32": (_I, [_P, _P, _P, _P, _P, _L, _L, _I, _P]),
     "cer_nchw_to_nhwc_f32": (_I, [_P, _P, _I, _L, _F, _P]),

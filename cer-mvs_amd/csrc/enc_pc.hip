@@ -1,0 +1,601 @@
+// Encoder convolutions, round 4: producer / consumer wave specialisation (reference: core/extractor.py:49-57,143-155).
+//
+// The round-2/3 kernels (enc_conv.hip) run every phase of a tile in every wave - load the halo, normalise + ReLU + split to
+// hi|lo f16, write LDS, barrier, MFMAs, barrier, epilogue - and by their own cycle trace spend 30 % of a block's life preparing
+// operands (pure VALU), 34 % in the matrix phase and the rest in epilogue / waits / barriers: the phases ADD.  Here a 512-thread
+// block (one per CU, persistent) is split by role:
+//   * waves 0-3, PRODUCERS: fetch the next unit's halo (one unit = one tile x one 32-channel chunk) into registers, apply the
+//     producer layer's instance norm + ReLU - or form the residual merge relu(fa(A) + fb(B)) of TWO tensors on the fly, which
+//     removes enc_merge_kernel as a pass - split to hi|lo f16 and write one of two LDS buffers; optionally the merged activation
+//     is written back once (core pixels only) for the residual branch that needs it later;
+//   * waves 4-7, CONSUMERS: fragments by ds_read_b128, weights resident in registers (<= 18 k16-steps) or streamed from L2 two
+//     steps ahead, 3 f16 MFMAs per product term set (x*w = xh*wh + 2^-11 (xh*wl' + xl'*wh), two fp32 accumulators - the
+//     arithmetic of enc_conv.hip, bit for bit), epilogue straight from the accumulators (a lane owns one output channel of 16
+//     pixels: 128-byte contiguous dword stores per half wave, per-lane statistics without any shuffle).
+// One s_barrier per unit couples the two groups: the producers are always one unit ahead (buffer k+1 is filled while buffer k
+// is multiplied), so the vector work of operand preparation runs UNDER the matrix work of the same SIMD instead of in front of it
+// (MI355X_MICROARCH.md: the MFMA and VALU pipes of a SIMD run concurrently for two different waves).
+// Happens-before for the LDS buffers (unit k lives in buffer k & 1; barrier #k is the k-th s_barrier every wave executes):
+//   producer: commit(k) -> lgkmcnt(0) -> barrier #k           consumer: barrier #k -> ds_reads of unit k -> (MFMAs wait for them)
+//   buffer k & 1 is rewritten by commit(k + 2), which the producers start after barrier #k+1; a consumer arrives at barrier
+//   #k+1 only after every fragment of unit k has landed in its registers (each MFMA waits for its operands), so no ds_read of
+//   unit k is outstanding when the first ds_write of unit k + 2 issues.
+// Statistics partials: consumers leave [row group][channel] (sum, sum of squares) in a double-buffered LDS patch; producer wave 0
+// adds the row groups in fixed order after the next barrier and writes the tile's record: deterministic, one record per tile
+// whatever block processed it (batch invariance, tests/test_hip_parity.py::test_encoder_engine_batch_invariance_at_tnt_size).
+#include "common.hpp"
+#include <string.h>
+#include <type_traits>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#ifndef PC_TRACE
+#define PC_TRACE 0                     // debug build: per-wave phase cycle sums written to a.out2 [blocks][8 waves][8] (u64); tools/trace_pc.py
+#endif
+#if PC_TRACE
+#define PC_T(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tsum[k] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define PC_T(k) do { } while (0)
+#endif
+#define PC_AS 144                      // LDS bytes per halo pixel and 32-channel chunk: 32 hi | 32 lo | 16 pad (conflict-free ds_read_b128)
+#define PC_EPI_RAW 0
+#define PC_EPI_FMAP 1
+#define PC_EPI_CTX 2
+
+struct PcArgs {
+    const float* srcA;                 // [N, h*w, CIN] channels-last
+    const float* tfA;                  // statistics [N*CIN][2] (mean, rstd) or NULL
+    const float* srcB;                 // second tensor of a residual merge (same geometry) or NULL
+    const float* tfB;
+    int flags;                         // 1 ReLU on the A term, 2 ReLU on the B term, 4 ReLU on the sum (enc_merge_kernel's flags)
+    float* mout;                       // merged activation written back [N, h*w, CIN] or NULL (stride 1 only)
+    const _Float16* wpk;               // cer_enc_conv_pack order
+    const float* bias;
+    float* out;
+    float* out2;
+    float* part;                       // statistics partials [N][nblk][COUT][2] or NULL
+    int h, w, ho, wo;
+    int tiles_x, nblk, total_tiles;
+    int out_border;
+    float out_scale;
+};
+
+template <int CIN, int COUT, int STRIDE, int TAPS>
+struct PcCfg {
+    static constexpr int NCH = CIN / 32, NT = COUT / 32;
+    static constexpr int PAD = TAPS == 9 ? 1 : 0;
+    static constexpr int WN = NT >= 4 ? 4 : NT, WM = 4 / WN;                    // consumer waves along channels / rows
+    static constexpr int TH = (TAPS == 9 && STRIDE == 2) ? 2 : (NT >= 4 ? 4 : 8);
+    static constexpr int RPW = TH / WM;                                         // output rows (m-tiles) per consumer wave
+    static constexpr int HH = TAPS == 9 ? (TH - 1) * STRIDE + 3 : TH;
+    static constexpr int HW = TAPS == 9 ? 31 * STRIDE + 3 : 32;
+    static constexpr int ROWS = HH * HW;                                        // halo pixels of a unit
+    static constexpr int ITEMS = (ROWS + 63) / 64;                              // (pixel, 8-channel group) items per producer lane
+    static constexpr int BUF = ROWS * PC_AS;
+    static constexpr int NS = TAPS * 2;                                         // k16-steps per unit
+    static constexpr bool WRES = NCH * NS <= 18;                                // weights resident in registers
+    static constexpr int RED = 2 * WM * COUT * 2 * 4;                           // bytes of the statistics patches
+    static constexpr int PATCH = 4 * 32 * 36 * 4;                               // epilogue transpose: 32 pixels x 32 channels (pitch 36) per consumer wave
+    static constexpr int SMEM = 2 * BUF + RED + PATCH;
+};
+
+__device__ __forceinline__ void pc_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");            // (the bare builtin does not order LDS accesses for the compiler)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// LDS pixel index of halo pixel (hy, hx): stride-2 3x3 tiles keep even and odd columns in separate planes of a row, so that the
+// consumers' fragment reads (lane = output column) stay unit-stride
+template <int STRIDE, int TAPS, int HW>
+__device__ __forceinline__ int pc_lds_pixel(int hy, int hx) {
+    if (TAPS == 9 && STRIDE == 2) return hy * HW + (hx & 1) * ((HW + 1) / 2) + (hx >> 1);
+    return hy * HW + hx;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ producers
+// Split of eight values given as y = 2048 x (the factor rides on rstd: a power of two, exact): hi = f16(y 2^-11) = f16(x),
+// lo = f16(y - 2048 hi) = f16((x - hi) 2^11) - the operands of enc_conv.hip bit for bit, in two v_fma_mix instructions per value
+// (the conversions, the subtraction and the scaling of cer_split8 cost 5; VALU issue is what the producers are bound by)
+__device__ __forceinline__ void pc_split8_scaled(const float (&y)[8], half8& hi, half8& lo) {
+    const float c_dn = 1.0f / 2048.0f, c_up = -2048.0f;
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h[k]) : "v"(y[2 * k]), "s"(c_dn));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h[k]) : "v"(y[2 * k + 1]), "s"(c_dn));
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l[k]) : "v"(h[k]), "s"(c_up), "v"(y[2 * k]));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l[k]) : "v"(h[k]), "s"(c_up), "v"(y[2 * k + 1]));
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    hi = __builtin_bit_cast(half8, (u32x4){h[0], h[1], h[2], h[3]});
+    lo = __builtin_bit_cast(half8, (u32x4){l[0], l[1], l[2], l[3]});
+}
+
+#define PC_YMAX 134152192.0f           // 65504 * 2048: what the f16 hi half can hold, in the scaled domain
+
+template <int CIN, int COUT, int STRIDE, int TAPS, bool DUAL>
+__device__ __forceinline__ void pc_producer(const PcArgs& a, char* __restrict__ lds, const float* __restrict__ red, int tid) {
+    using C = PcCfg<CIN, COUT, STRIDE, TAPS>;
+    constexpr int PS = TAPS == 9 ? 1 : STRIDE;                                   // pixel step of the halo in the source (1x1 stride 2: every other pixel)
+    const int g = tid & 3, prow0 = tid >> 2;
+    int hyv[C::ITEMS], hxv[C::ITEMS], lpix[C::ITEMS], ioff[C::ITEMS];
+#pragma unroll
+    for (int i = 0; i < C::ITEMS; ++i) {
+        const int row = min(prow0 + 64 * i, C::ROWS - 1);
+        hyv[i] = row / C::HW;
+        hxv[i] = row - hyv[i] * C::HW;
+        lpix[i] = pc_lds_pixel<STRIDE, TAPS, C::HW>(hyv[i], hxv[i]) * PC_AS + g * 16;
+        ioff[i] = (hyv[i] * PS * a.w + hxv[i] * PS) * CIN + 8 * g;              // element offset from the halo's first pixel (interior units)
+    }
+    // clamp bounds in the scaled domain: ReLU = lower bound 0; without it the lower bound is the f16 range (cer_split2's clamp)
+    const float lowA = (a.flags & 1) ? 0.f : -PC_YMAX, lowB = (a.flags & 2) ? 0.f : -PC_YMAX, lowS = (a.flags & 4) ? 0.f : -PC_YMAX;
+    const bool bplain = DUAL && !a.tfB && !(a.flags & 2);                        // the second tensor enters as it is (an already merged activation)
+    float4 rawA[C::ITEMS][2], rawB[DUAL ? C::ITEMS : 1][2];
+    const int G = (int)gridDim.x;
+    const int ntile = (a.total_tiles - (int)blockIdx.x + G - 1) / G;            // tiles of this block
+    const int U = ntile * C::NCH;
+
+    auto geom = [&](int u, int& img, int& tile, int& ty0, int& tx0, int& c0) {
+        const int t = (int)blockIdx.x + (u / C::NCH) * G;
+        img = t / a.nblk;
+        tile = t - img * a.nblk;
+        ty0 = (tile / a.tiles_x) * C::TH;
+        tx0 = (tile % a.tiles_x) * 32;
+        c0 = (u % C::NCH) * 32;
+    };
+    // whole halo inside the image (and, for the write-back / 1x1 forms, the whole tile inside the output): no clamps, no masks
+    auto is_interior = [&](int ty0, int tx0) -> bool {
+        const int y0 = ty0 * STRIDE - C::PAD, x0 = tx0 * STRIDE - C::PAD;
+        return y0 >= 0 && x0 >= 0 && y0 + (C::HH - 1) * PS < a.h && x0 + (C::HW - 1) * PS < a.w;
+    };
+    auto issue = [&](int u) {                                                    // global loads of unit u
+        int img, tile, ty0, tx0, c0;
+        geom(u, img, tile, ty0, tx0, c0);
+        const long ibase = (long)img * a.h * a.w * CIN + c0;
+        if (is_interior(ty0, tx0)) {                                             // scalar base + per-lane constant offsets
+            const long base = ibase + ((long)(ty0 * STRIDE - C::PAD) * a.w + tx0 * STRIDE - C::PAD) * CIN;
+            const float* pa = a.srcA + base;
+            const float* pb = DUAL ? a.srcB + base : nullptr;
+#pragma unroll
+            for (int i = 0; i < C::ITEMS; ++i) {
+                rawA[i][0] = cer_ld4(pa + ioff[i]);
+                rawA[i][1] = cer_ld4(pa + ioff[i] + 4);
+                if (DUAL) {
+                    rawB[DUAL ? i : 0][0] = cer_ld4(pb + ioff[i]);
+                    rawB[DUAL ? i : 0][1] = cer_ld4(pb + ioff[i] + 4);
+                }
+            }
+        } else {                                                                 // border: addresses clamped, values masked at commit
+#pragma unroll
+            for (int i = 0; i < C::ITEMS; ++i) {
+                const int gy = min(max(ty0 * STRIDE + hyv[i] * PS - C::PAD, 0), a.h - 1);
+                const int gx = min(max(tx0 * STRIDE + hxv[i] * PS - C::PAD, 0), a.w - 1);
+                const long off = ibase + ((long)gy * a.w + gx) * CIN + 8 * g;
+                rawA[i][0] = cer_ld4(a.srcA + off);
+                rawA[i][1] = cer_ld4(a.srcA + off + 4);
+                if (DUAL) {
+                    rawB[DUAL ? i : 0][0] = cer_ld4(a.srcB + off);
+                    rawB[DUAL ? i : 0][1] = cer_ld4(a.srcB + off + 4);
+                }
+            }
+        }
+    };
+    float muA[8], rsA[8], muB[8], rsB[8];                                        // rs = 2048 rstd
+    int cur_key = -1;
+    auto commit_items = [&](auto border_tag, auto bplain_tag, int img, int ty0, int tx0, int c0, char* buf) {
+        constexpr bool BORDER = decltype(border_tag)::value, BPLAIN = decltype(bplain_tag)::value;
+#pragma unroll
+        for (int i = 0; i < C::ITEMS; ++i) {
+            const int row = prow0 + 64 * i;
+            if (row < C::ROWS) {
+                const int sy = ty0 * STRIDE + hyv[i] * PS - C::PAD, sx = tx0 * STRIDE + hxv[i] * PS - C::PAD;
+                const bool inside = !BORDER || (sy >= 0 && sy < a.h && sx >= 0 && sx < a.w);
+                const float va[8] = {rawA[i][0].x, rawA[i][0].y, rawA[i][0].z, rawA[i][0].w, rawA[i][1].x, rawA[i][1].y, rawA[i][1].z, rawA[i][1].w};
+                constexpr int ib = DUAL ? 1 : 0;                                 // (rawB has one row when there is no second tensor)
+                const float4 b0 = rawB[ib * i][0], b1 = rawB[ib * i][1];
+                const float vb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                float yv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float y;
+                    if (!DUAL) {
+                        y = __builtin_amdgcn_fmed3f((va[e] - muA[e]) * rsA[e], lowA, PC_YMAX);
+                    } else {
+                        const float ya = fmaxf((va[e] - muA[e]) * rsA[e], lowA);
+                        const float yb = BPLAIN ? vb[e] * 2048.0f : fmaxf((vb[e] - muB[e]) * rsB[e], lowB);
+                        y = __builtin_amdgcn_fmed3f(ya + yb, lowS, PC_YMAX);
+                    }
+                    yv[e] = (BORDER && !inside) ? 0.f : y;                       // zero padding of the (normalised) activation
+                }
+                half8 hi, lo;
+                pc_split8_scaled(yv, hi, lo);
+                *reinterpret_cast<half8*>(buf + lpix[i]) = hi;
+                *reinterpret_cast<half8*>(buf + lpix[i] + 64) = lo;
+                if (DUAL && STRIDE == 1 && a.mout) {                             // merged activation, once per pixel: the tile's core
+                    const bool core = TAPS == 9 ? (hyv[i] >= 1 && hyv[i] <= C::TH && hxv[i] >= 1 && hxv[i] <= 32) : true;
+                    if (core && inside) {
+                        float* m = a.mout + (long)img * a.h * a.w * CIN + ((long)sy * a.w + sx) * CIN + c0 + 8 * g;
+                        constexpr float dn = 1.0f / 2048.0f;
+                        *reinterpret_cast<float4*>(m) = make_float4(yv[0] * dn, yv[1] * dn, yv[2] * dn, yv[3] * dn);
+                        *reinterpret_cast<float4*>(m + 4) = make_float4(yv[4] * dn, yv[5] * dn, yv[6] * dn, yv[7] * dn);
+                    }
+                }
+            }
+        }
+    };
+    auto commit = [&](int u) {
+        int img, tile, ty0, tx0, c0;
+        geom(u, img, tile, ty0, tx0, c0);
+        const int key = img * C::NCH + (u % C::NCH);
+        if (key != cur_key) {                                                    // statistics of this (image, chunk): block-uniform branch
+            cur_key = key;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const long s = 2 * ((long)img * CIN + c0 + 8 * g + e);
+                muA[e] = a.tfA ? a.tfA[s] : 0.f;
+                rsA[e] = (a.tfA ? a.tfA[s + 1] : 1.f) * 2048.0f;
+                muB[e] = (DUAL && a.tfB) ? a.tfB[s] : 0.f;
+                rsB[e] = ((DUAL && a.tfB) ? a.tfB[s + 1] : 1.f) * 2048.0f;
+            }
+        }
+        char* buf = lds + (u & 1) * C::BUF;
+        const bool interior = is_interior(ty0, tx0) && ty0 + C::TH <= a.ho && tx0 + 32 <= a.wo;
+        if (interior) {
+            if (bplain) commit_items(std::false_type{}, std::true_type{}, img, ty0, tx0, c0, buf);
+            else commit_items(std::false_type{}, std::false_type{}, img, ty0, tx0, c0, buf);
+        } else {
+            commit_items(std::true_type{}, std::false_type{}, img, ty0, tx0, c0, buf);
+        }
+    };
+    auto finalize = [&](int u) {                                                 // statistics record of the tile whose last unit was u
+        if (!a.part || (u % C::NCH) != C::NCH - 1 || tid >= COUT) return;
+        int img, tile, ty0, tx0, c0;
+        geom(u, img, tile, ty0, tx0, c0);
+        const float* r = red + ((u / C::NCH) & 1) * (C::WM * COUT * 2);
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int m = 0; m < C::WM; ++m) {
+            s += r[(m * COUT + tid) * 2 + 0];
+            q += r[(m * COUT + tid) * 2 + 1];
+        }
+        float* dst = a.part + (((long)img * a.nblk + tile) * COUT + tid) * 2;
+        dst[0] = s;
+        dst[1] = q;
+    };
+
+#if PC_TRACE
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+    const unsigned long long tstart = tlast;
+#endif
+    if (U > 0) issue(0);
+    for (int u = 0; u < U; ++u) {
+#if PC_TRACE
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                      // (trace build) the wait for the halo is its own phase
+        PC_T(0);
+#endif
+        commit(u);                                                               // (waits for the loads issued one unit earlier)
+        PC_T(1);
+        if (u + 1 < U) issue(u + 1);
+        PC_T(2);
+        pc_barrier();                                                            // #u: buffer u & 1 is complete
+        PC_T(3);
+        if (u >= 1) finalize(u - 1);
+        PC_T(4);
+    }
+    pc_barrier();                                                                // #U: the consumers' last epilogue is done
+    if (U >= 1) finalize(U - 1);
+#if PC_TRACE
+    if ((tid & 63) == 0 && a.out2) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(a.out2) + ((long)blockIdx.x * 8 + (tid >> 6)) * 8;
+        for (int k = 0; k < 5; ++k) o[k] = tsum[k];
+        o[6] = __builtin_readcyclecounter() - tstart;
+        o[7] = (unsigned long long)U;
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------ consumers
+template <int CIN, int COUT, int STRIDE, int TAPS, int EPI>
+__device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restrict__ lds, float* __restrict__ red, float* __restrict__ patch, int cw,
+                                            int lane) {
+    using C = PcCfg<CIN, COUT, STRIDE, TAPS>;
+    const int li = lane & 31, kg = lane >> 5;
+    const int wn = cw % C::WN, wm = cw / C::WN;
+    const int G = (int)gridDim.x;
+    const int ntile = (a.total_tiles - (int)blockIdx.x + G - 1) / G;
+    // this wave's slice of the packed weights: [chunk][tap][ntile][k16-step][hi|lo][lane][8].  Buffer loads with the step's
+    // offset in an SGPR: with flat addresses hipcc hoists one 64-bit pointer per step out of the tile loop and spills them
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.wpk), 0, C::NCH * TAPS * C::NT * 4096, 0x00020000);
+    const int wvoff = lane * 16, wsoff = wn * 4096;
+    auto ldw = [&](int chtap, int ks, int hl) -> half8 {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, wsoff + chtap * (C::NT * 4096) + ks * 2048 + hl * 1024, 0);
+        return __builtin_bit_cast(half8, v);
+    };
+    half8 wres[C::WRES ? C::NCH * C::NS : 1][2];
+    if (C::WRES) {
+#pragma unroll
+        for (int s = 0; s < C::NCH * C::NS; ++s) {
+            wres[s][0] = ldw(s >> 1, s & 1, 0);
+            wres[s][1] = ldw(s >> 1, s & 1, 1);
+        }
+    }
+    const float bias = a.bias ? a.bias[wn * 32 + li] : 0.f;
+    // byte offset of this lane's fragment for output row 0 of the wave, tap (0, 0), k16-step 0
+    int abase;
+    if (TAPS == 9 && STRIDE == 2) abase = ((wm * C::RPW * 2) * C::HW + li) * PC_AS + kg * 16;
+    else abase = ((wm * C::RPW) * C::HW + li) * PC_AS + kg * 16;
+    auto aoff = [&](int m, int s) -> int {                                       // compile-time offset of (row m, step s) from abase
+        const int tap = s >> 1, ks = s & 1, dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;
+        int pix;
+        if (TAPS == 9 && STRIDE == 2) pix = (2 * m + dy) * C::HW + (dx & 1) * ((C::HW + 1) / 2) + (dx >> 1);
+        else pix = (m + dy) * C::HW + dx;
+        return pix * PC_AS + ks * 32;
+    };
+#if PC_TRACE
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+    const unsigned long long tstart = tlast;
+#endif
+    constexpr bool ROLL = C::RPW >= 2;          // fragments rolled in place one step ahead (RPW = 1: triple-buffered two steps ahead)
+    constexpr int NBUF = ROLL ? 1 : 3;
+
+    for (int j = 0; j < ntile; ++j) {
+        const int t = (int)blockIdx.x + j * G;
+        const int img = t / a.nblk, tile = t - img * a.nblk;
+        const int ty0 = (tile / a.tiles_x) * C::TH + wm * C::RPW, tx0 = (tile % a.tiles_x) * 32;
+        floatx16 accm[C::RPW], accl[C::RPW];
+#pragma unroll
+        for (int m = 0; m < C::RPW; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                accm[m][r] = bias;
+                accl[m][r] = 0.f;
+            }
+#pragma unroll
+        for (int ch = 0; ch < C::NCH; ++ch) {
+            const int u = j * C::NCH + ch;
+            half8 fa[NBUF][C::RPW][2];
+            half8 wst[3][2];                                                     // streamed weights: ring of three steps
+            const char* A = lds + (u & 1) * C::BUF + abase;
+            auto loadA1 = [&](int b, int m, int s, int hl) { fa[b][m][hl] = *reinterpret_cast<const half8*>(A + aoff(m, s) + 64 * hl); };
+            auto loadW = [&](int b, int s) {
+                wst[b][0] = ldw(ch * TAPS + (s >> 1), s & 1, 0);
+                wst[b][1] = ldw(ch * TAPS + (s >> 1), s & 1, 1);
+            };
+            if (!C::WRES) {                                                      // (requested in front of the barrier: L2 latency under the wait)
+                loadW(0, 0);
+                loadW(1, 1);
+            }
+            PC_T(0);
+            pc_barrier();                                                        // #u: the producers have filled buffer u & 1
+            PC_T(1);
+            if (ROLL) {
+                // a step's MFMAs in three groups (main term, hi x lo, lo x hi); a row's hi fragment is re-requested for the next step
+                // right behind its last use in group 2, its lo fragment behind group 3: one fragment set in registers, every request
+                // RPW .. 3 RPW MFMAs (>= 128 cycles at RPW = 2) ahead of its first use
+#pragma unroll
+                for (int m = 0; m < C::RPW; ++m) {
+                    loadA1(0, m, 0, 0);
+                    loadA1(0, m, 0, 1);
+                }
+#pragma unroll
+                for (int s = 0; s < C::NS; ++s) {
+                    if (!C::WRES && s + 2 < C::NS) loadW((s + 2) % 3, s + 2);
+                    const half8 bh = C::WRES ? wres[ch * C::NS + s][0] : wst[s % 3][0];
+                    const half8 bl = C::WRES ? wres[ch * C::NS + s][1] : wst[s % 3][1];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < C::RPW; ++m) accm[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][m][0], bh, accm[m], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < C::RPW; ++m) {
+                        accl[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][m][0], bl, accl[m], 0, 0, 0);
+                        if (s + 1 < C::NS) loadA1(0, m, s + 1, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int m = 0; m < C::RPW; ++m) {
+                        accl[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][m][1], bh, accl[m], 0, 0, 0);
+                        if (s + 1 < C::NS) loadA1(0, m, s + 1, 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    loadA1(d, 0, d, 0);
+                    loadA1(d, 0, d, 1);
+                }
+#pragma unroll
+                for (int s = 0; s < C::NS; ++s) {
+                    if (s + 2 < C::NS) {
+                        loadA1((s + 2) % 3, 0, s + 2, 0);
+                        loadA1((s + 2) % 3, 0, s + 2, 1);
+                    }
+                    if (!C::WRES && s + 2 < C::NS) loadW((s + 2) % 3, s + 2);
+                    __builtin_amdgcn_sched_barrier(0);                           // the requests stay in front of this step's MFMAs
+                    const int b = s % 3;
+                    const half8 bh = C::WRES ? wres[ch * C::NS + s][0] : wst[s % 3][0];
+                    const half8 bl = C::WRES ? wres[ch * C::NS + s][1] : wst[s % 3][1];
+                    accm[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[b][0][0], bh, accm[0], 0, 0, 0);
+                    accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[b][0][0], bl, accl[0], 0, 0, 0);
+                    accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[b][0][1], bh, accl[0], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        PC_T(2);
+        // ---- epilogue: the lane holds channel co of pixels x = tx0 + (r & 3) + 8 (r >> 2) + 4 kg of each of its rows.  The values
+        // leave through a wave-private LDS transpose as 16-byte stores: with one dword store per accumulator register (256 B per
+        // wave instruction) the consumers issued 128 stores per tile and CU and every one of them waited ~100 cycles for a slot in
+        // the CU's memory pipeline behind the producers' halo loads (3.2 k of a tile's 7.6 k cycles by the trace); the pipeline is
+        // bound by instructions in flight, not by bytes.  Partial tiles take the guarded copy (uniform branch: with per-store bounds
+        // tests in the common path hipcc turns every store into its own exec-mask branch).
+        const int co = wn * 32 + li;
+        float ssum = 0.f, ssq = 0.f;
+        // (one lane-dependent 32-bit offset per access pattern; everything else is uniform or immediate: the kernel has no registers to spare)
+        float* Et_w = patch + cw * (32 * 36) + 4 * kg * 36 + li;                 // + ((r & 3) + 8 (r >> 2)) * 36
+        const float* Et_r = patch + cw * (32 * 36) + (lane >> 3) * 36 + 4 * (lane & 7);   // + 8 jj * 36
+        auto epilogue = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+            for (int m = 0; m < C::RPW; ++m) {
+                const int gy = ty0 + m;
+                float* o;                                                        // pixel tx0, this wave's 32 channels (uniform)
+                int pstride;
+                if (EPI == PC_EPI_RAW) {
+                    o = a.out + (((long)img * a.ho + gy) * a.wo + tx0) * COUT + wn * 32;
+                    pstride = COUT;
+                } else if (EPI == PC_EPI_FMAP) {
+                    const int wob = a.wo + 2 * a.out_border;
+                    o = a.out + (((long)img * (a.ho + 2 * a.out_border) + gy + a.out_border) * wob + tx0 + a.out_border) * COUT + wn * 32;
+                    pstride = COUT;
+                } else {
+                    constexpr int HALF = COUT / 2, HW_ = C::WN / 2;              // waves 0 .. WN/2-1: tanh -> out, the rest: relu -> out2
+                    o = (wn < HW_ ? a.out : a.out2) + (((long)img * a.ho + gy) * a.wo + tx0) * HALF + (wn % HW_) * 32;
+                    pstride = HALF;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pxc = (r & 3) + 8 * (r >> 2);
+                    float v = fmaf(accl[m][r], 1.0f / 2048.0f, accm[m][r]);
+                    if (EPI == PC_EPI_RAW) {
+                        if (FULL || (gy < a.ho && tx0 + pxc + 4 * kg < a.wo)) {
+                            ssum += v;
+                            ssq = fmaf(v, v, ssq);
+                        }
+                    } else if (EPI == PC_EPI_FMAP) {
+                        v *= a.out_scale;
+                    } else {
+                        v = (wn < C::WN / 2) ? tanhf(v) : fmaxf(v, 0.f);
+                    }
+                    Et_w[pxc * 36] = v;
+                }
+                const int lane_off = (lane >> 3) * pstride + 4 * (lane & 7);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(Et_r + 8 * jj * 36);       // (LDS operations of a wave execute in order)
+                    if (FULL || (gy < a.ho && tx0 + (lane >> 3) + 8 * jj < a.wo)) *reinterpret_cast<float4*>(o + lane_off + 8 * jj * pstride) = v4;
+                }
+            }
+        };
+        if (ty0 + C::RPW <= a.ho && tx0 + 32 <= a.wo) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
+        if (EPI == PC_EPI_RAW && a.part) {
+            const float s2 = ssum + __shfl_xor(ssum, 32), q2 = ssq + __shfl_xor(ssq, 32);
+            if (kg == 0) {
+                float* r = red + (j & 1) * (C::WM * COUT * 2) + (wm * COUT + co) * 2;
+                r[0] = s2;
+                r[1] = q2;
+            }
+        }
+        PC_T(3);
+    }
+    pc_barrier();                                                                // #U
+#if PC_TRACE
+    if (lane == 0 && a.out2 && EPI == PC_EPI_RAW) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(a.out2) + ((long)blockIdx.x * 8 + 4 + cw) * 8;
+        for (int k = 0; k < 4; ++k) o[k] = tsum[k];
+        o[6] = __builtin_readcyclecounter() - tstart;
+        o[7] = (unsigned long long)ntile;
+    }
+#endif
+}
+
+template <int CIN, int COUT, int STRIDE, int TAPS, int EPI, bool DUAL>
+__global__ __launch_bounds__(512, 2) void enc_pc_kernel(const PcArgs a) {
+    using C = PcCfg<CIN, COUT, STRIDE, TAPS>;
+    extern __shared__ __attribute__((aligned(16))) char pc_smem[];
+    float* red = reinterpret_cast<float*>(pc_smem + 2 * C::BUF);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);           // wave index in an SGPR: the role branch is scalar
+    if (wave < 4) pc_producer<CIN, COUT, STRIDE, TAPS, DUAL>(a, pc_smem, red, (int)threadIdx.x);
+    else pc_consumer<CIN, COUT, STRIDE, TAPS, EPI>(a, pc_smem, red, reinterpret_cast<float*>(pc_smem + 2 * C::BUF + C::RED), wave - 4, (int)(threadIdx.x & 63));
+}
+
+// ------------------------------------------------------------------------------------------------------------------ host side
+template <int CIN, int COUT, int STRIDE, int TAPS, int EPI>
+static int pc_launch(PcArgs a, int nimg, hipStream_t st) {
+    using C = PcCfg<CIN, COUT, STRIDE, TAPS>;
+    a.tiles_x = (a.wo + 31) / 32;
+    a.nblk = a.tiles_x * ((a.ho + C::TH - 1) / C::TH);
+    const long total = (long)a.nblk * nimg;
+    if (total >= (1L << 31)) return CER_ESHAPE;
+    a.total_tiles = (int)total;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const unsigned grid = (unsigned)(total < cus ? total : cus);
+    const bool dual = a.srcB != nullptr;
+    const void* fn = dual ? (const void*)enc_pc_kernel<CIN, COUT, STRIDE, TAPS, EPI, true> : (const void*)enc_pc_kernel<CIN, COUT, STRIDE, TAPS, EPI, false>;
+    static bool raised[2][64];                                                   // per instantiation, per device (not "first device only")
+    if (C::SMEM > 64 * 1024 && (dev < 0 || dev >= 64 || !raised[dual][dev])) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        if (e != hipSuccess) return (int)e;
+        if (dev >= 0 && dev < 64) raised[dual][dev] = true;
+    }
+    if (dual) hipLaunchKernelGGL((enc_pc_kernel<CIN, COUT, STRIDE, TAPS, EPI, true>), dim3(grid), dim3(512), C::SMEM, st, a);
+    else hipLaunchKernelGGL((enc_pc_kernel<CIN, COUT, STRIDE, TAPS, EPI, false>), dim3(grid), dim3(512), C::SMEM, st, a);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}
+
+static int pc_tile_rows(int Cout, int taps, int stride) { return (taps == 9 && stride == 2) ? 2 : (Cout >= 128 ? 4 : 8); }
+
+extern "C" int cer_enc_pc_supported(int Cin, int Cout, int taps, int stride, int epi) {
+    if (epi == PC_EPI_RAW) {
+        if (Cin == 32 && Cout == 32 && taps == 9 && stride == 1) return 1;
+        if (Cin == 32 && Cout == 64 && stride == 2 && (taps == 9 || taps == 1)) return 1;
+        if (Cin == 64 && Cout == 64 && taps == 9 && stride == 1) return 1;
+        return 0;
+    }
+    if (epi == PC_EPI_FMAP) return Cin == 64 && Cout == 64 && taps == 1 && stride == 1;
+    if (epi == PC_EPI_CTX) return Cin == 64 && Cout == 128 && taps == 1 && stride == 1;
+    return 0;
+}
+
+extern "C" int cer_enc_pc_tiles(int ho, int wo, int Cout, int taps, int stride) {
+    const int th = pc_tile_rows(Cout, taps, stride);
+    return ((wo + 31) / 32) * ((ho + th - 1) / th);
+}
+
+extern "C" int cer_enc_pc_conv(const float* srcA, const float* statsA, const float* srcB, const float* statsB, int flags, float* merged_out,
+                               const void* packed_w, const float* bias, float* out, float* out2, float* stats_partial, int N, int h, int w,
+                               int Cin, int Cout, int taps, int stride, int epi, int out_border, float out_scale, void* stream) {
+    if (!srcA || !packed_w || !out || N <= 0 || h <= 0 || w <= 0) return CER_EINVAL;
+    if (!cer_enc_pc_supported(Cin, Cout, taps, stride, epi)) return CER_ESHAPE;
+    if (epi == PC_EPI_CTX && !out2) return CER_EINVAL;
+    if (merged_out && (!srcB || stride != 1)) return CER_EINVAL;
+    if (!cer_aligned16(srcA) || !cer_aligned16(packed_w) || (srcB && !cer_aligned16(srcB)) || (merged_out && !cer_aligned16(merged_out)))
+        return CER_EALIGN;
+    PcArgs a;
+    memset(&a, 0, sizeof(a));
+    a.srcA = srcA;
+    a.tfA = statsA;
+    a.srcB = srcB;
+    a.tfB = srcB ? statsB : nullptr;
+    a.flags = flags;
+    a.mout = merged_out;
+    a.wpk = (const _Float16*)packed_w;
+    a.bias = bias;
+    a.out = out;
+    a.out2 = out2;
+    a.part = epi == PC_EPI_RAW ? stats_partial : nullptr;
+    a.h = h;
+    a.w = w;
+    const int pad = taps == 9 ? 1 : 0, ks = taps == 9 ? 3 : 1;
+    a.ho = (h + 2 * pad - ks) / stride + 1;
+    a.wo = (w + 2 * pad - ks) / stride + 1;
+    a.out_border = out_border;
+    a.out_scale = out_scale;
+    hipStream_t st = (hipStream_t)stream;
+    if (epi == PC_EPI_FMAP) return pc_launch<64, 64, 1, 1, PC_EPI_FMAP>(a, N, st);
+    if (epi == PC_EPI_CTX) return pc_launch<64, 128, 1, 1, PC_EPI_CTX>(a, N, st);
+    if (Cin == 32 && Cout == 32) return pc_launch<32, 32, 1, 9, PC_EPI_RAW>(a, N, st);
+    if (Cin == 32 && taps == 9) return pc_launch<32, 64, 2, 9, PC_EPI_RAW>(a, N, st);
+    if (Cin == 32) return pc_launch<32, 64, 2, 1, PC_EPI_RAW>(a, N, st);
+    return pc_launch<64, 64, 1, 9, PC_EPI_RAW>(a, N, st);
+}

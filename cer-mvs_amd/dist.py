@@ -77,3 +77,14 @@ def aggregate_views(frames, num_views, aggregation, group):
             dist.all_reduce(ss, op=dist.ReduceOp.SUM, group=group)
         out.append(torch.sqrt(ss / (num_views - 1)))
     return out
+
+
+def max_int(value, group, device):
+    """MAX of a host integer over the ranks of ``group`` (one tiny all-reduce: the overflow flag under overflow_policy="raise")."""
+    import torch.distributed as dist
+    if group is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return int(value)
+    on_dev = dist.get_backend(group) == "nccl"
+    t = torch.tensor([int(value)], dtype=torch.int32, device=device if on_dev else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())

@@ -6,12 +6,29 @@ each convolution stores its RAW output plus per-block statistics partials, and t
 ``relu((x - mean) * rstd)`` while it stages its input tile.  Activations are channels-last fp32; convolutions run on
 the split-f16 MFMA path (fp32-equivalent).  Only "instance" and "none" norms (the two the reference uses) are built."""
 import ctypes
+import os
 
 import torch
 
 from . import _lib as L
 
 STEM_MFMA = True          # 7x7 stem on the matrix cores (csrc/enc_stem.hip); False: the direct fp32 kernel (exact fmaf chain)
+# "pc" (round 4, default): producer / consumer convolutions with the residual merges formed on the fly (csrc/enc_pc.hip);
+# "tiled": the round-2/3 kernels (csrc/enc_conv.hip: every wave runs every phase; separate enc_merge passes) - kept for A/B runs
+ENGINE = os.environ.get("CER_ENC_ENGINE", "pc")
+
+
+class _In:
+    """A block input that is not (necessarily) materialised: x = relu_s( relu_a(n(A)) + relu_b(n(B)) ), B optional."""
+    __slots__ = ("A", "sA", "rA", "B", "sB", "rB", "C")
+
+    def __init__(self, A, sA, rA, C, B=None, sB=None, rB=False):
+        self.A, self.sA, self.rA, self.B, self.sB, self.rB, self.C = A, sA, rA, B, sB, rB, C
+
+    def images(self, n0, n1):
+        sl = lambda t: None if t is None else t[n0:n1]
+        ss = lambda t: None if t is None else t[n0 * self.C:n1 * self.C]
+        return _In(sl(self.A), ss(self.sA), self.rA, self.C, sl(self.B), ss(self.sB), self.rB)
 
 
 class _Conv:
@@ -88,6 +105,62 @@ class HipEncoder:
     def trunk(self, x, raw=False):
         """x [N,3,H,W] float32, normalised to [-1,1] - or, with ``raw``, 0..255 pixel values that the stem kernel normalises while
         it loads them (x * 2/255 - 1, core/raft.py:40-41: no separate pass over the image stack) -> (a [N, h*w, 64], h, w)."""
+        raw0, st0, ho, wo = self._stem(x, raw)
+        N = x.shape[0]
+        # `cur` = (tensor, stats, relu): the block input is relu(norm(tensor)) when stats/relu are set, else the tensor itself
+        cur, cur_st, cur_relu, h, w, C = raw0, st0, True, ho, wo, 32
+        for c1, c2, down in self.blocks:
+            r1, s1, h1, w1 = self._conv(c1, cur, N, h, w, cur_st, cur_relu)
+            r2, s2, _, _ = self._conv(c2, r1, N, h1, w1, s1, True)
+            if down is not None:
+                rd, sd, _, _ = self._conv(down, cur, N, h, w, cur_st, cur_relu)
+                nxt = self._merge(r2, s2, rd, sd, N, h1 * w1, c2.cout, 1 | 4)                      # relu(norm3(down) + relu(norm(r2)))
+            else:
+                nxt = self._merge(r2, s2, cur, cur_st, N, h1 * w1, c2.cout, 1 | (2 if cur_relu else 0) | 4)
+            cur, cur_st, cur_relu, h, w, C = nxt, None, False, h1, w1, c2.cout
+        return cur, h, w
+
+    # ---- producer / consumer engine (csrc/enc_pc.hip)
+    def _pc(self, c, x, N, h, w, merged=False, epi=0, out=None, out2=None, border=0, scale=1.0, want_stats=True):
+        """conv ``c`` of the (virtual) input ``x`` -> (raw out, stats, ho, wo, merged activation or None)."""
+        lib = L.load()
+        pad, ks = (1, 3) if c.taps == 9 else (0, 1)
+        ho, wo = (h + 2 * pad - ks) // c.stride + 1, (w + 2 * pad - ks) // c.stride + 1
+        part = None
+        if epi == 0:
+            out = torch.empty(N, ho * wo, c.cout, device=self.device, dtype=torch.float32)
+            if self.inorm and want_stats:
+                part = torch.empty(N, lib.cer_enc_pc_tiles(ho, wo, c.cout, c.taps, c.stride), c.cout, 2, device=self.device, dtype=torch.float32)
+        m = torch.empty(N, h * w, c.cin, device=self.device, dtype=torch.float32) if merged else None
+        flags = (1 if x.rA else 0) | ((2 if x.rB else 0) | 4 if x.B is not None else 0)
+        L.check(lib.cer_enc_pc_conv(L.dev_ptr(x.A, "srcA"), L.dev_ptr(x.sA, "statsA"), L.dev_ptr(x.B, "srcB"), L.dev_ptr(x.sB, "statsB"), flags,
+                                    L.dev_ptr(m, "merged"), L.dev_ptr(c.packed, "w", torch.float16), L.dev_ptr(c.bias, "bias"), L.dev_ptr(out, "out"),
+                                    L.dev_ptr(out2, "out2"), L.dev_ptr(part, "part"), N, h, w, c.cin, c.cout, c.taps, c.stride, epi, border,
+                                    float(scale), L.cur_stream()), "enc_pc_conv")
+        st = self._stats(part, N, part.shape[1], c.cout, ho * wo) if part is not None else None
+        return out, st, ho, wo, m
+
+    def _trunk_pc(self, x, raw=False):
+        """images -> the LAST residual block's output as a virtual input (two tensors, merged by the consumer) + geometry.
+        Tensor passes over the half-resolution layer: 13.5 (the tiled engine with its four merge passes: 16.25)."""
+        raw0, st0, h, w = self._stem(x, raw)
+        N = x.shape[0]
+        cur = _In(raw0, st0, True, 32)
+        for c1, c2, down in self.blocks:
+            keep = cur.B is not None and down is None                   # the skip branch needs the merged input as a tensor
+            r1, s1, h1, w1, m = self._pc(c1, cur, N, h, w, merged=keep)
+            r2, s2, _, _, _ = self._pc(c2, _In(r1, s1, True, c1.cout), N, h1, w1)
+            if down is not None:
+                rd, sd, _, _, _ = self._pc(down, cur, N, h, w)
+                cur = _In(r2, s2, True, c2.cout, rd, sd, False)         # relu(norm3(down) + relu(norm(r2)))
+            elif cur.B is None:
+                cur = _In(r2, s2, True, c2.cout, cur.A, cur.sA, cur.rA)
+            else:
+                cur = _In(r2, s2, True, c2.cout, m, None, False)
+            h, w = h1, w1
+        return cur, h, w
+
+    def _stem(self, x, raw):
         lib = L.load()
         N, _, H, W = x.shape
         x = x.contiguous()
@@ -106,47 +179,53 @@ class HipEncoder:
             L.check(lib.cer_enc_stem_f32(L.dev_ptr(x, "images"), L.dev_ptr(self.stem_w, "w"), L.dev_ptr(self.stem_b, "b"), L.dev_ptr(raw0, "out"),
                                          L.dev_ptr(part, "part"), N, H, W, int(bool(raw)), L.cur_stream()), "enc_stem")
         st0 = self._stats(part, N, part.shape[1], 32, ho * wo) if part is not None else None
-        # `cur` = (tensor, stats, relu): the block input is relu(norm(tensor)) when stats/relu are set, else the tensor itself
-        cur, cur_st, cur_relu, h, w, C = raw0, st0, True, ho, wo, 32
-        for c1, c2, down in self.blocks:
-            r1, s1, h1, w1 = self._conv(c1, cur, N, h, w, cur_st, cur_relu)
-            r2, s2, _, _ = self._conv(c2, r1, N, h1, w1, s1, True)
-            if down is not None:
-                rd, sd, _, _ = self._conv(down, cur, N, h, w, cur_st, cur_relu)
-                nxt = self._merge(r2, s2, rd, sd, N, h1 * w1, c2.cout, 1 | 4)                      # relu(norm3(down) + relu(norm(r2)))
-            else:
-                nxt = self._merge(r2, s2, cur, cur_st, N, h1 * w1, c2.cout, 1 | (2 if cur_relu else 0) | 4)
-            cur, cur_st, cur_relu, h, w, C = nxt, None, False, h1, w1, c2.cout
-        return cur, h, w
+        return raw0, st0, ho, wo
+
+    def _head(self, x, N, h, w, epi, out, out2=None, border=0, scale=1.0):
+        """final 1x1 conv of a (virtual or plain) trunk output into the consumers' layouts"""
+        if isinstance(x, _In):
+            self._pc(self.head, x, N, h, w, epi=epi, out=out, out2=out2, border=border, scale=scale)
+        else:
+            self._conv(self.head, x, N, h, w, None, False, epi=epi, out=out, out2=out2, border=border, scale=scale)
+
+    def _trunk_any(self, x, raw):
+        if ENGINE == "pc":
+            return self._trunk_pc(x, raw)
+        return self.trunk(x, raw)
 
     def features(self, x, n_ref=1, border=2, scale=0.125, src_out=None, raw=False):
         """fnet head: (ref [n_ref*h*w... ] plain, src bordered).  x [N,3,H,W]; the first ``n_ref`` images go to a plain
         [n_ref, h*w, C] map, the rest to a [N-n_ref, (h+2b)*(w+2b), C] map with a zero border; both scaled."""
-        a, h, w = self.trunk(x, raw)
+        a, h, w = self._trunk_any(x, raw)
         N, C = x.shape[0], self.head.cout
+        part = (lambda n0, n1: a.images(n0, n1)) if isinstance(a, _In) else (lambda n0, n1: a[n0:n1])
         ref = torch.empty(n_ref, h * w, C, device=self.device, dtype=torch.float32)
         if n_ref > 0:
-            self._conv(self.head, a[:n_ref], n_ref, h, w, None, False, epi=1, out=ref, border=0, scale=scale)
+            self._head(part(0, n_ref), n_ref, h, w, 1, ref, border=0, scale=scale)
         src = None
         if N > n_ref:
             src = src_out if src_out is not None else torch.zeros(N - n_ref, (h + 2 * border) * (w + 2 * border), C, device=self.device,
                                                                   dtype=torch.float32)
-            self._conv(self.head, a[n_ref:], N - n_ref, h, w, None, False, epi=1, out=src, border=border, scale=scale)
+            self._head(part(n_ref, N), N - n_ref, h, w, 1, src, border=border, scale=scale)
         return ref, src, h, w
 
     def context(self, x, raw=False):
         """cnet head: x [1,3,H,W] -> (net = tanh(first half) [P,64], inp = relu(second half) [P,64])."""
-        a, h, w = self.trunk(x, raw)
+        a, h, w = self._trunk_any(x, raw)
         half = self.head.cout // 2
         net = torch.empty(h * w, half, device=self.device, dtype=torch.float32)
         inp = torch.empty(h * w, half, device=self.device, dtype=torch.float32)
-        self._conv(self.head, a, 1, h, w, None, False, epi=2, out=net, out2=inp)
+        self._head(a, 1, h, w, 2, net, out2=inp)
         return net, inp, h, w
 
     def forward_nchw(self, x):
         """Plain module semantics: [N,3,H,W] -> [N,Cout,h,w] (used by parity tests)."""
-        a, h, w = self.trunk(x)
+        a, h, w = self._trunk_any(x, False)
         N, C = x.shape[0], self.head.cout
         out = torch.empty(N, h * w, C, device=self.device, dtype=torch.float32)
-        self._conv(self.head, a, N, h, w, None, False, epi=1, out=out, border=0, scale=1.0)
+        if C == 64 or not isinstance(a, _In):
+            self._head(a, N, h, w, 1, out, border=0, scale=1.0)
+        else:                                  # (the 128-channel context head exists as the tanh | relu epilogue only: materialise for the plain form)
+            m = self._merge(a.A, a.sA, a.B, a.sB, N, h * w, a.C, (1 if a.rA else 0) | (2 if a.rB else 0) | 4)
+            self._conv(self.head, m, N, h, w, None, False, epi=1, out=out, border=0, scale=1.0)
         return out.view(N, h, w, C).permute(0, 3, 1, 2).contiguous()

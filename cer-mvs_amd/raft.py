@@ -278,7 +278,10 @@ class RAFT(nn.Module):
                     L.load().cer_cost_build_algo(algo)
                 ops.check_overflow(dev)
             return out
-        return self._forward_fast(images, poses, intrinsics, scale, do_report)
+        if self.overflow_policy == "fallback" and self.view_group is not None:
+            raise NotImplementedError("RAFT.overflow_policy='fallback' is not available with view_group (every rank would have to repeat "
+                                      "the forward together): use 'lazy' or 'raise'")
+        return self._forward_fast(images, poses, intrinsics, scale, do_report)     # ("raise" with a view_group: handled at its end)
 
     def _forward_fast(self, images, poses, intrinsics, scale, do_report):
         self._validate_packs()
@@ -330,8 +333,11 @@ class RAFT(nn.Module):
         net_l = ub.prepare_net(net_l, h, w)
         del images
         # split-f16 operand rows of the cost volume's MFMA products (csrc/cost_lines.hip): the same for every stage
+        # (only when the epipolar-line-tile kernel will run for some stage: cer_feat_split_f16 is what raises overflow bit 1, and a
+        # forward on the fp32 walk - cer_cost_build_algo(1), the remedy the overflow error names - must not be able to raise it)
         if split is None:
-            split = (ops.feat_split(f1), ops.feat_split(f2)) if (views and self.dim_fmap == 64) else None
+            lines = (views and self.dim_fmap == 64 and L.load().cer_cost_build_algo(-1) != 1 and any(D_ <= 64 for D_, _, _ in self.stages()))
+            split = (ops.feat_split(f1), ops.feat_split(f2)) if lines else None
 
         hoisted_all = ub.hoist_all(inp_l, h, w, len(self.cascade))
         ws = ub.workspace(h, w, dev)
@@ -356,6 +362,12 @@ class RAFT(nn.Module):
             ub.run(T, vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws)
         if self.overflow_policy == "lazy":
             ops.overflow_snapshot(dev)
+        elif self.overflow_policy == "raise" and self.view_group is not None:
+            # sharded by views: every rank reads its flag and the ranks agree (MAX) before anyone raises, so that no rank leaves the
+            # collective sequence alone (the single-GPU form of "raise" / "fallback" is in forward())
+            bits = cdist.max_int(int(ops.check_overflow(dev)), self.view_group, dev)
+            if bits:
+                self._raise_overflow(bits)
         return disp.view(1, 1, h, w) * s
 
     def _forward_literal(self, images, poses, intrinsics, scale, do_report):

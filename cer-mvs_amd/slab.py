@@ -83,6 +83,10 @@ class LocalExchange:
             out.append((rp if g > 0 else None, rn if g < self.G - 1 else None))
         return out
 
+    def max_int(self, value, device):
+        """MAX of a host integer over the ranks (all of them live in this process)."""
+        return int(value)
+
     def all_gather_flat(self, tensors):
         """list of G equal-sized tensors -> per simulated rank the stacked [G, ...] tensor."""
         assert len(tensors) == self.G
@@ -102,6 +106,14 @@ class DistExchange:
         self.group = group
         self.G = dist.get_world_size(group)
         self.ranks = [dist.get_rank(group)]
+
+    def max_int(self, value, device):
+        """MAX of a host integer over the ranks (one tiny all-reduce; used for the overflow flag under overflow_policy="raise")."""
+        import torch.distributed as dist
+        on_dev = dist.get_backend(self.group) == "nccl"
+        t = torch.tensor([int(value)], dtype=torch.int32, device=device if on_dev else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
 
     def neighbor_exchange(self, bufs):
         """Halo refresh as point-to-point traffic: this rank's buffer is [top half | bottom half]; the top half goes to rank g-1,
@@ -278,6 +290,25 @@ def unpack_halo(net, disp, allbuf, w, g, G, r0, r1, e0, e1, halo=HALO, copy=_dev
 P2P_HALO = True           # halo refresh by neighbour point-to-point exchange (False: one all-gather of every rank's strips)
 
 
+def _finish_overflow(model, ex, dev, workspaces, ub):
+    """End-of-forward overflow handling of the sharded path.  "lazy": asynchronous snapshot, polled by the next forward (every rank
+    polls its own flag; the ranks run the same GRU on overlapping rows, but a rank can saturate alone - a hit then raises on that
+    rank at its next forward).  "raise": the flag is read here and MAX-reduced over the ranks, so that every rank raises together
+    instead of one rank leaving the collective sequence.  "fallback" has no sharded form: it is refused up front (sharded_forward)."""
+    from . import ops
+    if ub.conv_mode == "s16" and ub.CHECK_OVERFLOW:
+        for ws in workspaces:
+            ops.scan_overflow(ws["c1"])
+            ops.scan_overflow(ws["c2"])
+    policy = getattr(model, "overflow_policy", "lazy")
+    if policy == "lazy":
+        ops.overflow_snapshot(dev)
+    elif policy == "raise":
+        bits = ex.max_int(int(ops.check_overflow(dev)), dev)
+        if bits:
+            model._raise_overflow(bits)
+
+
 def sharded_forward(model, images, poses, intrinsics, scale, ex):
     """Test-mode RAFT.forward sharded over ``ex.G`` ranks; ``ex.ranks`` are the ranks simulated by this process.
     Returns the full-resolution disparity [1,1,h,w] * scale (identical on every rank)."""
@@ -286,6 +317,9 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
     from .projective import pij_matrices
     dev = images.device
     G = ex.G
+    if getattr(model, "overflow_policy", "lazy") == "fallback":
+        raise NotImplementedError("RAFT.overflow_policy='fallback' is not available on the sharded forward (every rank would have to "
+                                  "repeat the forward together): use 'lazy' or 'raise'")
     s = float(torch.as_tensor(scale).reshape(-1)[0])
     poses = poses.clone().float()
     poses[..., :3, 3] *= s
@@ -402,6 +436,10 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
                                       rows=d["rows"])
                 else:
                     d["plan_halo"].replay()
+
+    # ---- saturation is never silent on the sharded path either: the slab loop calls ub.step, not ub.run, so the
+    # scans of the corr features happen here; bits 1 / 2 were or-ed into the flag by the kernels themselves
+    _finish_overflow(model, ex, dev, [st[g]["ws"] for g in ex.ranks], ub)
 
     # ---- gather the owned rows of every rank (persistent send / receive buffers)
     rows_max = (h + G - 1) // G

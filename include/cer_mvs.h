@@ -386,6 +386,22 @@ int cer_enc_conv_f16x3(const float* src, const float* tf_stats, int tf_relu, con
 int cer_enc_stats_reduce_f32(const float* partial, float* stats, int N, int nblk, int C, long pixels, float eps, void* stream);
 int cer_enc_merge_f32(const float* a, const float* a_stats, const float* b, const float* b_stats, float* out,
                       int N, long pixels, int C, int flags, void* stream);
+/* Round 4: the same convolutions with producer / consumer wave roles (csrc/enc_pc.hip; reference: core/extractor.py:49-57,
+ * 143-155).  Operand preparation (the producer layer's instance norm + ReLU, split to hi|lo f16) runs in four producer waves
+ * UNDER the matrix work of four consumer waves of the same 512-thread persistent block, and the block's input may be the residual
+ * merge of TWO tensors formed on the fly,
+ *     x = relu4( relu1(n_A(A)) + relu2(n_B(B)) ),   n(t) = stats ? (t - mean[n,c]) * rstd[n,c] : t,   flags = 1 | 2 | 4 as in
+ * cer_enc_merge_f32 (srcB NULL: x = relu1(n_A(A))), so that no merged activation has to be produced by a pass of its own;
+ * merged_out (optional, stride 1, needs srcB) receives x once per pixel [N, h*w, Cin] for a later residual branch.
+ * Same packed weights (cer_enc_conv_pack), same arithmetic (three f16 MFMA terms, two fp32 accumulators) and the same epilogues
+ * (epi 0 RAW / 1 FMAP / 2 CTX) as cer_enc_conv_f16x3; stats_partial (RAW) is [N][cer_enc_pc_tiles(...)][Cout][2].
+ * Shapes: cer_enc_pc_supported(Cin, Cout, taps, stride, epi) != 0 - the "HR" encoder's: 32->32 3x3; 32->64 3x3 / 1x1 stride 2;
+ * 64->64 3x3; 64->64 1x1 FMAP; 64->128 1x1 CTX.  Everything else returns CER_ESHAPE (use cer_enc_conv_f16x3). */
+int cer_enc_pc_supported(int Cin, int Cout, int taps, int stride, int epi);
+int cer_enc_pc_tiles(int ho, int wo, int Cout, int taps, int stride);
+int cer_enc_pc_conv(const float* srcA, const float* statsA, const float* srcB, const float* statsB, int flags, float* merged_out,
+                    const void* packed_w, const float* bias, float* out, float* out2, float* stats_partial, int N, int h, int w,
+                    int Cin, int Cout, int taps, int stride, int epi, int out_border, float out_scale, void* stream);
 
 /* NCHW [C,h,w] -> NHWC [h*w,C] with a scale (feature maps: scale = 1/8, core/corr.py:30-31)
  * and NHWC -> NCHW; C % 4 == 0. */
