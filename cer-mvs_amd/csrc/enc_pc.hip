@@ -30,6 +30,9 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+#ifndef PC_ABL
+#define PC_ABL 0                       // profiling ablations (variant builds only): 1 no MFMAs, 2 no output stores, 4 no operand transform (halves of the raw bits)
+#endif
 #ifndef PC_TRACE
 #define PC_TRACE 0                     // debug build: per-wave phase cycle sums written to a.out2 [blocks][8 waves][8] (u64); tools/trace_pc.py
 #endif
@@ -94,6 +97,32 @@ __device__ __forceinline__ int pc_lds_pixel(int hy, int hx) {
     return hy * HW + hx;
 }
 
+// Work order.  Block b runs on XCD b % 8 (observed, not promised: used for speed only), and every XCD has its own L2.  The j-th work
+// item of block b is index j * G + (b % 8) * (G / 8) + b / 8 of a COLUMN-major enumeration of an image's tiles: at any time the 32
+// blocks of an XCD work on 32 vertically adjacent tiles, so the two halo rows a tile shares with the tile above / below (25 % extra
+// reads with 8-row tiles) are fetched into that XCD's L2 once instead of crossing the fabric twice.  The tile's identity (statistics
+// record, output position) stays row-major.
+#ifndef PC_XCD_ORDER
+#define PC_XCD_ORDER 1
+#endif
+__device__ __forceinline__ int pc_work_offset() {
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    return (PC_XCD_ORDER && G % 8 == 0) ? (b % 8) * (G / 8) + b / 8 : b;
+}
+__device__ __forceinline__ void pc_work_tile(const PcArgs& a, int widx, int& img, int& tile, int& ty, int& tx) {
+    img = widx / a.nblk;
+    const int c = widx - img * a.nblk;
+    if (PC_XCD_ORDER) {
+        const int tiles_y = a.nblk / a.tiles_x;
+        tx = c / tiles_y;
+        ty = c - tx * tiles_y;
+    } else {
+        ty = c / a.tiles_x;
+        tx = c - ty * a.tiles_x;
+    }
+    tile = ty * a.tiles_x + tx;
+}
+
 // ------------------------------------------------------------------------------------------------------------------ producers
 // Split of eight values given as y = 2048 x (the factor rides on rstd: a power of two, exact): hi = f16(y 2^-11) = f16(x),
 // lo = f16(y - 2048 hi) = f16((x - hi) 2^11) - the operands of enc_conv.hip bit for bit, in two v_fma_mix instructions per value
@@ -113,13 +142,19 @@ __device__ __forceinline__ void pc_split8_scaled(const float (&y)[8], half8& hi,
     lo = __builtin_bit_cast(half8, (u32x4){l[0], l[1], l[2], l[3]});
 }
 
+#if PC_ABL & 1
+__device__ __forceinline__ floatx16 pc_keep(half8 a_, half8 b_, floatx16 c_) { asm volatile("" :: "v"(a_), "v"(b_)); return c_; }
+#define PC_MFMA(a_, b_, c_) pc_keep(a_, b_, c_)
+#else
+#define PC_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, 0, 0, 0)
+#endif
 #define PC_YMAX 134152192.0f           // 65504 * 2048: what the f16 hi half can hold, in the scaled domain
 
 template <int CIN, int COUT, int STRIDE, int TAPS, bool DUAL>
 __device__ __forceinline__ void pc_producer(const PcArgs& a, char* __restrict__ lds, const float* __restrict__ red, int tid) {
     using C = PcCfg<CIN, COUT, STRIDE, TAPS>;
     constexpr int PS = TAPS == 9 ? 1 : STRIDE;                                   // pixel step of the halo in the source (1x1 stride 2: every other pixel)
-    const int g = tid & 3, prow0 = tid >> 2;
+    const int g = tid & 3, prow0 = (tid >> 2) & 63;
     int hyv[C::ITEMS], hxv[C::ITEMS], lpix[C::ITEMS], ioff[C::ITEMS];
 #pragma unroll
     for (int i = 0; i < C::ITEMS; ++i) {
@@ -134,15 +169,15 @@ __device__ __forceinline__ void pc_producer(const PcArgs& a, char* __restrict__ 
     const bool bplain = DUAL && !a.tfB && !(a.flags & 2);                        // the second tensor enters as it is (an already merged activation)
     float4 rawA[C::ITEMS][2], rawB[DUAL ? C::ITEMS : 1][2];
     const int G = (int)gridDim.x;
-    const int ntile = (a.total_tiles - (int)blockIdx.x + G - 1) / G;            // tiles of this block
+    const int woff = pc_work_offset();
+    const int ntile = max(0, (a.total_tiles - woff + G - 1) / G);                // tiles of this block
     const int U = ntile * C::NCH;
 
     auto geom = [&](int u, int& img, int& tile, int& ty0, int& tx0, int& c0) {
-        const int t = (int)blockIdx.x + (u / C::NCH) * G;
-        img = t / a.nblk;
-        tile = t - img * a.nblk;
-        ty0 = (tile / a.tiles_x) * C::TH;
-        tx0 = (tile % a.tiles_x) * 32;
+        int ty, tx;
+        pc_work_tile(a, woff + (u / C::NCH) * G, img, tile, ty, tx);
+        ty0 = ty * C::TH;
+        tx0 = tx * 32;
         c0 = (u % C::NCH) * 32;
     };
     // whole halo inside the image (and, for the write-back / 1x1 forms, the whole tile inside the output): no clamps, no masks
@@ -150,36 +185,33 @@ __device__ __forceinline__ void pc_producer(const PcArgs& a, char* __restrict__ 
         const int y0 = ty0 * STRIDE - C::PAD, x0 = tx0 * STRIDE - C::PAD;
         return y0 >= 0 && x0 >= 0 && y0 + (C::HH - 1) * PS < a.h && x0 + (C::HW - 1) * PS < a.w;
     };
-    auto issue = [&](int u) {                                                    // global loads of unit u
+    // the NEXT unit's halo loads are issued item by item, each right behind the commit of the same item of the current unit (a burst
+    // of 12-24 KiB-sized loads per wave at the end of a commit queued in front of everything else the CU had to fetch or store)
+    // (branch-free: with scalar branches inside the item loop hipcc falls back to vmcnt(0) at the top of a commit - every load of
+    // the unit waited for at once; straight-line code gets counted waits, one item at a time.  Past the block's last unit the
+    // current unit is simply requested again.)
+    bool nx_interior = false;
+    const float *nx_pa = nullptr, *nx_pb = nullptr;
+    int nx_y0 = 0, nx_x0 = 0;
+    auto prepare = [&](int u) {                                                  // addressing of unit u's loads (uniform)
         int img, tile, ty0, tx0, c0;
-        geom(u, img, tile, ty0, tx0, c0);
+        geom(min(u, U - 1), img, tile, ty0, tx0, c0);
         const long ibase = (long)img * a.h * a.w * CIN + c0;
-        if (is_interior(ty0, tx0)) {                                             // scalar base + per-lane constant offsets
-            const long base = ibase + ((long)(ty0 * STRIDE - C::PAD) * a.w + tx0 * STRIDE - C::PAD) * CIN;
-            const float* pa = a.srcA + base;
-            const float* pb = DUAL ? a.srcB + base : nullptr;
-#pragma unroll
-            for (int i = 0; i < C::ITEMS; ++i) {
-                rawA[i][0] = cer_ld4(pa + ioff[i]);
-                rawA[i][1] = cer_ld4(pa + ioff[i] + 4);
-                if (DUAL) {
-                    rawB[DUAL ? i : 0][0] = cer_ld4(pb + ioff[i]);
-                    rawB[DUAL ? i : 0][1] = cer_ld4(pb + ioff[i] + 4);
-                }
-            }
-        } else {                                                                 // border: addresses clamped, values masked at commit
-#pragma unroll
-            for (int i = 0; i < C::ITEMS; ++i) {
-                const int gy = min(max(ty0 * STRIDE + hyv[i] * PS - C::PAD, 0), a.h - 1);
-                const int gx = min(max(tx0 * STRIDE + hxv[i] * PS - C::PAD, 0), a.w - 1);
-                const long off = ibase + ((long)gy * a.w + gx) * CIN + 8 * g;
-                rawA[i][0] = cer_ld4(a.srcA + off);
-                rawA[i][1] = cer_ld4(a.srcA + off + 4);
-                if (DUAL) {
-                    rawB[DUAL ? i : 0][0] = cer_ld4(a.srcB + off);
-                    rawB[DUAL ? i : 0][1] = cer_ld4(a.srcB + off + 4);
-                }
-            }
+        nx_interior = is_interior(ty0, tx0);
+        nx_y0 = ty0 * STRIDE - C::PAD;
+        nx_x0 = tx0 * STRIDE - C::PAD;
+        nx_pa = a.srcA + ibase;
+        nx_pb = DUAL ? a.srcB + ibase : nullptr;
+    };
+    auto issue_item = [&](int i) {
+        // interior units: the precomputed offset from the halo's first pixel; border units: clamped coordinates (masked at commit)
+        const int gy = min(max(nx_y0 + hyv[i] * PS, 0), a.h - 1), gx = min(max(nx_x0 + hxv[i] * PS, 0), a.w - 1);
+        const int off = nx_interior ? (nx_y0 * a.w + nx_x0) * CIN + ioff[i] : (gy * a.w + gx) * CIN + 8 * g;
+        rawA[i][0] = cer_ld4(nx_pa + off);
+        rawA[i][1] = cer_ld4(nx_pa + off + 4);
+        if (DUAL) {
+            rawB[DUAL ? i : 0][0] = cer_ld4(nx_pb + off);
+            rawB[DUAL ? i : 0][1] = cer_ld4(nx_pb + off + 4);
         }
     };
     float muA[8], rsA[8], muB[8], rsB[8];                                        // rs = 2048 rstd
@@ -188,8 +220,9 @@ __device__ __forceinline__ void pc_producer(const PcArgs& a, char* __restrict__ 
         constexpr bool BORDER = decltype(border_tag)::value, BPLAIN = decltype(bplain_tag)::value;
 #pragma unroll
         for (int i = 0; i < C::ITEMS; ++i) {
-            const int row = prow0 + 64 * i;
-            if (row < C::ROWS) {
+            // (lanes whose item index lies beyond ROWS hold the clamped last halo pixel: they repeat its owner's writes - same
+            // address, same value - instead of branching around the item)
+            {
                 const int sy = ty0 * STRIDE + hyv[i] * PS - C::PAD, sx = tx0 * STRIDE + hxv[i] * PS - C::PAD;
                 const bool inside = !BORDER || (sy >= 0 && sy < a.h && sx >= 0 && sx < a.w);
                 const float va[8] = {rawA[i][0].x, rawA[i][0].y, rawA[i][0].z, rawA[i][0].w, rawA[i][1].x, rawA[i][1].y, rawA[i][1].z, rawA[i][1].w};
@@ -210,6 +243,11 @@ __device__ __forceinline__ void pc_producer(const PcArgs& a, char* __restrict__ 
                     yv[e] = (BORDER && !inside) ? 0.f : y;                       // zero padding of the (normalised) activation
                 }
                 half8 hi, lo;
+                if (PC_ABL & 4) {
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    hi = __builtin_bit_cast(half8, (f32x4){va[0], va[1], va[2], va[3]});
+                    lo = __builtin_bit_cast(half8, (f32x4){va[4], va[5], va[6], va[7]});
+                } else
                 pc_split8_scaled(yv, hi, lo);
                 *reinterpret_cast<half8*>(buf + lpix[i]) = hi;
                 *reinterpret_cast<half8*>(buf + lpix[i] + 64) = lo;
@@ -223,6 +261,7 @@ __device__ __forceinline__ void pc_producer(const PcArgs& a, char* __restrict__ 
                     }
                 }
             }
+            issue_item(i);
         }
     };
     auto commit = [&](int u) {
@@ -241,6 +280,7 @@ __device__ __forceinline__ void pc_producer(const PcArgs& a, char* __restrict__ 
             }
         }
         char* buf = lds + (u & 1) * C::BUF;
+        prepare(u + 1);
         const bool interior = is_interior(ty0, tx0) && ty0 + C::TH <= a.ho && tx0 + 32 <= a.wo;
         if (interior) {
             if (bplain) commit_items(std::false_type{}, std::true_type{}, img, ty0, tx0, c0, buf);
@@ -269,15 +309,15 @@ __device__ __forceinline__ void pc_producer(const PcArgs& a, char* __restrict__ 
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
     const unsigned long long tstart = tlast;
 #endif
-    if (U > 0) issue(0);
+    if (U > 0) {
+        prepare(0);
+#pragma unroll
+        for (int i = 0; i < C::ITEMS; ++i) issue_item(i);
+    }
     for (int u = 0; u < U; ++u) {
-#if PC_TRACE
-        __builtin_amdgcn_s_waitcnt(0x0F70);                                      // (trace build) the wait for the halo is its own phase
         PC_T(0);
-#endif
-        commit(u);                                                               // (waits for the loads issued one unit earlier)
+        commit(u);                                                               // (per item: wait for its loads, transform, LDS, request the next unit's)
         PC_T(1);
-        if (u + 1 < U) issue(u + 1);
         PC_T(2);
         pc_barrier();                                                            // #u: buffer u & 1 is complete
         PC_T(3);
@@ -304,7 +344,8 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
     const int li = lane & 31, kg = lane >> 5;
     const int wn = cw % C::WN, wm = cw / C::WN;
     const int G = (int)gridDim.x;
-    const int ntile = (a.total_tiles - (int)blockIdx.x + G - 1) / G;
+    const int woff = pc_work_offset();
+    const int ntile = max(0, (a.total_tiles - woff + G - 1) / G);
     // this wave's slice of the packed weights: [chunk][tap][ntile][k16-step][hi|lo][lane][8].  Buffer loads with the step's
     // offset in an SGPR: with flat addresses hipcc hoists one 64-bit pointer per step out of the tile loop and spills them
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.wpk), 0, C::NCH * TAPS * C::NT * 4096, 0x00020000);
@@ -342,9 +383,9 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
     constexpr int NBUF = ROLL ? 1 : 3;
 
     for (int j = 0; j < ntile; ++j) {
-        const int t = (int)blockIdx.x + j * G;
-        const int img = t / a.nblk, tile = t - img * a.nblk;
-        const int ty0 = (tile / a.tiles_x) * C::TH + wm * C::RPW, tx0 = (tile % a.tiles_x) * 32;
+        int img, tile, ty_, tx_;
+        pc_work_tile(a, woff + j * G, img, tile, ty_, tx_);
+        const int ty0 = ty_ * C::TH + wm * C::RPW, tx0 = tx_ * 32;
         floatx16 accm[C::RPW], accl[C::RPW];
 #pragma unroll
         for (int m = 0; m < C::RPW; ++m)
@@ -357,7 +398,8 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
         for (int ch = 0; ch < C::NCH; ++ch) {
             const int u = j * C::NCH + ch;
             half8 fa[NBUF][C::RPW][2];
-            half8 wst[3][2];                                                     // streamed weights: ring of three steps
+            constexpr int WD = 4, WR = WD + 1;                                   // streamed weights: requested WD steps ahead (ring of WR)
+            half8 wst[WR][2];
             const char* A = lds + (u & 1) * C::BUF + abase;
             auto loadA1 = [&](int b, int m, int s, int hl) { fa[b][m][hl] = *reinterpret_cast<const half8*>(A + aoff(m, s) + 64 * hl); };
             auto loadW = [&](int b, int s) {
@@ -365,8 +407,8 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
                 wst[b][1] = ldw(ch * TAPS + (s >> 1), s & 1, 1);
             };
             if (!C::WRES) {                                                      // (requested in front of the barrier: L2 latency under the wait)
-                loadW(0, 0);
-                loadW(1, 1);
+#pragma unroll
+                for (int d = 0; d < WD; ++d) loadW(d, d);
             }
             PC_T(0);
             pc_barrier();                                                        // #u: the producers have filled buffer u & 1
@@ -382,22 +424,22 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
                 }
 #pragma unroll
                 for (int s = 0; s < C::NS; ++s) {
-                    if (!C::WRES && s + 2 < C::NS) loadW((s + 2) % 3, s + 2);
-                    const half8 bh = C::WRES ? wres[ch * C::NS + s][0] : wst[s % 3][0];
-                    const half8 bl = C::WRES ? wres[ch * C::NS + s][1] : wst[s % 3][1];
+                    if (!C::WRES && s + WD < C::NS) loadW((s + WD) % WR, s + WD);
+                    const half8 bh = C::WRES ? wres[ch * C::NS + s][0] : wst[s % WR][0];
+                    const half8 bl = C::WRES ? wres[ch * C::NS + s][1] : wst[s % WR][1];
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int m = 0; m < C::RPW; ++m) accm[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][m][0], bh, accm[m], 0, 0, 0);
+                    for (int m = 0; m < C::RPW; ++m) accm[m] = PC_MFMA(fa[0][m][0], bh, accm[m]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int m = 0; m < C::RPW; ++m) {
-                        accl[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][m][0], bl, accl[m], 0, 0, 0);
+                        accl[m] = PC_MFMA(fa[0][m][0], bl, accl[m]);
                         if (s + 1 < C::NS) loadA1(0, m, s + 1, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
                     for (int m = 0; m < C::RPW; ++m) {
-                        accl[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][m][1], bh, accl[m], 0, 0, 0);
+                        accl[m] = PC_MFMA(fa[0][m][1], bh, accl[m]);
                         if (s + 1 < C::NS) loadA1(0, m, s + 1, 1);
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -414,14 +456,14 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
                         loadA1((s + 2) % 3, 0, s + 2, 0);
                         loadA1((s + 2) % 3, 0, s + 2, 1);
                     }
-                    if (!C::WRES && s + 2 < C::NS) loadW((s + 2) % 3, s + 2);
+                    if (!C::WRES && s + WD < C::NS) loadW((s + WD) % WR, s + WD);
                     __builtin_amdgcn_sched_barrier(0);                           // the requests stay in front of this step's MFMAs
                     const int b = s % 3;
-                    const half8 bh = C::WRES ? wres[ch * C::NS + s][0] : wst[s % 3][0];
-                    const half8 bl = C::WRES ? wres[ch * C::NS + s][1] : wst[s % 3][1];
-                    accm[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[b][0][0], bh, accm[0], 0, 0, 0);
-                    accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[b][0][0], bl, accl[0], 0, 0, 0);
-                    accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[b][0][1], bh, accl[0], 0, 0, 0);
+                    const half8 bh = C::WRES ? wres[ch * C::NS + s][0] : wst[s % WR][0];
+                    const half8 bl = C::WRES ? wres[ch * C::NS + s][1] : wst[s % WR][1];
+                    accm[0] = PC_MFMA(fa[b][0][0], bh, accm[0]);
+                    accl[0] = PC_MFMA(fa[b][0][0], bl, accl[0]);
+                    accl[0] = PC_MFMA(fa[b][0][1], bh, accl[0]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -477,7 +519,8 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const float4 v4 = *reinterpret_cast<const float4*>(Et_r + 8 * jj * 36);       // (LDS operations of a wave execute in order)
-                    if (FULL || (gy < a.ho && tx0 + (lane >> 3) + 8 * jj < a.wo)) *reinterpret_cast<float4*>(o + lane_off + 8 * jj * pstride) = v4;
+                    if (PC_ABL & 2) asm volatile("" :: "v"(v4.x), "v"(v4.y), "v"(v4.z), "v"(v4.w));
+                    else if (FULL || (gy < a.ho && tx0 + (lane >> 3) + 8 * jj < a.wo)) *reinterpret_cast<float4*>(o + lane_off + 8 * jj * pstride) = v4;
                 }
             }
         };

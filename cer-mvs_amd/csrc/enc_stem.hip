@@ -17,6 +17,8 @@
 // deterministic: one record per tile, reduced in fp64 by cer_enc_stats_reduce_f32).
 #include "common.hpp"
 #include <math.h>
+#include <stdlib.h>
+#include <type_traits>
 
 typedef _Float16 sm_half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 sm_half4 __attribute__((ext_vector_type(4)));
@@ -171,14 +173,231 @@ __global__ __launch_bounds__(256, 2) void enc_stem_s16_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------- round 4: producer / consumer form
+// The kernel above runs stage -> barrier -> MFMA -> epilogue -> barrier in every wave: 27.6 k cycles per tile and block (two
+// blocks per CU) against 2.7 k of matrix work and ~5 k cycles of memory time per tile and CU.  Here, as in enc_pc.hip, a 512-thread
+// persistent block (one per CU) is split by role: waves 0-3 fetch the NEXT tile's input patch as 16-byte loads of an aligned
+// superset of its columns (patch column c = image column 64 tx - 4 + c; the kernel row is packed with its zero padding in FRONT so
+// that the fragments stay 16-byte aligned: cer_enc_stem_s16_pack's second layout), normalise, split with v_fma_mix and fill one of
+// two LDS patches; waves 4-7 multiply (orientation pixels x channels: a lane ends up with one channel of 16 pixels, so the
+// statistics are in-lane sums) and store through a wave-private LDS transpose as 16-byte stores.  One s_barrier per tile.
+// Needs W % 4 == 0 and a 16-byte aligned image base; everything else takes the kernel above.
+#define SP_PATCH (2 * SM_PLANE)                    // hi plane | lo plane of one patch
+#define SP_RED (2 * 4 * 32 * 2 * 4)                // statistics patches: [parity][consumer wave][channel][2]
+#define SP_TR (4 * 32 * 36 * 4)                    // epilogue transposes: 32 pixels x 32 channels (pitch 36) per consumer wave
+#define SP_SMEM (2 * SP_PATCH + SP_RED + SP_TR)
+
+__device__ __forceinline__ void sp_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__global__ __launch_bounds__(512, 2) void enc_stem_pc_kernel(const float* __restrict__ img, const _Float16* __restrict__ wpk,
+                                                             const float* __restrict__ bias, float* __restrict__ out, float* __restrict__ part,
+                                                             int H, int W, int ho, int wo, int tiles_x, int tiles_per_img, int total,
+                                                             int normalize, float invS) {
+    extern __shared__ __attribute__((aligned(16))) char sp_smem[];
+    float* red = reinterpret_cast<float*>(sp_smem + 2 * SP_PATCH);
+    float* trp = reinterpret_cast<float*>(sp_smem + 2 * SP_PATCH + SP_RED);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // work order as in enc_pc.hip: the 32 blocks of an XCD (block b: XCD b % 8) take vertically adjacent tiles of a column-major
+    // enumeration, so that the 5 patch rows two such tiles share come from that XCD's L2
+    const int G = (int)gridDim.x;
+    const int woff = (G % 8 == 0) ? ((int)blockIdx.x % 8) * (G / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
+    const int ntile = max(0, (total - woff + G - 1) / G);
+    const int tiles_y = tiles_per_img / tiles_x;
+    auto work_tile = [&](int k, int& n, int& t, int& ty, int& tx) {
+        const int widx = woff + k * G;
+        n = widx / tiles_per_img;
+        const int c = widx - n * tiles_per_img;
+        tx = c / tiles_y;
+        ty = c - tx * tiles_y;
+        t = ty * tiles_x + tx;
+    };
+    const long plane = (long)H * W;
+    const long Po = (long)ho * wo;
+    if (wave < 4) {
+        // ---------------- producers: item = (patch row r, column quad q): three 16-byte loads (one per colour plane) -> 4 pixels x
+        // [3 channels + zero] halves, hi and lo: two ds_write_b128 each.  378 items per tile: 256 + 122.
+        constexpr int NQ = SM_PC / 4, ITEMS = SM_PR * NQ;                  // 18, 378
+        const float nsc = normalize ? (2.0f / 255.0f) * (float)(1 << SM_XLOG2) : (float)(1 << SM_XLOG2);
+        const float nof = normalize ? -(float)(1 << SM_XLOG2) : 0.f;
+        float4 px[2][3];
+        auto request = [&](int k) {
+            int n, t, ty, tx;
+            work_tile(k, n, t, ty, tx);
+            const int iy0 = 2 * ty * SM_TH - 3, ix0 = 2 * tx * SM_TW - 4;
+            const float* im = img + (long)n * 3 * plane;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx / NQ, q = idx - r * NQ;
+                const int iy = iy0 + r, ix = ix0 + 4 * q;
+                const bool ok = idx < ITEMS && iy >= 0 && iy < H && ix >= 0 && ix < W;     // (W % 4 == 0: a quad is inside or outside as a whole)
+                const float* p = im + (long)(ok ? iy : 0) * W + (ok ? ix : 0);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    px[i][c] = cer_ld4(p + c * plane);
+                    if (!ok) px[i][c] = make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);     // marker: the quad is zero padding (of the NORMALISED image)
+                }
+            }
+        };
+        auto stage = [&](int k) {
+            char* buf = sp_smem + (k & 1) * SP_PATCH;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + 256 * i;
+                if (idx < ITEMS) {
+                    const bool pad = px[i][0].x != px[i][0].x;
+                    const float v[3][4] = {{px[i][0].x, px[i][0].y, px[i][0].z, px[i][0].w}, {px[i][1].x, px[i][1].y, px[i][1].z, px[i][1].w},
+                                           {px[i][2].x, px[i][2].y, px[i][2].z, px[i][2].w}};
+                    unsigned hw[8], lw[8];                                 // pixel j: words 2j (channels 0, 1), 2j + 1 (channel 2, zero)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float y[3];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float t_ = __builtin_amdgcn_fmed3f(fmaf(v[c][j], nsc, nof), -65504.0f, 65504.0f);
+                            y[c] = pad ? 0.f : t_;
+                        }
+                        const float one = 1.0f, mone = -1.0f;
+                        unsigned h0, h1 = 0, l0, l1 = 0;
+                        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h0) : "v"(y[0]), "s"(one));
+                        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h0) : "v"(y[1]), "s"(one));
+                        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(h1) : "v"(y[2]), "s"(one));
+                        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h0), "s"(mone), "v"(y[0]));
+                        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l0) : "v"(h0), "s"(mone), "v"(y[1]));
+                        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "+v"(l1) : "v"(h1), "s"(mone), "v"(y[2]));
+                        hw[2 * j] = h0; hw[2 * j + 1] = h1; lw[2 * j] = l0; lw[2 * j + 1] = l1;
+                    }
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4* dh = reinterpret_cast<u32x4*>(buf + idx * 32);
+                    u32x4* dl = reinterpret_cast<u32x4*>(buf + SM_PLANE + idx * 32);
+                    dh[0] = (u32x4){hw[0], hw[1], hw[2], hw[3]};
+                    dh[1] = (u32x4){hw[4], hw[5], hw[6], hw[7]};
+                    dl[0] = (u32x4){lw[0], lw[1], lw[2], lw[3]};
+                    dl[1] = (u32x4){lw[4], lw[5], lw[6], lw[7]};
+                }
+            }
+        };
+        auto finalize = [&](int k) {                                       // statistics record of tile k: the four consumer waves in order
+            if (!part || tid >= 64) return;
+            int n, t, ty, tx;
+            work_tile(k, n, t, ty, tx);
+            const int tile_ = n * tiles_per_img + t;
+            const int c = tid >> 1, w2 = tid & 1;
+            const float* r = red + (k & 1) * (4 * 32 * 2);
+            part[((long)tile_ * 32 + c) * 2 + w2] = r[(0 * 32 + c) * 2 + w2] + r[(1 * 32 + c) * 2 + w2] + r[(2 * 32 + c) * 2 + w2] + r[(3 * 32 + c) * 2 + w2];
+        };
+        if (ntile > 0) request(0);
+        for (int k = 0; k < ntile; ++k) {
+            stage(k);
+            if (k + 1 < ntile) request(k + 1);
+            sp_barrier();                                                  // #k: patch k & 1 is complete
+            if (k >= 1) finalize(k - 1);
+        }
+        sp_barrier();                                                      // #ntile
+        if (ntile >= 1) finalize(ntile - 1);
+    } else {
+        // ---------------- consumers: wave cw owns output rows 2 cw, 2 cw + 1 of the tile
+        const int cw = wave - 4;
+        const int li = lane & 31, kg = lane >> 5;
+        sm_half8 wh[SM_STEPS], wl[SM_STEPS];
+        const _Float16* wp2 = wpk + (long)SM_STEPS * 2 * 64 * 8;          // second layout: kernel rows with the padding column in front
+#pragma unroll
+        for (int s = 0; s < SM_STEPS; ++s) {
+            wh[s] = *reinterpret_cast<const sm_half8*>(wp2 + ((s * 2 + 0) * 64 + lane) * 8);
+            wl[s] = *reinterpret_cast<const sm_half8*>(wp2 + ((s * 2 + 1) * 64 + lane) * 8);
+        }
+        const float bch = bias[li];
+        float* Et_w = trp + cw * (32 * 36) + 4 * kg * 36 + li;
+        const float* Et_r = trp + cw * (32 * 36) + (lane >> 3) * 36 + 4 * (lane & 7);
+        const int abase = (2 * (2 * cw) * SM_PC + 2 * li + 2 * kg) * 8;
+        for (int k = 0; k < ntile; ++k) {
+            int n, t, ty, tx;
+            work_tile(k, n, t, ty, tx);
+            const int oy0 = ty * SM_TH + 2 * cw, ox0 = tx * SM_TW;
+            sp_barrier();                                                  // #k
+            const char* patch = sp_smem + (k & 1) * SP_PATCH + abase;
+            sm_floatx16 acc[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+            sm_half8 xh[2], xl[2];
+            auto load_x = [&](int s) {
+                const int off = ((s >> 1) * SM_PC + 4 * (s & 1)) * 8;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    xh[m] = *reinterpret_cast<const sm_half8*>(patch + off + m * 2 * SM_PC * 8);
+                    xl[m] = *reinterpret_cast<const sm_half8*>(patch + SM_PLANE + off + m * 2 * SM_PC * 8);
+                }
+            };
+            load_x(0);
+#pragma unroll
+            for (int s = 0; s < SM_STEPS; ++s) {
+                const sm_half8 h0 = xh[0], h1 = xh[1], l0 = xl[0], l1 = xl[1];
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 1 < SM_STEPS) load_x(s + 1);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, wh[s], acc[0], 0, 0, 0);       // rows = pixels, columns = channels
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, wh[s], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, wl[s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, wl[s], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(l0, wh[s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(l1, wh[s], acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- epilogue: acc[m][r] = 2^(14 + kw) conv of channel li at pixel (oy0 + m, ox0 + (r & 3) + 8 (r >> 2) + 4 kg)
+            float ssum = 0.f, ssq = 0.f;
+            auto epilogue = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int gy = oy0 + m;
+                    float* o = out + ((long)n * Po + (long)gy * wo + ox0) * 32;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int pxc = (r & 3) + 8 * (r >> 2);
+                        const float v = fmaf(acc[m][r], invS, bch);
+                        if (FULL || (gy < ho && ox0 + pxc + 4 * kg < wo)) {
+                            ssum += v;
+                            ssq = fmaf(v, v, ssq);
+                        }
+                        Et_w[pxc * 36] = v;
+                    }
+                    const int lane_off = (lane >> 3) * 32 + 4 * (lane & 7);
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const float4 v4 = *reinterpret_cast<const float4*>(Et_r + 8 * jj * 36);
+                        if (FULL || (gy < ho && ox0 + (lane >> 3) + 8 * jj < wo)) *reinterpret_cast<float4*>(o + lane_off + 8 * jj * 32) = v4;
+                    }
+                }
+            };
+            if (oy0 + 2 <= ho && ox0 + 32 <= wo) epilogue(std::true_type{});
+            else epilogue(std::false_type{});
+            if (part) {
+                const float s2 = ssum + __shfl_xor(ssum, 32), q2 = ssq + __shfl_xor(ssq, 32);
+                if (kg == 0) {
+                    float* r = red + (k & 1) * (4 * 32 * 2) + (cw * 32 + li) * 2;
+                    r[0] = s2;
+                    r[1] = q2;
+                }
+            }
+        }
+        sp_barrier();                                                      // #ntile
+    }
+}
+
 // ---------------------------------------------------------------------------------------- host side
-extern "C" long cer_enc_stem_s16_packed_size(void) { return (long)SM_STEPS * 2 * 64 * 8; }     // halves
+extern "C" long cer_enc_stem_s16_packed_size(void) { return 2L * SM_STEPS * 2 * 64 * 8; }     // halves: two layouts (below)
 
 extern "C" int cer_enc_stem_s16_tiles(int ho, int wo) { return ((ho + SM_TH - 1) / SM_TH) * ((wo + SM_TW - 1) / SM_TW); }
 
 // w_oihw [32][3][7][7] (host) -> A fragments [step][hi | lo][lane][8]: lane (channel = lane & 31, kg = lane >> 5), element e:
 // ky = step >> 1, column = 4 (step & 1) + 2 kg + (e >> 2), input channel = e & 3 (column 7 and channel 3 are padding: zero).
-// *log2s_w = the power-of-two weight scale that was applied.
+// A second copy follows with the padding column in FRONT (kernel column = that index - 1): the layout of enc_stem_pc_kernel, whose
+// patch starts one image column earlier (16-byte aligned loads).  *log2s_w = the power-of-two weight scale that was applied.
 extern "C" int cer_enc_stem_s16_pack(const float* w_oihw, void* packed_v, int* log2s_w) {
     if (!w_oihw || !packed_v || !log2s_w) return CER_EINVAL;
     double wmax = 0.0;
@@ -189,18 +408,20 @@ extern "C" int cer_enc_stem_s16_pack(const float* w_oihw, void* packed_v, int* l
     *log2s_w = k;
     const float sc = ldexpf(1.0f, k);
     _Float16* packed = static_cast<_Float16*>(packed_v);
-    for (int s = 0; s < SM_STEPS; ++s)
-        for (int lane = 0; lane < 64; ++lane)
-            for (int e = 0; e < 8; ++e) {
-                const int ch = lane & 31, kg = lane >> 5;
-                const int ky = s >> 1, col = 4 * (s & 1) + 2 * kg + (e >> 2), ci = e & 3;
-                float v = 0.f;
-                if (col < 7 && ci < 3) v = w_oihw[((ch * 3 + ci) * 7 + ky) * 7 + col] * sc;
-                const _Float16 hi = (_Float16)v;
-                const _Float16 lo = (_Float16)(v - (float)hi);
-                packed[((long)(s * 2 + 0) * 64 + lane) * 8 + e] = hi;
-                packed[((long)(s * 2 + 1) * 64 + lane) * 8 + e] = lo;
-            }
+    for (int layout = 0; layout < 2; ++layout)
+        for (int s = 0; s < SM_STEPS; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int ch = lane & 31, kg = lane >> 5;
+                    const int ky = s >> 1, col = 4 * (s & 1) + 2 * kg + (e >> 2) - layout, ci = e & 3;
+                    float v = 0.f;
+                    if (col >= 0 && col < 7 && ci < 3) v = w_oihw[((ch * 3 + ci) * 7 + ky) * 7 + col] * sc;
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    _Float16* dst = packed + (long)layout * SM_STEPS * 2 * 64 * 8;
+                    dst[((long)(s * 2 + 0) * 64 + lane) * 8 + e] = hi;
+                    dst[((long)(s * 2 + 1) * 64 + lane) * 8 + e] = lo;
+                }
     return CER_OK;
 }
 
@@ -219,6 +440,21 @@ extern "C" int cer_enc_stem_s16(const float* images, const void* packed_w, const
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
         if (ncu <= 0) ncu = 256;
+    }
+    if (W % 4 == 0 && cer_aligned16(images) && !getenv("CER_STEM_TILED")) {       // producer / consumer form: 16-byte image loads
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        static bool raised[64];
+        if (dev < 0 || dev >= 64 || !raised[dev]) {
+            hipError_t e = hipFuncSetAttribute((const void*)enc_stem_pc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SP_SMEM);
+            if (e != hipSuccess) return (int)e;
+            if (dev >= 0 && dev < 64) raised[dev] = true;
+        }
+        hipLaunchKernelGGL(enc_stem_pc_kernel, dim3((unsigned)(total < ncu ? total : ncu)), dim3(512), SP_SMEM, (hipStream_t)stream, images,
+                           (const _Float16*)packed_w, bias, out, stats_partial, H, W, ho, wo, tiles_x, (int)per_img, (int)total, normalize,
+                           ldexpf(1.0f, -(SM_XLOG2 + log2s_w)));
+        CER_RETURN_IF_LAUNCH_FAILED();
+        return CER_OK;
     }
     const unsigned grid = (unsigned)(total < 2L * ncu ? total : 2L * ncu);
     hipLaunchKernelGGL(enc_stem_s16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, images, (const _Float16*)packed_w, bias, out,

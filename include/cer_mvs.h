@@ -368,7 +368,8 @@ int cer_norm_act_f32(const float* x, const float* x_stats, const float* res, con
 int cer_enc_stem_tiles(int ho, int wo);
 /* The stem on the matrix cores (csrc/enc_stem.hip): same operands and outputs as cer_enc_stem_f32, single-accumulator split-f16
  * MFMA arithmetic (fp32-class).  Weights are packed once on the host from OIHW [32][3][7][7] (cer_enc_stem_s16_pack returns the
- * power-of-two weight scale it applied in *log2s_w; packed buffer: cer_enc_stem_s16_packed_size() halves); stats_partial is
+ * power-of-two weight scale it applied in *log2s_w; packed buffer: cer_enc_stem_s16_packed_size() halves = two fragment layouts,
+ * the second for the round-4 producer / consumer kernel that serves W % 4 == 0 images with 16-byte loads); stats_partial is
  * [N][cer_enc_stem_s16_tiles(ho, wo)][32][2] (8 x 32-pixel output tiles). */
 long cer_enc_stem_s16_packed_size(void);
 int cer_enc_stem_s16_tiles(int ho, int wo);

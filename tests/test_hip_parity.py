@@ -590,12 +590,13 @@ def test_hip_encoder_engine_matches_oracle(dev, which, size):
     assert rel_l1(got, ref) < 1e-5
 
 
-@pytest.mark.parametrize("size", [(64, 96), (70, 130), (37, 51)])
+@pytest.mark.parametrize("size", [(64, 96), (70, 130), (37, 51), (70, 132), (37, 52), (150, 260)])
 @pytest.mark.parametrize("raw", [False, True])
 def test_stem_on_matrix_cores(dev, size, raw):
     """7x7 stride-2 stem (core/extractor.py:81,145; raw: with the x * 2/255 - 1 of core/raft.py:40-41 folded in): the MFMA kernel
     (csrc/enc_stem.hip: K padded to 7 x 32, split-f16 single accumulator) and the direct fp32 kernel against an fp64 conv, incl.
-    ragged sizes (partial tiles, odd widths) and the per-tile (sum, sum of squares) records of the following instance norm."""
+    ragged sizes (partial tiles, odd widths) and the per-tile (sum, sum of squares) records of the following instance norm.
+    Widths that are multiples of 4 run the round-4 producer / consumer form (16-byte image loads), the others the round-2 kernel."""
     import ctypes
     from cer_mvs_amd import _lib as L
     H, W = size

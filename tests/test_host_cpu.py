@@ -98,16 +98,23 @@ def test_argument_errors_of_the_conv_and_encoder_entry_points():
     assert lib.cer_enc_conv_tiles(296, 400, 1, 9, 64) == 13 * 37 and lib.cer_enc_conv_tiles(296, 400, 2, 9, 64) == 13 * 148
     assert lib.cer_enc_stem_tiles(592, 800) == 925          # 592 rows x 400 pixel PAIRS / 256 threads
     assert lib.cer_enc_stem_s16_tiles(592, 800) == 74 * 25 and lib.cer_enc_stem_s16_tiles(9, 33) == 4      # 8 x 32-pixel tiles
-    assert lib.cer_enc_stem_s16_packed_size() == 14 * 2 * 64 * 8
+    assert lib.cer_enc_stem_s16_packed_size() == 2 * 14 * 2 * 64 * 8          # two layouts: round-2 kernel | producer / consumer kernel
+    assert lib.cer_enc_pc_supported(32, 32, 9, 1, 0) == 1 and lib.cer_enc_pc_supported(64, 64, 9, 1, 0) == 1 and lib.cer_enc_pc_supported(128, 128, 9, 1, 0) == 0
+    assert lib.cer_enc_pc_tiles(296, 400, 64, 9, 1) == 13 * 37 and lib.cer_enc_pc_tiles(296, 400, 64, 9, 2) == 13 * 148 and lib.cer_enc_pc_tiles(296, 400, 128, 1, 1) == 13 * 74
+    assert lib.cer_enc_pc_conv(fake, null, null, null, 1, null, fake, null, fake, null, null, 1, 8, 8, 48, 64, 9, 1, 0, 0, 1.0, null) == -2     # shape outside the HR encoder's
+    assert lib.cer_enc_pc_conv(null, null, null, null, 1, null, fake, null, fake, null, null, 1, 8, 8, 32, 32, 9, 1, 0, 0, 1.0, null) == -1
+    assert lib.cer_enc_pc_conv(fake, null, null, null, 1, fake, fake, null, fake, null, null, 1, 8, 8, 32, 32, 9, 1, 0, 0, 1.0, null) == -1     # merged_out needs srcB
     import numpy as np
     w = np.zeros((32, 3, 7, 7), dtype=np.float32)
     w[5, 1, 2, 6] = 0.75                                    # channel 5, ci 1, ky 2, kx 6 -> step 2*2 + 1, kg 1, element 0*4 + 1
-    pk = np.zeros(14 * 2 * 64 * 8, dtype=np.float16)
+    pk = np.zeros(lib.cer_enc_stem_s16_packed_size(), dtype=np.float16)
     k = ctypes.c_int(0)
     assert lib.cer_enc_stem_s16_pack(w.ctypes.data_as(ctypes.c_void_p), pk.ctypes.data_as(ctypes.c_void_p), ctypes.byref(k)) == 0
     assert k.value == 14                                    # 0.75 * 2^14 = 12288 < 16384
-    pk = pk.reshape(14, 2, 64, 8)
-    assert pk[5, 0, 32 + 5, 1] == 12288.0 and np.count_nonzero(pk) == 1
+    pk = pk.reshape(2, 14, 2, 64, 8)
+    assert pk[0, 5, 0, 32 + 5, 1] == 12288.0 and np.count_nonzero(pk[0]) == 1
+    # second layout (producer / consumer kernel): the padding column in front, i.e. kernel column 6 sits at index 7 = 4 * 1 + 2 * 1 + 1
+    assert pk[1, 5, 0, 32 + 5, 4 + 1] == 12288.0 and np.count_nonzero(pk[1]) == 1
     assert lib.cer_enc_stem_s16_pack(None, pk.ctypes.data_as(ctypes.c_void_p), ctypes.byref(k)) == -1
     assert lib.cer_enc_merge_f32(fake, null, null, null, fake, 1, 10, 30, 0, null) == -2                      # C % 4
     assert lib.cer_delta_sum_f32(null, 2, 0.0, fake, fake, null, 4, 4, null) == -1

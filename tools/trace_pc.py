@@ -38,6 +38,15 @@ for _ in range(3):
     e1.record()
 torch.cuda.synchronize()
 print(f"{which} dual={dual}: launch {e0.elapsed_time(e1) * 1e3:.1f} us (trace build)")
+# sustained: 30 launches back to back (does the chip hold its clock under this kernel?)
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(31)]
+ev[0].record()
+for i in range(30):
+    eng._pc(c, inp, N, h, w, out2=trace, want_stats=False)
+    ev[i + 1].record()
+torch.cuda.synchronize()
+ts = [ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(30)]
+print("  sustained launches (us): " + " ".join(f"{t:.0f}" for t in ts))
 t = trace.view(torch.int64).cpu().numpy().reshape(nblocks, 8, 8).astype(np.float64)
 P, Cw = t[:, :4], t[:, 4:]
 units, tiles = P[:, :, 7].mean(), Cw[:, :, 7].mean()
