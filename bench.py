@@ -64,9 +64,11 @@ def parse():
                          "of the multi-rank code path on a box with fewer GPUs than ranks: ranks share devices)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "amp"])
     ap.add_argument("--encoder", default="hip", choices=["hip", "miopen"], help="encoder backend: channels-last HIP engine or PyTorch-ROCm (MIOpen)")
-    ap.add_argument("--gru-precision", default="s16f8", choices=["s16f8", "s16", "f16x3", "fp32"],
+    ap.add_argument("--gru-precision", default="auto", choices=["auto", "s16f8", "s16", "f16x3", "fp32"],
                     help="arithmetic of the update block's 3x3 convs: split-f16 MFMA (s16f8: correction terms on the fp8 matrix instruction, "
-                         "4e-6 from fp32; s16: all-f16, fp32-class, one accumulator; f16x3: round-1 kernels), or exact fp32 MFMA")
+                         "4e-6 from fp32; s16: all-f16, fp32-class, one accumulator; f16x3: round-1 kernels), or exact fp32 MFMA.  auto (the "
+                         "product's default): s16f8 if the model's first forward agrees with s16 within 2.5e-5 relative L1, else s16 - the "
+                         "calibration forward runs in the warm-up; the JSON line says which form the timed region used")
     return ap.parse_args()
 
 
@@ -274,6 +276,10 @@ def main():
         args.mode = min(ok, key=lambda m: modes[m]["ms_per_step"])
     shard = world > 1 and args.mode in ("shard", "views")
     elapsed, out, model, inputs, scale, sd = timed_run(args.mode)
+    requested_precision = args.gru_precision
+    if args.gru_precision == "auto":     # the form the calibration kept (cer-mvs_amd/raft.py: RAFT._forward_calibrating) is what was timed
+        assert model.auto_choice in ("s16f8", "s16"), "the warm-up did not calibrate gru_precision='auto'"
+        args.gru_precision = model.auto_choice
     if modes is not None:
         modes[args.mode].update(value=args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps, headline=True)
     maps = args.steps * (world if (world > 1 and not shard) else 1)
@@ -425,6 +431,11 @@ def main():
                         "end to end, bar 1e-4]" if args.gru_precision == "s16f8" else
                         " [dense convs: f32 operands split into 2 x f16, 3 MFMAs per product, f32 accumulate - fp32-class]" if split else ""),
             "data": "synthetic",
+            "gru_precision": {"requested": requested_precision, "timed": args.gru_precision,
+                              **({"calibration_rel_l1_s16f8_vs_s16": model.auto_error, "tolerance": model.AUTO_TOL,
+                                  "note": "gru_precision='auto': the first forward of a set of weights runs in both split-f16 forms (inside the "
+                                          "warm-up); the fp8-correction form is kept only if the two agree within the tolerance"}
+                                 if requested_precision == "auto" else {})},
             "config": {"workload": args.workload, "image": f"{W}x{H}", "src_views": V, "cascade": cascade,
                        "gru_iters": sum(c[2] for c in cascade),
                        "depth_maps_in_flight": getattr(timed_run, "streams", 1),

@@ -20,12 +20,22 @@ extern "C" int cer_device_count(void) {
     return n;
 }
 
-// ---- sticky overflow flag: a caller-owned device int; kernels that saturate a split-f16 operand or into it (bit 1: feature rows of
-// the cost volume, cer_feat_split_f16 takes its flag explicitly; bit 2: the hidden map of the fused delta head; cer_f16_scan_overflow
-// sets the bit it is given).  One per process (one process per GPU); NULL (default) disables the in-kernel checks.
-static int* g_overflow_flag = nullptr;
-int* cer_overflow_flag_get() { return g_overflow_flag; }
+// ---- sticky overflow flag: a caller-owned device int PER DEVICE; kernels that saturate a split-f16 operand or into it (bit 1:
+// feature rows of the cost volume, cer_feat_split_f16 takes its flag explicitly; bit 2: the hidden map of the fused delta head;
+// cer_f16_scan_overflow sets the bit it is given).  cer_overflow_flag registers the flag for the CURRENT device (hipGetDevice) and a
+// launch uses the flag of the device it runs on - a process that drives two GPUs no longer lets the second registration redirect
+// the first GPU's kernels into foreign memory.  NULL (default) disables the in-kernel checks on that device.
+#define CER_MAX_DEVICES 64
+static int* g_overflow_flag[CER_MAX_DEVICES];
+int* cer_overflow_flag_get() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CER_MAX_DEVICES) return nullptr;
+    return g_overflow_flag[dev];
+}
 extern "C" int cer_overflow_flag(int* flag) {
-    g_overflow_flag = flag;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return flag ? CER_EINVAL : CER_OK;      // (no device: nothing to register; clearing is a no-op)
+    if (dev < 0 || dev >= CER_MAX_DEVICES) return CER_ESHAPE;
+    g_overflow_flag[dev] = flag;
     return CER_OK;
 }

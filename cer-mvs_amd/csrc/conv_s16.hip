@@ -28,78 +28,7 @@
 //   * the disparity encoder's 49 channels are generated from an LDS disparity tile: interior tiles use the collapsed 81-tap
 //     form (6 single-tap steps), border tiles the literal one (4 half-chunks x 9 taps) - same algebra as round 1;
 //   * the hoisted `init` term / bias is the accumulators' initial value (16-byte loads in the prologue).
-#include "common.hpp"
-#include <math.h>
-#include <type_traits>
-#include <stdlib.h>
-#include <string.h>
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef int intx8 __attribute__((ext_vector_type(8)));
-
-#define SX_TW 16                           // tile width in pixels
-#define SX_HW 18                           // halo columns
-#define SX_PITCH 20                        // LDS pixels per halo row (pitch % 4 == 0 keeps (q % 4) == (col % 4))
-#define SX_ROWB (SX_PITCH * 64)            // LDS bytes per halo row
-#define SX_ROWB8 (SX_PITCH * 128)          // ... of a 32-channel chunk in the fp8-correction form
-#define SX_DTW 24                          // disparity tile columns (halo + 3 each side)
-#define SX_EPI_DELTA 4
-#define SX_HID_LOG2 4                      // scale of the delta head's hidden activations (relu outputs)
-// Wait states (and a compiler memory barrier) behind the 16-byte LDS stores of the disparity generators: an EMPIRICAL margin.  One
-// generator variant produced intermittently wrong last tile rows and became clean with them; the cause was not identified (DESIGN.md 3g:
-// two candidate hardware hazards were excluded by micro-tests).  The form that ships never failed with or without them.
-#define SX_LDS_STORE_WAIT() asm volatile("s_nop 3" ::: "memory")
-#ifndef SX_TRACE
-#define SX_TRACE 0   // variant builds only (tools/trace_s16.py): per wave cycle stamps + HW_ID written to `aux2` (GATES: unused there)
-#endif
-
-struct S16Args {
-    const char* src[CER_CONV_MAX_SRC];     // tensors (frag16) first, the disparity source (fp32 [P]) last
-    int ch[CER_CONV_MAX_SRC];
-    int kind[CER_CONV_MAX_SRC];            // 2 = frag16 tensor, 1 = disparity
-    int nsrc;
-    const _Float16* wpk;                   // literal packing
-    const _Float16* wpk_c;                 // collapsed packing (interior tiles) or null
-    const float* bias;
-    const float* init;                     // acc32 layout
-    float* out;
-    float* out2;
-    const float* aux;
-    const float* aux2;
-    const void* edge;                      // rim-correction filters of the collapsed disparity form (cer_conv3x3_s16_edge_pack) or null
-    int h, w, cout, tiles_x, ntiles, ny, mtx, mty;
-    int border_first;                      // tiles on the image rim are given to the first blocks launched (see the kernel)
-    float S, invS;                         // accumulator = S * conv
-    float out_scale;                       // frag16 outputs
-    float aux_inv;                         // 1 / scale of the frag16 hidden state read by GATES / GRU
-    float disp_scale;                      // generated disparity features
-    float proj_inv;                        // DELTA: 1 / (hidden scale * w2 scale)
-    int out_split;
-    int* flag;                             // sticky overflow flag (cer_overflow_flag) or null
-};
-
-// ---- operand split: 8 fp32 -> hi | lo halves of v * scale (packed conversions)
-__device__ __forceinline__ void sx_split8(const float (&v)[8], float scale, half8& hi, half8& lo) {
-    cer_h2 h[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        cer_f2 x = (cer_f2){v[2 * i], v[2 * i + 1]} * scale;
-        x = __builtin_elementwise_min(__builtin_elementwise_max(x, (cer_f2){-65504.0f, -65504.0f}), (cer_f2){65504.0f, 65504.0f});
-        h[i] = __builtin_convertvector(x, cer_h2);
-        l[i] = __builtin_convertvector(x - __builtin_convertvector(h[i], cer_f2), cer_h2);
-    }
-    hi = (half8){h[0].x, h[0].y, h[1].x, h[1].y, h[2].x, h[2].y, h[3].x, h[3].y};
-    lo = (half8){l[0].x, l[0].y, l[1].x, l[1].y, l[2].x, l[2].y, l[3].x, l[3].y};
-}
-__device__ __forceinline__ void sx_join8(const half8 hi, const half8 lo, float inv, float (&v)[8]) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = ((float)hi[e] + (float)lo[e]) * inv;
-}
-// gate non-linearities on the hardware exp2 / rcp (1 ulp each; ~5 instructions instead of ~25 for expf + IEEE division: the
-// epilogue was VALU-bound).  Absolute error <= 3e-7 - the class of the fp32 accumulation that feeds them.
-__device__ __forceinline__ float sx_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
-__device__ __forceinline__ float sx_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
+#include "conv_s16_shared.hpp"
 
 struct SxStage {                           // what to put into the NEXT activation buffer
     int kind;                              // 0 nothing, 2 tensor half-chunk, 1 literal disparity group, 3 collapsed disparity group
@@ -1196,7 +1125,9 @@ static int sx_launch(S16Args& a, int epi, hipStream_t st) {
     a.border_first = a.edge && a.wpk_c && a.nsrc > 0 && a.kind[a.nsrc - 1] == 1 && a.ny == 1 && a.tiles_x >= 3 && tiles_y >= 3;
     dim3 grid((unsigned)(a.ntiles * a.ny)), block(256);
     if (smem > 64 * 1024) {                                // (two blocks per CU still fit: 2 x 74 KiB at most)
-        static bool raised[5] = {false, false, false, false, false};
+        static bool raised[64][5];                         // per device (the attribute is a per-device property of the function)
+        int dev_ = 0;
+        if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 0;
         const void* fn = nullptr;
         switch (epi) {
             case CER_EPI_LINEAR: fn = (const void*)conv3x3_s16_kernel<WM_, WN_, MT, CER_EPI_LINEAR, F8>; break;
@@ -1209,9 +1140,9 @@ static int sx_launch(S16Args& a, int epi, hipStream_t st) {
             if (epi == SX_EPI_DELTA) fn = (const void*)conv3x3_s16_kernel<WM_, WN_, MT, SX_EPI_DELTA, F8>;
         }
         if (!fn || epi < 0 || epi > 4) return CER_EINVAL;
-        if (!raised[epi]) {
+        if (!raised[dev_][epi]) {
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return CER_EINVAL;
-            raised[epi] = true;
+            raised[dev_][epi] = true;
         }
     }
     switch (epi) {

@@ -88,3 +88,14 @@ def max_int(value, group, device):
     t = torch.tensor([int(value)], dtype=torch.int32, device=device if on_dev else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return int(t.item())
+
+
+def max_float(value, group, device):
+    """MAX of a host float over the ranks of ``group`` (the calibration figure of gru_precision="auto": every rank takes the same decision)."""
+    import torch.distributed as dist
+    if group is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return float(value)
+    on_dev = dist.get_backend(group) == "nccl"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if on_dev else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())

@@ -73,17 +73,30 @@ def inference(test_loader, ckpt, output_folder, rescale=1, crop=None, do_report=
         model = RAFT(test_mode=True).cuda()
         if ckpt is not None:
             model.load_state_dict(torch.load(ckpt, map_location="cpu"), strict=True)
-    model.eval()
+    # the reference wraps its model in nn.DataParallel (inference.py:28-35): the pipeline works on the RAFT module itself
+    core = model.module if hasattr(model, "module") and isinstance(getattr(model, "module"), RAFT) else model
+    was_training = core.training
+    core.eval()
     output_folder = Path(output_folder)
     (output_folder / "depths").mkdir(exist_ok=True, parents=True)
     written = []
     from .pipeline import DepthMapPipeline
-    pipe = DepthMapPipeline(model, streams=1 if do_report else max(1, int(streams)))
+    # Depth maps in flight: each extra stream is a REPLICA of the model (weights, packed weights, feature buffers, workspaces: ~3.7 GB
+    # per replica at DTU size, ~32 GB at 3840x2160 x 15 views).  A sharded model (view_group) runs collectives inside its forward:
+    # replicas issuing them from several streams in rank-dependent order could deadlock, and a process group is not deep-copyable - one
+    # depth map at a time there (bench.py does the same).
+    n_streams = 1 if (do_report or getattr(core, "view_group", None) is not None) else max(1, int(streams))
+    pipe = DepthMapPipeline(core, streams=n_streams)
     pending = []
 
     def finish(entry):
         handle, name, nf = entry
         disp_est = pipe.result(handle)
+        # saturation of a split-f16 operand is an error, not a silent clamp: under the lazy policy the flag of forward k is polled when
+        # forward k + streams starts; nothing is written for a forward whose flag is already known to be set
+        bits = pipe.poll_overflow()
+        if bits:
+            core._raise_overflow(bits)
         if do_report:
             torch.cuda.synchronize()
             print(f"per view time: {time.time() - tic[0]}")
@@ -116,5 +129,18 @@ def inference(test_loader, ckpt, output_folder, rescale=1, crop=None, do_report=
                 finish(pending.pop(0))
         while pending:
             finish(pending.pop(0))
-    pipe.check_overflow()                                   # saturation of a split-f16 operand is an error, not a silent clamp
+    try:
+        pipe.check_overflow()                               # (reads the flag: covers the last forwards, whose snapshots nobody polled)
+    except RuntimeError:
+        # the files of the last `streams` forwards were written before their flags could be read: remove them rather than leave
+        # saturated depth maps next to good ones
+        for path in written[-len(pipe):]:
+            try:
+                Path(path).unlink()
+            except OSError:
+                pass
+        raise
+    finally:
+        if was_training:
+            core.train()
     return written

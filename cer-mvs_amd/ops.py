@@ -156,6 +156,14 @@ def feat_split(x, out=None):
 _LINES_WS = {}
 
 
+def release_lines_workspace(device, stream=None):
+    """Forget the workspace of ``stream`` (a torch.cuda.Stream) - or of every stream of ``device`` - so that its memory returns to the
+    caching allocator (every inference() call creates new streams; their entries used to accumulate)."""
+    dev = str(device)
+    for key in [k for k in _LINES_WS if k[0] == dev and (stream is None or k[1] == stream.cuda_stream)]:
+        del _LINES_WS[key]
+
+
 def lines_workspace(V, h1, w1, D, device):
     """The (persistent, per device and stream) workspace of the epipolar-line-tile cost volume: partial volumes + tile parameters."""
     return _lines_workspace(V, h1, w1, D, device)

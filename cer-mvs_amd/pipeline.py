@@ -83,3 +83,21 @@ class DepthMapPipeline:
 
     def check_overflow(self, raise_error=True):
         return self.models[0].check_overflow(self.device, raise_error=raise_error)
+
+    def poll_overflow(self):
+        """Bits of the last completed asynchronous flag snapshot (RAFT.overflow_policy "lazy"), 0 if clean or none is ready: never blocks."""
+        from . import ops
+        return ops.overflow_poll(self.device) or 0
+
+    def close(self):
+        """Drop the replicas and the per-stream workspaces of the cost volume (ops._LINES_WS holds ~300 MB per stream at DTU size)."""
+        from . import ops
+        for st in self.streams:
+            ops.release_lines_workspace(self.device, st)
+        self.models = self.models[:1]
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

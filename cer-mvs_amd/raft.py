@@ -35,7 +35,7 @@ _SIDE_STREAMS = {}
 
 class RAFT(nn.Module):
     def __init__(self, cascade=[(64, 64, 8), (-1, 320, 8)], encoder_type="HR", dim_fmap=64, dim_net=64, dim_inp=64,
-                 test_mode=False, precision="fp32", view_group=None, gru_precision="s16f8", encoder_backend="hip", shard="slab"):
+                 test_mode=False, precision="fp32", view_group=None, gru_precision="auto", encoder_backend="hip", shard="slab"):
         super().__init__()
         self.cascade = [tuple(c) for c in cascade]
         self.encoder_type = encoder_type
@@ -47,8 +47,20 @@ class RAFT(nn.Module):
         self.fnet = BasicEncoder(output_dim=dim_fmap, norm_fn="instance", type=encoder_type)
         self.cnet = BasicEncoder(output_dim=dim_net + dim_inp, norm_fn="none", type=encoder_type)
         self.update_block = UpdateBlock(cascade=self.cascade, dim_net=dim_net, dim_inp=dim_inp)
-        self.update_block.conv_mode = "s16" if gru_precision == "s16f8" else gru_precision
-        self.update_block.corr_fp8 = gru_precision == "s16f8"
+        if gru_precision not in ("auto", "s16f8", "s16", "f16x3", "fp32"):
+            raise ValueError(f"RAFT: unknown gru_precision {gru_precision!r}")
+        self.gru_precision = gru_precision
+        self.update_block.conv_mode = "s16" if gru_precision in ("s16f8", "auto") else gru_precision
+        self.update_block.corr_fp8 = gru_precision in ("s16f8", "auto")
+        # "auto" (default): the fp8-correction form keeps ~15 product bits in the correction terms; how much of that reaches the depth
+        # depends on how the update block's weights condition the 32-iteration recurrence (tests/test_determinism_gpu.py: 22-38 x the
+        # all-f16 form's distance from exact fp32 - 3e-6 on the golden weights, 3e-4 with the conv weights doubled and heavy-tailed).
+        # So the FIRST test-mode forward of a set of weights runs twice - "s16f8" and "s16" (fp32-class) - on its own input; if the two
+        # disparities differ by more than AUTO_TOL relative L1 the model keeps "s16" (with a warning), else "s16f8".  One extra forward
+        # per set of weights buys the 12 % of the fp8 form wherever it is safe, and the fp32-class margin wherever it is not.
+        self.auto_choice = None                   # None until calibrated; then "s16f8" or "s16"
+        self.auto_error = None                    # the measured relative L1 between the two forms
+        self._auto_sig = None
         self.encoder_backend = encoder_backend      # "hip": channels-last engine (csrc/enc_conv.hip); "miopen": PyTorch-ROCm convs
         self._engines = None
         self._src_buf = {}
@@ -264,7 +276,12 @@ class RAFT(nn.Module):
             bits = ops.overflow_poll(dev)              # what an EARLIER forward left (asynchronous snapshot: never blocks)
             if bits:
                 self._raise_overflow(bits)
+            if self.gru_precision == "auto" and self._auto_pending():
+                return self._forward_calibrating(images, poses, intrinsics, scale, do_report)
         elif self.overflow_policy in ("raise", "fallback") and self.view_group is None:
+            if self.gru_precision == "auto" and self._auto_pending():
+                self._forward_calibrating(images, poses, intrinsics, scale, do_report)        # (decides the form; the policy's own forward follows)
+                self.check_overflow(dev, raise_error=False)
             out = self._forward_fast(images, poses, intrinsics, scale, do_report)
             bits = self.check_overflow(dev, raise_error=self.overflow_policy == "raise")
             if bits:                                   # fallback: repeat with the wide-range arithmetic
@@ -278,10 +295,44 @@ class RAFT(nn.Module):
                     L.load().cer_cost_build_algo(algo)
                 ops.check_overflow(dev)
             return out
+        if self.gru_precision == "auto" and self._auto_pending():
+            return self._forward_calibrating(images, poses, intrinsics, scale, do_report)
         if self.overflow_policy == "fallback" and self.view_group is not None:
             raise NotImplementedError("RAFT.overflow_policy='fallback' is not available with view_group (every rank would have to repeat "
                                       "the forward together): use 'lazy' or 'raise'")
         return self._forward_fast(images, poses, intrinsics, scale, do_report)     # ("raise" with a view_group: handled at its end)
+
+    AUTO_TOL = 2.5e-5                             # a quarter of the 1e-4 parity bar
+
+    def _auto_pending(self):
+        return self.update_block.conv_mode == "s16" and self._auto_sig != self._params_sig()
+
+    def _forward_calibrating(self, images, poses, intrinsics, scale, do_report):
+        """gru_precision="auto": this set of weights has not been calibrated yet - run the forward in both split-f16 forms, keep the
+        fp8-correction form if it stays within AUTO_TOL of the fp32-class one on this input (all ranks of a view_group agree on the
+        worst rank's figure), and return the result of the form that was kept."""
+        ub = self.update_block
+        ub.corr_fp8 = True
+        out8 = self._forward_fast(images, poses, intrinsics, scale, do_report).clone()
+        ub.corr_fp8 = False
+        out16 = self._forward_fast(images, poses, intrinsics, scale, do_report)
+        if ub.conv_mode != "s16":                  # (the weights did not fit a shared split-f16 scale: the forward fell back to f16x3 kernels)
+            self._auto_sig = self._params_sig()
+            return out16
+        den = out16.abs().sum()
+        err = float(((out8 - out16).abs().sum() / den.clamp_min(1e-30)).item())
+        if self.view_group is not None:
+            err = cdist.max_float(err, self.view_group, images.device)
+        self.auto_error = err
+        ok = err == err and err <= self.AUTO_TOL
+        self.auto_choice = "s16f8" if ok else "s16"
+        ub.corr_fp8 = ok
+        self._auto_sig = self._params_sig()
+        if not ok:
+            import warnings
+            warnings.warn(f"cer-mvs_amd: gru_precision='auto': the fp8-correction form differs from the all-f16 form by {err:.2e} relative L1 on "
+                          f"this model's first input (tolerance {self.AUTO_TOL:.1e}): keeping gru_precision='s16' (fp32-class) for these weights")
+        return out8 if ok else out16
 
     def _forward_fast(self, images, poses, intrinsics, scale, do_report):
         self._validate_packs()

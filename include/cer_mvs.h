@@ -9,7 +9,9 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); the call only
  *     enqueues work on it and returns (asynchronous), so it is hipGraph-capturable;
  *   - return 0 on success, a negative CER_E* for an argument error (nothing was launched),
- *     or a positive hipError_t from the launch; never throws; stateless and re-entrant.
+ *     or a positive hipError_t from the launch; never throws.  Compute entry points keep no state between calls and are
+ *     re-entrant; the library holds exactly two process-wide switches, both set through their own entry points and read by later
+ *     launches: the per-device overflow flag (cer_overflow_flag) and the cost-volume algorithm selector (cer_cost_build_algo).
  *
  * Each function cites the reference interface (file:line under the reference tree) it
  * replaces.  INTEGRATION.md shows the binding a reference maintainer would add.
@@ -35,7 +37,8 @@ int cer_device_count(void);
 
 /* Saturation is never silent.  The split-f16 kernels clamp an operand whose scaled value leaves the f16 range (update block,
  * "s16" path: ReLU-class activations beyond 4094 = 65504 / 2^4; cost-volume feature rows beyond 1023).  cer_overflow_flag
- * registers a caller-owned DEVICE int (one per process; NULL = off, the default) that such kernels or into when they clamp in
+ * registers a caller-owned DEVICE int for the CURRENT device (hipGetDevice; one per device, NULL = off, the default; launches use
+ * the flag of the device they run on) that such kernels or into when they clamp in
  * registers (bit 2: the hidden map of the fused delta head, which never reaches memory).  Tensors that do reach memory are
  * checked after the fact: cer_f16_scan_overflow ors `bit` into *flag if any half of a split-f16 buffer (frag16 tensors, split
  * feature rows; `bytes` % 16 == 0) sits at the f16 maximum or is not finite.  The host reads the flag when convenient. */
@@ -111,7 +114,7 @@ int cer_cost_build_algo(int algo);
 
 /* ------------------------------------------------------------------------------------
  * The same cost volume (fold modes 1 / 2 of cer_cost_build_f32; C == 64, D <= 64) on epipolar-line tiles
- * (csrc/cost_lines.hip): per source view the reference grid is cut into 64-pixel digital lines along the view's
+ * (csrc/cost_lines.hip): per source view the reference grid is cut into 32-pixel digital lines along the view's
  * epipolar direction; per (view, tile) the dot products of the tile's reference rows with every texel of the tile's
  * epipolar band are MFMA products (split-f16, fp32-class) and every sample gathers its 4 dots from LDS.  Cells, weights
  * and the treatment of out-of-map / non-finite samples are those of cer_cost_build_f32 (same fp32 expressions); results

@@ -1,0 +1,224 @@
+"""Run-to-run determinism and the shipped regime.
+
+Two rounds in a row a kernel VARIANT produced timing-dependent wrong output (round 2: a lookup specialisation under GPU sharing;
+round 3: a disparity-generator variant of the s16 conv), was replaced by a form that never failed, and shipped without a root
+cause.  These tests are the guard on what ships: every epilogue / arithmetic form / tile height of the update-block convolutions,
+the lookup, the cost volume and the round-4 producer / consumer encoder kernels are launched hundreds of times on fixed inputs and
+must reproduce the first launch bit for bit; the shipped inference regime (three depth maps in flight at the bench workload) must
+reproduce the reference capture every time; and the default arithmetic (s16f8) must stay inside 5e-5 of the oracle when the
+weights get larger / heavier-tailed than the golden ones."""
+import pytest
+import torch
+
+from conftest import cached_scene, rel_l1
+from test_oracle_golden import hashed
+
+pytestmark = pytest.mark.gpu
+
+LAUNCHES = 200
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _nhwc(x):
+    return x[0].permute(1, 2, 0).reshape(-1, x.shape[1]).contiguous()
+
+
+def _repeat(fn, n=LAUNCHES):
+    """fn() -> tensor or tuple of tensors (may alias persistent buffers: compared against clones of the first result)."""
+    first, bad = None, 0
+    for _ in range(n):
+        out = fn()
+        out = out if isinstance(out, (tuple, list)) else (out,)
+        if first is None:
+            first = [o.clone() for o in out]
+            assert all(torch.isfinite(o.float()).all() for o in first)
+        elif not all(torch.equal(a, b) for a, b in zip(out, first)):
+            bad += 1
+    return bad
+
+
+@pytest.mark.parametrize("size", [(74, 100), (296, 400)], ids=["quarter", "bench"])
+@pytest.mark.parametrize("mt", [2, 4])
+@pytest.mark.parametrize("f8", [False, True], ids=["s16", "s16f8"])
+def test_update_block_convs_are_deterministic(dev, f8, mt, size):
+    """z|r gates, GRU blend, fused delta head, ReLU conv (corr2 shape) and the hoisted linear conv - rim tiles, interior tiles, partial
+    last tiles - 200 launches each, every output bit-identical to the first launch's."""
+    from cer_mvs_amd import _lib as L, ops
+    h, w = size
+    if size == (296, 400) and mt == 2:
+        pytest.skip("half-height tiles are selected for slabs only")
+    ops.TILE_MT = mt
+    try:
+        P = h * w
+        U, R, Dp = L.S16_UNIT, L.S16_RELU, L.S16_DISP
+        net = torch.tanh(hashed((1, 64, h, w), 901, -2, 2))
+        c2 = torch.relu(hashed((1, 64, h, w), 902, -1, 2))
+        disp = hashed((P,), 903, 0.0005, 0.0025).to(dev)
+        src = [(64, 2, U), (49, 1, Dp), (64, 2, R)]
+        pzr = ops.PackedConvS16(hashed((128, 177, 3, 3), 905, -0.05, 0.05), None, src, dev, corr_fp8=f8)
+        pq = ops.PackedConvS16(hashed((64, 177, 3, 3), 906, -0.05, 0.05), None, src, dev, corr_fp8=f8)
+        pr = ops.PackedConvS16(hashed((64, 64, 3, 3), 907, -0.05, 0.05), hashed((64,), 908, -0.1, 0.1), [(64, 2, R)], dev, corr_fp8=f8)
+        pd = ops.PackedConvS16(hashed((256, 64, 3, 3), 909, -0.08, 0.08), hashed((256,), 910, -0.1, 0.1), [(64, 2, U)], dev, corr_fp8=f8)
+        proj = ops.delta_proj_pack_s16(hashed((1, 256, 3, 3), 911, -0.05, 0.05), dev)
+        net_s = ops.to_frag16(_nhwc(net).to(dev), h, w, U)
+        c2_s = ops.to_frag16(_nhwc(c2).to(dev), h, w, R)
+        init = ops.s16_layout(hashed((P, 128), 904, -0.3, 0.3).to(dev), h, w, L.S16_ACC32)
+        initq = ops.s16_layout(hashed((P, 64), 912, -0.3, 0.3).to(dev), h, w, L.S16_ACC32)
+        z, rh = ops.conv3x3_s16(pzr, [net_s, disp, c2_s], h, w, L.EPI_GATES, aux=net_s, init=init, log2s_out=U, log2s_aux=U)
+        z, rh = z.clone(), rh.clone()
+        cases = {
+            "gates": lambda: ops.conv3x3_s16(pzr, [net_s, disp, c2_s], h, w, L.EPI_GATES, aux=net_s, init=init, log2s_out=U, log2s_aux=U),
+            "gru": lambda: ops.conv3x3_s16(pq, [rh, disp, c2_s], h, w, L.EPI_GRU, aux=net_s, aux2=z, init=initq, log2s_out=U, log2s_aux=U),
+            "delta": lambda: ops.conv3x3_s16(pd, [net_s], h, w, L.EPI_DELTA, aux=proj),
+            "relu": lambda: ops.conv3x3_s16(pr, [c2_s], h, w, L.EPI_RELU, log2s_out=R),
+            "linear": lambda: ops.conv3x3_s16(pzr, [net_s, disp, c2_s], h, w, L.EPI_LINEAR),
+        }
+        for name, fn in cases.items():
+            bad = _repeat(fn)
+            assert bad == 0, f"{name}: {bad} of {LAUNCHES - 1} launches differ from the first (f8={f8}, mt={mt}, {h}x{w})"
+        assert not ops.check_overflow(dev)
+    finally:
+        ops.TILE_MT = 0
+
+
+def test_lookup_and_cost_volume_are_deterministic(dev):
+    """cer_lookup_encode_f32 (persistent blocks, register prefetch) and cer_cost_lines_f32 (epipolar-line tiles + view reduction) on a
+    quarter-size scene: 200 launches, bit-identical."""
+    from cer_mvs_amd import RAFT, ops
+    from cer_mvs_amd.projective import pij_matrices
+    from cer_mvs_amd.synthetic import fill_state_dict
+    H, W, V = 592, 800, 4
+    images, poses, intr, scale = cached_scene(H, W, V, 21)
+    model = RAFT(test_mode=True)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=9))
+    model = model.to(dev).eval()
+    h, w = H // 4, W // 4
+    with torch.no_grad():
+        net, inp, f1, f2 = model.encode(images.to(dev).float(), list(range(1, V + 1)), raw=True)
+        p = poses.clone().float()
+        p[..., :3, 3] *= float(scale)
+        k = intr.clone().float()
+        k[:, :, :2] /= 4
+        Pij = pij_matrices(p[0], k[0], [0] * V, list(range(1, V + 1))).to(dev)
+        disp = torch.zeros(h * w, device=dev)
+        split = (ops.feat_split(f1), ops.feat_split(f2))
+        (D, incre, _) = model.stages()[0]
+        build = lambda: ops.cost_build(f1, f2, Pij, disp, D, incre, True, h, w, 3, fold=True, pyramid_scale=1.0 / V, split=split)
+        assert _repeat(build) == 0
+        vol, origin = build()
+        ub = model.update_block
+        ub.corr_fp8, ub.conv_mode = True, "s16"
+        pk = ub.packed(0, dev)
+        from cer_mvs_amd import _lib as L
+        d1 = torch.full((h * w,), 0.0012, device=dev)
+        look = lambda: ops.lookup_encode(vol, origin, d1, pk["w0t"], pk["b0"], D, incre, ub.num_levels, ub.radius, out_split=2, log2s=L.S16_RELU, img_w=w)
+        assert _repeat(look) == 0
+    assert not ops.check_overflow(dev)
+
+
+@pytest.mark.parametrize("which", ["fnet", "cnet"])
+def test_encoder_engine_is_deterministic(dev, which):
+    """The round-4 producer / consumer encoder (stem + convolutions with on-the-fly merges): 40 whole encoder passes over 3 images at
+    592 x 800 (partial tiles in both directions at quarter resolution), every output bit-identical to the first pass."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.encoder_hip import HipEncoder
+    from cer_mvs_amd.synthetic import fill_state_dict
+    images, _, _, _ = cached_scene(592, 800, 2, 21)
+    model = RAFT(test_mode=True)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=13))
+    eng = HipEncoder(getattr(model, which), dev)
+    x = images[0].float().to(dev)
+    with torch.no_grad():
+        if which == "fnet":
+            fn = lambda: eng.features(x, n_ref=1, raw=True)[:2]
+        else:
+            fn = lambda: eng.context(x[:1], raw=True)[:2]
+        assert _repeat(fn, 40) == 0
+
+
+def test_three_depth_maps_in_flight_reproduce_the_capture(dev, golden):
+    """The shipped inference regime: pipeline.DepthMapPipeline(streams=3) at BASELINE configs[1] (1600x1184, 10 views, 32 iterations),
+    36 forwards: each bit-identical to the first and within the bar of the reference's own output (tests/golden/e2e_cfg2.npz)."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.pipeline import DepthMapPipeline
+    from cer_mvs_amd.synthetic import fill_state_dict
+    g = golden("e2e_cfg2")
+    H, W, V = int(g["H"]), int(g["W"]), int(g["V"])
+    cascade = [tuple(int(x) for x in c) for c in g["cascade"]]
+    images, poses, intr, scale = cached_scene(H, W, V, int(g["scene_seed"]))
+    model = RAFT(cascade=cascade, test_mode=True)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(g["weight_seed"])))
+    model = model.to(dev).eval()
+    scene = (images.to(dev), poses.to(dev), intr.to(dev), scale)
+    pipe = DepthMapPipeline(model, streams=3)
+    ref = torch.from_numpy(g["disp"])
+    first, n = None, 0
+    for out in pipe.map([scene] * 36):
+        if first is None:
+            first = out.clone()
+            err = rel_l1(first.cpu(), ref)
+            print(f"three in flight, cfg2: rel-L1 vs the reference capture {err:.3e}")
+            assert err < 1e-4
+        else:
+            assert torch.equal(out, first), f"forward {n} differs from the first"
+        n += 1
+    assert n == 36 and pipe.check_overflow() == 0
+
+
+@pytest.mark.parametrize("tail", ["uniform", "heavy"])
+@pytest.mark.parametrize("gain", [1.0, 2.0, 4.0])
+def test_precision_margin_under_weight_gain(dev, gain, tail):
+    """the fp8-correction form keeps ~15 product bits in the update block's correction terms.  At 32 GRU iterations,
+    with the update block's conv weights scaled by 1 / 2 / 4 (and a heavy-tailed filler: 2 % of the weights 8 x larger), every
+    precision is run against the exact-fp32 kernels (gru_precision="fp32").  Measured (MI355X): s16f8 sits 22-38 x further from fp32
+    than the all-f16 forms - 3e-6 / 5e-6 at gain 1, 1.2e-5 at gain 2, but 2.8e-4 at gain 2 heavy-tailed and 5.2e-4 at gain 4 - so it
+    cannot be an unconditional default.  The default is "auto": the first forward of a set of weights runs both forms and keeps the
+    fp8 one only if they agree within RAFT.AUTO_TOL.  Asserted here: "auto" ends below 5e-5 (half the bar) wherever the recurrence
+    itself is well-conditioned, i.e. wherever the fp32-CLASS forms reproduce exact fp32 to 2e-5; at gain 4 heavy-tailed nothing does
+    (s16 / f16x3: 5e-3 - the GRU amplifies one-ulp differences), and there "auto" must simply have picked the fp32-class form."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.synthetic import fill_state_dict
+    import warnings
+    H, W, V = 160, 224, 3
+    cascade = [(64, 64, 16), (-1, 320, 16)]
+    images, poses, intr, scale = cached_scene(H, W, V, 33)
+    base = RAFT(cascade=cascade, test_mode=True)
+    sd = fill_state_dict(base.state_dict(), seed=41)
+    gen = torch.Generator().manual_seed(5)
+    for k_, v in sd.items():
+        if k_.startswith("update_block.") and k_.endswith("weight") and v.dim() == 4 and "delta" not in k_:
+            v = v * gain
+            if tail == "heavy":
+                m = torch.rand(v.shape, generator=gen) < 0.02
+                v = torch.where(m, v * 8.0, v)
+            sd[k_] = v
+    outs, choice = {}, None
+    for prec in ("fp32", "s16", "s16f8", "f16x3", "auto"):
+        model = RAFT(cascade=cascade, test_mode=True, gru_precision=prec)
+        model.load_state_dict(sd)
+        model = model.to(dev).eval()
+        model.overflow_policy = "ignore"
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            outs[prec] = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale).cpu()
+            if prec == "auto":
+                choice, cal = model.auto_choice, model.auto_error
+                again = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale).cpu()     # calibrated: one forward, same form
+                assert torch.equal(again, outs[prec]) and model.auto_choice == choice
+        assert torch.isfinite(outs[prec]).all()
+    e = {p: rel_l1(outs[p], outs["fp32"]) for p in ("s16", "s16f8", "f16x3", "auto")}
+    print(f"gain x{gain} {tail}: rel-L1 vs exact fp32: s16 {e['s16']:.2e}  s16f8 {e['s16f8']:.2e}  f16x3 {e['f16x3']:.2e}  auto {e['auto']:.2e} "
+          f"(kept {choice}, calibration {cal:.2e}; s16f8 / s16 = {e['s16f8'] / max(e['s16'], 1e-12):.0f})")
+    assert choice in ("s16f8", "s16")
+    assert torch.equal(outs["auto"], outs[choice])
+    if max(e["s16"], e["f16x3"]) < 2e-5:
+        assert e["auto"] < 5e-5
+        if e["s16f8"] > 5e-5:
+            assert choice == "s16"
+    else:
+        assert choice == "s16"
