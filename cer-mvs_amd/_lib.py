@@ -48,6 +48,7 @@ _SIGNATURES = {
     "cer_alt_corr_bwd_reduce_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "cer_cost_build_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _D, _I, _I, _I, _I, _F, _P]),
     "cer_cost_build_algo": (_I, [_I]),
+    "cer_conv3x3_s16_pc": (_I, [_I]),
     "cer_overflow_flag": (_I, [_P]),
     "cer_f16_scan_overflow": (_I, [_P, _L, _P, _I, _P]),
     "cer_feat_split_f16": (_I, [_P, _P, _L, _L, _I, _P, _P]),

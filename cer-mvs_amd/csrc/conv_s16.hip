@@ -1252,6 +1252,12 @@ extern "C" int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, con
     };
     // the fp8-correction kernels evaluate a disparity source in the collapsed form with the rim correction only
     if (corr_fp8 && nd == 1 && !(packed_collapsed && edge_w)) return CER_ESHAPE;
+    // round 4: the GRU loop's fp8-correction convolutions run with producer / consumer wave roles (conv_s16pc.hip) unless a tile
+    // height is forced (tests and experiments that address the kernels of this file)
+    if (corr_fp8 && tile_mt == 0) {
+        const int rc = sxpc_dispatch(a, epi, tile_mt, st);
+        if (rc != CER_ESHAPE) return rc;
+    }
     if (Cout % 128 == 0) {
         int mt = tile_mt;
         if (mt != 2 && mt != 4) mt = pick(2, 2, 4, Cout / 128) == 2 ? 2 : 4;

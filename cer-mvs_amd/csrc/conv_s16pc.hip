@@ -1,0 +1,772 @@
+// K3, round 4: the GRU loop's fp8-correction convolutions with PRODUCER / CONSUMER wave roles (reference: core/update.py:13-25,
+// 61-71,80-85,87-120; same operands, layouts, packed weights and arithmetic as conv3x3_s16_kernel<..., F8 = 1> in conv_s16.hip).
+//
+// Why.  In conv_s16.hip every wave stages its tile's halo, converts it to the f16 | fp8 operand slots, multiplies, and runs the
+// epilogue.  Its steady K-loop sits at the matrix-pipe floor, but prologue + disparity section + epilogue are 45 % of a block's
+// life, and the two co-resident blocks of a CU run in lock-step - both multiply, both idle the matrix pipe (33 % busy by PMC).
+// Here a 512-thread persistent block (one per CU) splits the work by role, as csrc/enc_pc.hip does for the encoders:
+//   * waves 0-3, PRODUCERS: stage the next 32-channel chunk of the halo tile (two 16-byte loads -> f16 hi slot + fp8 [hi | lo] slot),
+//     load the disparity tile and generate the six collapsed disparity groups, and run the VALU-heavy epilogue (gate non-linearities,
+//     GRU blend, hi | lo split, stores) of the PREVIOUS tile from accumulators the consumers left in LDS;
+//   * waves 4-7, CONSUMERS: nothing but fragment reads, MFMAs (two f16 + one scaled fp8 K = 64 instruction per tap and m-tile),
+//     register-resident weight slices from L2, the rim correction, and a 16-byte-per-lane dump of the accumulators.
+// The consumers run from one tile's last MFMA into the next tile's first; the matrix pipe only pauses for the dump.
+//
+// Barriers (s_barrier counts all eight waves; both roles execute the same sequence per tile).  Tile T, ng chunks, buffers c & 1:
+//   b_0(T)        producers: chunk 0 of T staged (before the dump of T-1 was even finished: right behind b_D(T-1))
+//                 consumers: accumulators of T-1 dumped                       -> consumers multiply chunk 0, producers run E-slices of T-1
+//   b_k(T), k>=1  producers: chunk k staged                                   -> the barrier sits in front of the LAST tap of chunk k-1
+//                 (that tap's fragments are already in registers), so chunk k's first fragments roll in behind it
+//   b_D(T)        producers: disparity groups generated (disparity source)    -> in front of the last tap of the last chunk
+//   (DELTA: b_R(T) between the consumers' partial tap planes in LDS and their reduction)
+// Happens-before per LDS region:
+//   chunk buffer c & 1: written (chunk c) between b_{c-1} and b_c - its previous contents, chunk c-2, were last READ in front of
+//     b_{c-1} (the reads of a chunk's last tap roll in before the barrier that precedes that tap) - read between b_c and b_{c+1};
+//     chunk 0 of T+1 is written behind b_D(T) (or b_{ng-1}(T)): buffer 0's chunk ng-2 of T was read in front of b_{ng-1}(T);
+//   disparity buffers: written between b_{ng-1}(T) and b_D(T), read between b_D(T) and b_0(T+1); next write behind b_{ng-1}(T+1);
+//   disparity tile (ldsD): written between b_{ng-3}(T) and b_{ng-2}(T), read by the generators behind b_{ng-2}(T) and by the
+//     consumers' rim correction in front of b_0(T+1);
+//   accumulator dump: written in front of b_0(T+1), read by the E-slices between b_0(T+1) and the last barrier of T+1, rewritten
+//     behind that barrier.
+#include "conv_s16_shared.hpp"
+
+#ifndef SXPC_TRACE
+#define SXPC_TRACE 0 // variant build (tools/trace_sxpc.py): per wave phase cycle sums written to aux2 of a GATES launch [blocks][8 waves][16] (u64)
+#endif
+#if SXPC_TRACE
+#define SXPC_T(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tsum[k] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define SXPC_T(k) do { } while (0)
+#endif
+#ifndef SXPC_ABL
+#define SXPC_ABL 0   // profiling ablations (variant builds, wrong results): 1 no E-slices, 2 no disparity generation, 4 staging without conversion, 8 no MFMAs
+#endif
+
+template <int WM_, int WN_, int MT>
+struct SxpcCfg {
+    static constexpr int TH = WM_ * 2 * MT, HR = TH + 2;
+    static constexpr int ABUF = HR * SX_ROWB8;                         // one 32-channel chunk of the halo tile (f16 | fp8 slots)
+    static constexpr int NPIX = HR * SX_HW, NITEM8 = NPIX * 4, ITEMS8 = (NITEM8 + 255) / 256;
+    static constexpr int DGRP = TH * SX_TW * 64;                       // one collapsed disparity group, own pixels only: hi | lo halves
+    static constexpr int DBUF = 6 * DGRP;
+    static constexpr int DROWS = HR + 6;
+    static constexpr int DTILE = DROWS * SX_DTW * 4;
+    static constexpr int DUMP = 4 * MT * 4096;                         // accumulators: [consumer wave][m][jp][q][lane][16 B]
+    static constexpr int RED = WN_ * MT * 9 * 32 * 4;                  // DELTA: partial tap planes
+    static constexpr int OFF_D = 2 * ABUF, OFF_T = OFF_D + DBUF, OFF_X = OFF_T + ((DTILE + 15) & ~15);
+    static constexpr int SMEM_MAX = OFF_X + (DUMP > RED ? DUMP : RED);
+};
+
+__device__ __forceinline__ void sxpc_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+#if SXPC_ABL & 8
+__device__ __forceinline__ floatx16 sxpc_keep16(half8 a_, half8 b_, floatx16 c_) { asm volatile("" :: "v"(a_), "v"(b_)); return c_; }
+__device__ __forceinline__ floatx16 sxpc_keep8(intx8 a_, intx8 b_, floatx16 c_) { asm volatile("" :: "v"(a_), "v"(b_)); return c_; }
+#define SXPC_MFMA16(a_, b_, c_) sxpc_keep16(a_, b_, c_)
+#define SXPC_MFMA8(a_, b_, c_) sxpc_keep8(a_, b_, c_)
+#else
+#define SXPC_MFMA16(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, 0, 0, 0)
+#define SXPC_MFMA8(a_, b_, c_) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a_, b_, c_, 0, 0, 0, 127, 0, 130)
+#endif
+
+struct SxpcTile { int tile_y, tile_x, by, ty0, tx0, nb0; bool interior; };
+
+template <int WM_, int WN_, int MT, int EPI, int DISP, int NG>
+__global__ __launch_bounds__(512, 2) void conv3x3_s16pc_kernel(const S16Args a, int total_work) {
+    using C = SxpcCfg<WM_, WN_, MT>;
+    constexpr int TH = C::TH, ABUF = C::ABUF;
+    constexpr int NB = WN_ * 32;
+    extern __shared__ __attribute__((aligned(16))) char sx_smem[];
+    char* const ldsDB = sx_smem + C::OFF_D;
+    float* const ldsD = reinterpret_cast<float*>(sx_smem + C::OFF_T);
+    char* const ldsX = sx_smem + C::OFF_X;
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 31, kg = lane >> 5;
+    const int NT = a.cout >> 5;
+    const int ntens = DISP ? a.nsrc - 1 : a.nsrc;
+    (void)ntens;
+    const float* dsrc = DISP ? reinterpret_cast<const float*>(a.src[a.nsrc - 1]) : nullptr;
+    constexpr int ng = NG;                                             // 32-channel chunks of the tensor sources (checked by the launcher)
+    const int nsteps_t = ng * 18;                                      // 16-channel steps of the tensor sources
+    const char* wbase = reinterpret_cast<const char*>(DISP ? a.wpk_c : a.wpk);
+    const long wstep = (long)NT * 2048;
+
+    // ---- work: index -> (tile, channel block); XCD-contiguous like conv_s16.hip's (block b runs on XCD b % 8)
+    const int G = (int)gridDim.x;
+    const int woff = (G % 8 == 0) ? ((int)blockIdx.x % 8) * (G / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
+    const int nwork = max(0, (total_work - woff + G - 1) / G);
+    auto work = [&](int j) {
+        SxpcTile t;
+        const int widx = woff + j * G;
+        const int tile = widx / a.ny;
+        t.by = widx - tile * a.ny;
+        t.tile_y = tile / a.tiles_x;
+        t.tile_x = tile - t.tile_y * a.tiles_x;
+        t.ty0 = t.tile_y * TH;
+        t.tx0 = t.tile_x * SX_TW;
+        t.nb0 = t.by * NB;
+        t.interior = t.ty0 >= 1 && t.ty0 + TH <= a.h - 1 && t.tx0 >= 1 && t.tx0 + SX_TW <= a.w - 1;
+        return t;
+    };
+    const int half = a.cout >> 1;
+
+    if (wave < 4) {
+        // ======================================================================================================== PRODUCERS
+        const int tid = threadIdx.x;                                   // 0 .. 255
+        const int pw = wave, wm = pw / WN_, wn = pw % WN_;             // the consumer wave whose accumulators this wave finishes
+        constexpr int ITEMS8 = C::ITEMS8, IB8 = ITEMS8;
+        uint4 raw8[IB8][2];
+        int st8_pk[ITEMS8];
+        auto describe = [&](int c, const char*& base, long& mtb) {     // chunk c of the tensor sources
+            int s = 0, g = c;
+            while (g >= (a.ch[s] >> 5)) { g -= a.ch[s] >> 5; ++s; }
+            base = a.src[s] + g * 4096;
+            mtb = (long)(a.ch[s] >> 4) * 2048;
+        };
+        auto items_of = [&](const SxpcTile& t) {                       // staging items of this lane for tile t: (halo pixel, hc, kg)
+#pragma unroll
+            for (int i = 0; i < ITEMS8; ++i) {
+                const int it = tid + 256 * i;
+                const int n = min(it >> 2, C::NPIX - 1);
+                const int r = n / SX_HW, c = n - r * SX_HW;
+                const int gy = t.ty0 + r - 1, gx = t.tx0 + c - 1;
+                const bool valid = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+                const int cy = min(max(gy, 0), a.h - 1), cx = min(max(gx, 0), a.w - 1);
+                st8_pk[i] = ((cy >> 1) * a.mtx + (cx >> 4)) | ((((cy & 1) << 4) | (cx & 15)) << 20) | ((valid ? 1 : 0) << 28) | ((it < C::NITEM8 ? 1 : 0) << 29);
+            }
+        };
+        auto stage_load = [&](int c) {
+            const char* base; long mtb;
+            describe(c, base, mtb);
+#pragma unroll
+            for (int i = 0; i < ITEMS8; ++i) {
+                const int pk = st8_pk[i], it = tid + 256 * i;
+                const char* p = base + (long)(pk & 0xFFFFF) * mtb + (((it >> 1) & 1) * 2048 + (it & 1) * 512 + ((pk >> 20) & 31) * 16);
+                raw8[i][0] = *reinterpret_cast<const uint4*>(p);
+                raw8[i][1] = *reinterpret_cast<const uint4*>(p + 1024);
+            }
+        };
+        auto stage_store = [&](int bufoff) {                           // (conv_s16.hip: stage8_put)
+#pragma unroll
+            for (int i = 0; i < ITEMS8; ++i) {
+                const int pk = st8_pk[i], it = tid + 256 * i;
+                const unsigned m = (pk & (1 << 28)) ? 0xFFFFFFFFu : 0u;            // zero padding of the feature map
+                uint4 vh = raw8[i][0], vl = raw8[i][1];
+                vh.x &= m; vh.y &= m; vh.z &= m; vh.w &= m;
+                vl.x &= m; vl.y &= m; vl.z &= m; vl.w &= m;
+                const int n = it >> 2, r = (n * 3641) >> 16, c = n - r * SX_HW;     // n / 18 for n < 3641
+                const int hc = (it >> 1) & 1, kgs = it & 1, key = (c >> 1) & 7;
+                char* px = sx_smem + bufoff + (r * SX_PITCH + c) * 128;
+                union { uint4 u; cer_h2 h[4]; } ch, cl;
+                ch.u = vh; cl.u = vl;
+                typedef short short2_t __attribute__((ext_vector_type(2)));
+                union { uint4 u; short2_t s[4]; } q;
+                q.s[0] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16((short2_t){0, 0}, ch.h[0], 256.0f, false);
+                q.s[0] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q.s[0], ch.h[1], 256.0f, true);
+                q.s[1] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16((short2_t){0, 0}, ch.h[2], 256.0f, false);
+                q.s[1] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q.s[1], ch.h[3], 256.0f, true);
+                q.s[2] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16((short2_t){0, 0}, cl.h[0], 0.125f, false);
+                q.s[2] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q.s[2], cl.h[1], 0.125f, true);
+                q.s[3] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16((short2_t){0, 0}, cl.h[2], 0.125f, false);
+                q.s[3] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(q.s[3], cl.h[3], 0.125f, true);
+                if (SXPC_ABL & 4) q.u = raw8[i][1];
+                if (pk & (1 << 29)) {
+                    *reinterpret_cast<uint4*>(px + (((2 * kgs + hc) ^ key) << 4)) = vh;
+                    *reinterpret_cast<uint4*>(px + (((4 + 2 * kgs + hc) ^ key) << 4)) = q.u;
+                }
+            }
+        };
+        // ---- disparity tile and the six collapsed groups (own pixels only: the consumers read the centre tap)
+        constexpr int DITEMS = (C::DROWS * SX_DTW + 255) / 256;
+        float dval[DITEMS];
+        auto disp_load = [&](const SxpcTile& t) {
+#pragma unroll
+            for (int i = 0; i < DITEMS; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx / SX_DTW, c = idx - r * SX_DTW;
+                const int gy = t.ty0 + r - 4, gx = t.tx0 + c - 4;
+                dval[i] = (idx < C::DROWS * SX_DTW && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) ? dsrc[(long)gy * a.w + gx] : 0.f;
+            }
+        };
+        auto disp_store = [&]() {
+#pragma unroll
+            for (int i = 0; i < DITEMS; ++i)
+                if (tid + 256 * i < C::DROWS * SX_DTW) ldsD[tid + 256 * i] = dval[i];
+        };
+        auto gen_half = [&](auto g0_tag) {
+            // lane = (pixel, three of the six groups): channel s = (sy, sx) of the 9 x 9 window holds 100 * (d[p + s - 4] - d[p]);
+            // compile-time window offsets (they fold into the ds_read offsets: conv_s16.hip's generators were bound by address arithmetic)
+            constexpr int G0 = decltype(g0_tag)::value;
+            const int u = tid & 127;
+            if (u >= TH * SX_TW) return;
+            const int pr = u >> 4, pc = u & 15;
+            const float* dp = ldsD + pr * SX_DTW + pc;
+            const float ctr = dp[4 * SX_DTW + 4];
+            const int key = (pc >> 2) & 3;
+            char* px = ldsDB + (pr * SX_TW + pc) * 64;
+#pragma unroll
+            for (int g = G0; g < G0 + 3; ++g)
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) {
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int s_ = 16 * g + 8 * kh + k;
+                        const int sy = (s_ * 57) >> 9, sx = s_ - 9 * sy;            // s / 9, s % 9 for s < 96
+                        v[k] = (s_ < 81) ? 100.0f * (dp[sy * SX_DTW + sx] - ctr) : 0.f;
+                    }
+                    half8 hi, lo;
+                    sx_split8(v, a.disp_scale, hi, lo);
+                    *reinterpret_cast<half8*>(px + g * C::DGRP + ((kh ^ key) * 16)) = hi;
+                    *reinterpret_cast<half8*>(px + g * C::DGRP + (((2 + kh) ^ key) * 16)) = lo;
+                }
+        };
+        auto gen_groups = [&]() {                                      // producer waves 0, 1: groups 0-2; waves 2, 3: groups 3-5 (wave-uniform)
+            if (SXPC_ABL & 2) return;
+            if (pw < 2) gen_half(std::integral_constant<int, 0>{});
+            else gen_half(std::integral_constant<int, 3>{});
+        };
+        // ---- E-slice: the epilogue of m-tile m of tile t, from the accumulators consumer wave pw left in the dump.  Two halves: the
+        // global operands (hoisted init term, previous hidden state, z) are REQUESTED at the top of an interval and consumed at its
+        // end, behind the staging work - a producer wave has nobody to hide a memory latency behind but its own other work.
+        struct ESlice { bool on; half8 ph[2], pl[2]; float4 z0[2], z1[2], i0[2], i1[2]; long off[2]; };
+        ESlice es;
+        es.on = false;
+        auto eslice_request = [&](const SxpcTile& t, int m) {
+            es.on = false;
+            if (EPI == SX_EPI_DELTA || (SXPC_ABL & 1)) return;
+            const int mrow0 = (t.ty0 >> 1) + wm * MT;
+            if (mrow0 + m >= a.mty) return;                            // wave-uniform: the m-tile row is past the image
+            es.on = true;
+            const long mt = (long)mrow0 * a.mtx + t.tile_x + (long)m * a.mtx;
+            const int nt = (t.nb0 >> 5) + wn;
+            const bool is_r = EPI == CER_EPI_GATES && nt * 32 >= half;
+            const int Gc = (EPI == CER_EPI_GATES ? half : a.cout) >> 4;
+            const int g0 = (EPI == CER_EPI_GATES ? ((nt * 32) % half) >> 4 : nt * 2);
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                es.off[jp] = ((mt * Gc + g0 + jp) * 2) * 1024 + lane * 16;
+                if ((EPI == CER_EPI_GATES && is_r) || EPI == CER_EPI_GRU) {
+                    const char* p = reinterpret_cast<const char*>(a.aux) + es.off[jp];
+                    es.ph[jp] = *reinterpret_cast<const half8*>(p);
+                    es.pl[jp] = *reinterpret_cast<const half8*>(p + 1024);
+                    if (EPI == CER_EPI_GRU) {
+                        const char* zp = reinterpret_cast<const char*>(a.aux2) + es.off[jp];
+                        es.z0[jp] = *reinterpret_cast<const float4*>(zp);
+                        es.z1[jp] = *reinterpret_cast<const float4*>(zp + 1024);
+                    }
+                }
+                if (a.init) {
+                    // acc32 layout: (m-tile, n-tile, j < 4) -> 1 KiB, lane (kg', li) holds channels 8j + 4kg' + 0..3; after the consumers'
+                    // permlane swap this lane owns channels 16jp + 8kg + 0..7 = register group j = 2jp + kg, both kg' halves
+                    const char* ip = reinterpret_cast<const char*>(a.init) + ((mt * NT + nt) * 4 + 2 * jp + kg) * 1024 + li * 16;
+                    es.i0[jp] = *reinterpret_cast<const float4*>(ip);
+                    es.i1[jp] = *reinterpret_cast<const float4*>(ip + 512);
+                }
+            }
+        };
+        auto eslice_finish = [&](const SxpcTile& t, int m) {
+            if (!es.on) return;
+            const int nt = (t.nb0 >> 5) + wn;
+            const bool is_r = EPI == CER_EPI_GATES && nt * 32 >= half;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                const char* dp = ldsX + (((pw * MT + m) * 2 + jp) * 2) * 1024 + lane * 16;
+                const float4 d0 = *reinterpret_cast<const float4*>(dp), d1 = *reinterpret_cast<const float4*>(dp + 1024);
+                float v[8] = {d0.x * a.invS, d0.y * a.invS, d0.z * a.invS, d0.w * a.invS, d1.x * a.invS, d1.y * a.invS, d1.z * a.invS, d1.w * a.invS};
+                if (a.init) {
+                    const float in[8] = {es.i0[jp].x, es.i0[jp].y, es.i0[jp].z, es.i0[jp].w, es.i1[jp].x, es.i1[jp].y, es.i1[jp].z, es.i1[jp].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += in[e];
+                }
+                const long off = es.off[jp];
+                auto st_split = [&](float* base, const float (&o)[8]) {
+                    half8 hi, lo;
+                    sx_split8(o, a.out_scale, hi, lo);
+                    *reinterpret_cast<half8*>(reinterpret_cast<char*>(base) + off) = hi;
+                    *reinterpret_cast<half8*>(reinterpret_cast<char*>(base) + off + 1024) = lo;
+                };
+                if (EPI == CER_EPI_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    st_split(a.out, v);
+                } else if (EPI == CER_EPI_GATES) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = sx_sigmoid(v[e]);
+                    if (!is_r) {
+                        *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.out) + off) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.out) + off + 1024) = make_float4(v[4], v[5], v[6], v[7]);
+                    } else {
+                        float hp[8];
+                        sx_join8(es.ph[jp], es.pl[jp], a.aux_inv, hp);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= hp[e];
+                        st_split(a.out2, v);
+                    }
+                } else if (EPI == CER_EPI_GRU) {
+                    float hp[8];
+                    sx_join8(es.ph[jp], es.pl[jp], a.aux_inv, hp);
+                    const float z[8] = {es.z0[jp].x, es.z0[jp].y, es.z0[jp].z, es.z0[jp].w, es.z1[jp].x, es.z1[jp].y, es.z1[jp].z, es.z1[jp].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (1.0f - z[e]) * hp[e] + z[e] * sx_tanh(v[e]);
+                    st_split(a.out, v);
+                }
+            }
+        };
+        // ---- the producers' tile loop.  The halo loads of a chunk are issued one interval BEFORE the interval that converts and
+        // stores it (the same registers: a chunk's loads follow the previous chunk's stores), so a whole consumer chunk (3-4 k cycles)
+        // covers their latency; the first version issued and consumed them inside one interval and the consumers waited at every barrier.
+#if SXPC_TRACE
+        unsigned long long tsum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+        const unsigned long long tstart = tlast;
+#endif
+        if (nwork > 0) {
+            SxpcTile cur = work(0), prev = cur;
+            items_of(cur);
+            stage_load(0);
+            stage_store(0);
+            if (ng > 1) stage_load(1);
+            SXPC_T(0);
+            for (int j = 0; j < nwork; ++j) {
+                const bool have_prev = j > 0, have_next = j + 1 < nwork;
+                sxpc_barrier();                                                // b_0(T): chunk 0 staged (and T-1 dumped)
+                SXPC_T(1);                                                     // [1] wait at b_0
+                if (DISP) disp_load(cur);
+#pragma unroll 1
+                for (int k = 1; k < ng; ++k) {                                 // interval k-1: chunk k of T; E-slice k-1 of T-1
+                    const bool es_here = have_prev && k - 1 < MT;
+                    if (es_here) eslice_request(prev, k - 1);
+                    SXPC_T(2);                                                 // [2] E-slice requests
+                    stage_store((k & 1) * ABUF);                               // (loads issued one interval ago)
+                    SXPC_T(3);                                                 // [3] convert + store a chunk (incl. waiting for its loads)
+                    if (k + 1 < ng) {
+                        stage_load(k + 1);
+                    } else if (have_next) {                                    // the next tile's chunk 0: its items replace this tile's
+                        const SxpcTile nx = work(j + 1);
+                        items_of(nx);
+                        stage_load(0);
+                    }
+                    SXPC_T(4);                                                 // [4] issue the next chunk's loads
+                    if (es_here) eslice_finish(prev, k - 1);
+                    SXPC_T(5);                                                 // [5] E-slice math + stores
+                    if (!DISP && have_prev && k == ng - 1) {                   // without a disparity source the consumers dump behind b_{ng-1}:
+#pragma unroll 1
+                        for (int m = k; m < MT; ++m) {                         // every slice of T-1 has to be through in front of it
+                            eslice_request(prev, m);
+                            eslice_finish(prev, m);
+                        }
+                    }
+                    if (DISP && k == ng - 2) disp_store();                     // (read by the generators behind b_{ng-2})
+                    SXPC_T(6);
+                    sxpc_barrier();                                            // b_k(T)
+                    SXPC_T(7);                                                 // [7] wait at b_k
+                }
+                if (DISP && have_prev) {                                       // slices the chunk intervals did not cover (the dump follows b_D)
+#pragma unroll 1
+                    for (int m = max(ng - 1, 0); m < MT; ++m) {
+                        eslice_request(prev, m);
+                        eslice_finish(prev, m);
+                    }
+                }
+                SXPC_T(8);                                                     // [8] left-over E-slices
+                if (DISP) {
+                    gen_groups();
+                    SXPC_T(9);                                                 // [9] disparity generation
+                    sxpc_barrier();                                            // b_D(T)
+                    SXPC_T(10);                                                // [10] wait at b_D
+                }
+                prev = cur;
+                if (have_next) {                                               // chunk 0 of the next tile (requested above), one barrier early
+                    cur = work(j + 1);
+                    stage_store(0);
+                    if (ng > 1) stage_load(1);
+                }
+                if (EPI == SX_EPI_DELTA) sxpc_barrier();                       // b_R(T): the consumers' partial tap planes are complete
+                SXPC_T(11);                                                    // [11] next tile's chunk 0
+            }
+            sxpc_barrier();                                                    // the last tile's accumulators are dumped
+#pragma unroll 1
+            for (int m = 0; m < MT; ++m) {
+                eslice_request(prev, m);
+                eslice_finish(prev, m);
+            }
+        }
+#if SXPC_TRACE
+        if (EPI == CER_EPI_GATES && lane == 0 && a.aux2) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.aux2)) + ((long)blockIdx.x * 8 + wave) * 16;
+            for (int k = 0; k < 12; ++k) o[k] = tsum[k];
+            o[14] = __builtin_readcyclecounter() - tstart;
+            o[15] = (unsigned long long)nwork;
+        }
+#endif
+        return;
+    }
+
+    // ============================================================================================================ CONSUMERS
+    const int cw = wave - 4;
+    const int wm = cw / WN_, wn = cw % WN_;
+    const int ctid = threadIdx.x - 256;
+    // fragment addresses inside a chunk buffer (conv_s16.hip: xa) and inside a disparity group (own pixels, 16-channel layout)
+    int xa[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int col = (li & 15) + dx;
+        xa[dx] = (2 * wm * MT + (li >> 4)) * SX_ROWB8 + col * 128 + (((2 * kg) ^ ((col >> 1) & 7)) << 4);
+    }
+    const int dcol = li & 15;
+    const int dsl = kg ^ ((dcol >> 2) & 3);
+    const int dh = ((2 * wm * MT + (li >> 4)) * SX_TW + dcol) * 64 + dsl * 16, dl = ((2 * wm * MT + (li >> 4)) * SX_TW + dcol) * 64 + (dsl ^ 2) * 16;
+
+    struct XFrag { half8 h[MT], l[MT]; };
+    struct WFrag { half8 h, l; };
+    struct W8 { half8 h0, h1; union { intx8 v; uint4 q[2]; } q; };
+    union F8Frag { intx8 v; uint4 q[2]; };
+
+#if SXPC_TRACE
+    unsigned long long tsum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+    const unsigned long long tstart = tlast;
+#endif
+    for (int j = 0; j < nwork; ++j) {
+        const SxpcTile t = work(j);
+        const char* wlane = wbase + ((long)(t.nb0 >> 5) + wn) * 2048 + lane * 16;
+        const char* wlane8 = wbase + ((long)(t.nb0 >> 5) + wn) * 4096 + lane * 16;
+        auto load_w = [&](WFrag& f, int step) {
+            const char* p = wlane + (long)step * wstep;
+            f.h = *reinterpret_cast<const half8*>(p);
+            f.l = *reinterpret_cast<const half8*>(p + 1024);
+        };
+        auto load_w8 = [&](W8& f, int cstep) {
+            const char* p = wlane8 + (long)((SXPC_ABL & 16) ? 0 : min(cstep, ng * 9 - 1)) * (2 * wstep);
+            f.h0 = *reinterpret_cast<const half8*>(p);
+            f.h1 = *reinterpret_cast<const half8*>(p + 1024);
+            f.q.q[0] = *reinterpret_cast<const uint4*>(p + 2048);
+            f.q.q[1] = *reinterpret_cast<const uint4*>(p + 3072);
+        };
+        XFrag fx;
+        F8Frag f8[MT];
+        // weight slices WD taps ahead (ring of WD + 1 register slots; the chunk / tap loops are fully unrolled, so a slot index is a
+        // compile-time constant).  One tap ahead - conv_s16.hip's distance, where the co-resident block covers an L2 round trip - left this
+        // wave, alone on its SIMD, waiting ~500 cycles per tap (871 cycles per tap against 384 of matrix work by the cycle trace).
+        constexpr int WD = 3, NW = WD + 1;
+        W8 w8[NW];
+        WFrag fw[3];
+#pragma unroll
+        for (int d = 0; d < WD; ++d) load_w8(w8[d], d);
+        // ---- accumulators: zero, or the bias on the accumulator scale.  The hoisted `init` term (60 MB per z|r launch, an HBM latency
+        // per tile in front of the first MFMA) is added by the producers' E-slices instead: acc / S + init.
+        const int mrow0 = (t.ty0 >> 1) + wm * MT;
+        (void)mrow0;
+        floatx16 acc[MT];
+        {
+            float4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                bq[q] = (!a.init && a.bias) ? cer_ld4(a.bias + t.nb0 + wn * 32 + 8 * q + 4 * kg) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[m][4 * q + 0] = bq[q].x * a.S; acc[m][4 * q + 1] = bq[q].y * a.S; acc[m][4 * q + 2] = bq[q].z * a.S; acc[m][4 * q + 3] = bq[q].w * a.S;
+                }
+        }
+        SXPC_T(0);                                                             // [0] tile setup
+        sxpc_barrier();                                                        // b_0(T)
+        SXPC_T(1);                                                             // [1] wait at b_0
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            fx.h[m] = *reinterpret_cast<const half8*>(sx_smem + xa[0] + (2 * m) * SX_ROWB8);
+            fx.l[m] = *reinterpret_cast<const half8*>(sx_smem + (xa[0] ^ 16) + (2 * m) * SX_ROWB8);
+            f8[m].q[0] = *reinterpret_cast<const uint4*>(sx_smem + (xa[0] ^ 64) + (2 * m) * SX_ROWB8);
+            f8[m].q[1] = *reinterpret_cast<const uint4*>(sx_smem + (xa[0] ^ 80) + (2 * m) * SX_ROWB8);
+        }
+        auto mma8_roll = [&](const W8& w, int pa, int rowoff) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = SXPC_MFMA16(w.h0, fx.h[m], acc[m]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[m] = SXPC_MFMA16(w.h1, fx.l[m], acc[m]);
+                fx.h[m] = *reinterpret_cast<const half8*>(sx_smem + pa + (2 * m) * SX_ROWB8 + rowoff);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[m] = SXPC_MFMA8(w.q.v, f8[m].v, acc[m]);
+                fx.l[m] = *reinterpret_cast<const half8*>(sx_smem + (pa ^ 16) + (2 * m) * SX_ROWB8 + rowoff);
+                f8[m].q[0] = *reinterpret_cast<const uint4*>(sx_smem + (pa ^ 64) + (2 * m) * SX_ROWB8 + rowoff);
+                f8[m].q[1] = *reinterpret_cast<const uint4*>(sx_smem + (pa ^ 80) + (2 * m) * SX_ROWB8 + rowoff);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // the last tap of the last chunk: rolls in the first operands of the disparity section (or nothing)
+        auto mma8_last = [&](const W8& w) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = SXPC_MFMA16(w.h0, fx.h[m], acc[m]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[m] = SXPC_MFMA16(w.h1, fx.l[m], acc[m]);
+                if (DISP) fx.h[m] = *reinterpret_cast<const half8*>(ldsDB + dh + (2 * m) * SX_TW * 64);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[m] = SXPC_MFMA8(w.q.v, f8[m].v, acc[m]);
+                if (DISP) fx.l[m] = *reinterpret_cast<const half8*>(ldsDB + dl + (2 * m) * SX_TW * 64);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+#pragma unroll
+        for (int gi = 0; gi < ng; ++gi) {
+            const bool last = gi + 1 == ng;
+            const int bufC = (gi & 1) * ABUF, bufN = ABUF - bufC;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int T_ = gi * 9 + tp;                                    // tap counter of the tile (compile time)
+                if (tp == 8 && (!last || DISP)) {
+                    SXPC_T(2);                                                 // [2] taps 0-7 of a chunk
+                    sxpc_barrier();                                            // b_{gi+1}(T) / b_D(T): the next operands are complete
+                    SXPC_T(3);                                                 // [3] wait at b_k / b_D
+                }
+                if (T_ + WD < ng * 9) load_w8(w8[(T_ + WD) % NW], T_ + WD);
+                if (tp == 8 && last && DISP) { load_w(fw[0], nsteps_t); load_w(fw[1], nsteps_t + 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                const W8& wc = w8[T_ % NW];
+                if (tp < 8) mma8_roll(wc, xa[(tp + 1) % 3] + bufC, ((tp + 1) / 3) * SX_ROWB8);
+                else if (!last) mma8_roll(wc, xa[0] + bufN, 0);
+                else mma8_last(wc);
+            }
+        }
+        SXPC_T(4);                                                             // [4] last taps
+        // ---- collapsed disparity source: six single-tap steps, all groups resident
+        if (DISP) {
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                if (g + 2 < 6) load_w(fw[(g + 2) % 3], nsteps_t + g + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                const WFrag& w = fw[g % 3];
+                const int nx = min(g + 1, 5) * C::DGRP;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = SXPC_MFMA16(w.h, fx.h[m], acc[m]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    acc[m] = SXPC_MFMA16(w.l, fx.h[m], acc[m]);
+                    fx.h[m] = *reinterpret_cast<const half8*>(ldsDB + nx + dh + (2 * m) * SX_TW * 64);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    acc[m] = SXPC_MFMA16(w.h, fx.l[m], acc[m]);
+                    fx.l[m] = *reinterpret_cast<const half8*>(ldsDB + nx + dl + (2 * m) * SX_TW * 64);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- rim correction of the collapsed form (conv_s16.hip): extra K-steps with register-generated fragments
+            if (a.edge && !t.interior) {
+                // `vary` = 0 at run time, but derived from the tile counter: everything this rare path computes from the lane index is
+                // re-derived here instead of being hoisted out of the tile loop as an invariant (hipcc otherwise keeps ~100 such registers
+                // alive across the MFMA loop and spills inside it)
+                const int vary = (j >> 28) * 0x11111111;
+                const int lane_ = lane ^ vary, li_ = lane_ & 31, kg_ = lane_ >> 5;
+                const _Float16* ew = reinterpret_cast<const _Float16*>(a.edge) + ((long)(t.nb0 >> 5) + wn) * 1024 + lane_ * 8;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int py = 2 * (wm * MT + m) + (li_ >> 4), px = li_ & 15;
+                    const int y = t.ty0 + py, x = t.tx0 + px;
+                    const bool in = y < a.h && x < a.w;
+                    const bool top = in && y == 0, bot = in && y == a.h - 1, lef = in && x == 0, rig = in && x == a.w - 1;
+                    auto D = [&](int r, int c) { return ldsD[(r - t.ty0 + 4) * SX_DTW + (c - t.tx0 + 4)]; };
+                    auto apply = [&](int e, int nks, bool on, auto&& pos) {
+                        if (!__any(on)) return;
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            if (ks >= nks) break;
+                            float v[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const int k = 16 * ks + 8 * kg_ + q;
+                                int r = 0, c = 0;
+                                const bool ok = pos(k, r, c);
+                                v[q] = (on && ok) ? 100.0f * D(r, c) : 0.f;
+                            }
+                            half8 fh, fl;
+                            sx_split8(v, a.disp_scale, fh, fl);
+                            const _Float16* wp = ew + (long)((e * 2 + ks) * NT) * 1024;
+                            const half8 wh = *reinterpret_cast<const half8*>(wp), wl = *reinterpret_cast<const half8*>(wp + 512);
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fh, acc[m], 0, 0, 0);
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fl, acc[m], 0, 0, 0);
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, fh, acc[m], 0, 0, 0);
+                        }
+                    };
+                    apply(0, 2, top, [&](int k, int& r, int& c) { r = k / 9; c = x + k % 9 - 4; return k < 27; });
+                    apply(1, 2, bot, [&](int k, int& r, int& c) { r = a.h - 3 + k / 9; c = x + k % 9 - 4; return k < 27; });
+                    apply(2, 2, lef, [&](int k, int& r, int& c) { r = y + k / 3 - 4; c = k % 3; return k < 27; });
+                    apply(3, 2, rig, [&](int k, int& r, int& c) { r = y + k / 3 - 4; c = a.w - 3 + k % 3; return k < 27; });
+                    apply(4, 1, top && lef, [&](int k, int& r, int& c) { r = k / 3; c = k % 3; return k < 9; });
+                    apply(5, 1, top && rig, [&](int k, int& r, int& c) { r = k / 3; c = a.w - 3 + k % 3; return k < 9; });
+                    apply(6, 1, bot && lef, [&](int k, int& r, int& c) { r = a.h - 3 + k / 3; c = k % 3; return k < 9; });
+                    apply(7, 1, bot && rig, [&](int k, int& r, int& c) { r = a.h - 3 + k / 3; c = a.w - 3 + k % 3; return k < 9; });
+                }
+            }
+        }
+        SXPC_T(5);                                                             // [5] disparity steps + rim correction
+        if constexpr (EPI == SX_EPI_DELTA) {
+            // ---- delta head, fused (conv_s16.hip): hid = relu(conv) in registers -> projection onto the 9 taps -> LDS -> tap planes
+            const _Float16* w2 = reinterpret_cast<const _Float16*>(a.aux) + ((long)(t.by * WN_ + wn) * 2) * 1024;
+            float* red = reinterpret_cast<float*>(ldsX);                       // [wn][m][tap 9][32 px]
+            const float hs = a.invS * (float)(1 << SX_HID_LOG2);
+            float hmax = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                floatx16 tm;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tm[r] = 0.f;
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[m][8 * jp + e]), __float_as_uint(acc[m][8 * jp + 4 + e]), false, false);
+                        v[e] = fmaxf(__uint_as_float(sw[0]), 0.f);
+                        v[4 + e] = fmaxf(__uint_as_float(sw[1]), 0.f);
+                    }
+                    hmax = fmaxf(hmax, fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7]))));
+                    half8 hh, hl;
+                    sx_split8(v, hs, hh, hl);
+                    const half8 wh = *reinterpret_cast<const half8*>(w2 + (jp * 2 + 0) * 512 + lane * 8);
+                    const half8 wl = *reinterpret_cast<const half8*>(w2 + (jp * 2 + 1) * 512 + lane * 8);
+                    tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hh, tm, 0, 0, 0);
+                    tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hl, tm, 0, 0, 0);
+                    tm = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hh, tm, 0, 0, 0);
+                }
+                float* rp = red + ((wn * MT + m) * 9) * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rp[(r + 4 * kg) * 32] = tm[r];
+                if (kg == 0) rp[8 * 32] = tm[4];
+            }
+            if (a.flag && __ballot(!(hmax * hs <= 65504.0f)) != 0ull && lane == 0) atomicOr(a.flag, 2);
+            sxpc_barrier();                                                    // b_R(T)
+            const long P = (long)a.h * a.w;
+            for (int idx = ctid; idx < MT * 9 * 32; idx += 256) {
+                const int m = idx / (9 * 32), rem = idx - m * 9 * 32, tap = rem >> 5, px = rem & 31;
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < WN_; ++q) s += red[((q * MT + m) * 9 + tap) * 32 + px];
+                const int gy = t.ty0 + 2 * m + (px >> 4), gx = t.tx0 + (px & 15);
+                if (gy < a.h && gx < a.w) a.out[((long)t.by * 9 + tap) * P + (long)gy * a.w + gx] = s * a.proj_inv;
+            }
+        } else {
+            // ---- dump: after one v_permlane32_swap per register pair a lane owns 8 consecutive channels of its pixel (conv_s16.hip);
+            // the producers finish them - same lane, same addresses - while this wave multiplies the next tile
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[m][8 * jp + e]), __float_as_uint(acc[m][8 * jp + 4 + e]), false, false);
+                        v[e] = __uint_as_float(sw[0]);
+                        v[4 + e] = __uint_as_float(sw[1]);
+                    }
+                    char* dp = ldsX + (((cw * MT + m) * 2 + jp) * 2) * 1024 + lane * 16;
+                    *reinterpret_cast<float4*>(dp) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(dp + 1024) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+        }
+        SXPC_T(6);                                                             // [6] dump / DELTA epilogue
+    }
+    if (nwork > 0) sxpc_barrier();                                             // the last tile's accumulators are dumped
+#if SXPC_TRACE
+    if (EPI == CER_EPI_GATES && lane == 0 && a.aux2) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.aux2)) + ((long)blockIdx.x * 8 + wave) * 16;
+        for (int k = 0; k < 8; ++k) o[k] = tsum[k];
+        o[14] = __builtin_readcyclecounter() - tstart;
+        o[15] = (unsigned long long)nwork;
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------ host side
+static int sxpc_num_cus() {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) return v;
+    return 256;
+}
+
+template <int WM_, int WN_, int MT, int EPI, int DISP, int NG>
+static int sxpc_launch(S16Args& a, hipStream_t st) {
+    using C = SxpcCfg<WM_, WN_, MT>;
+    constexpr int TH = C::TH;
+    const int tiles_y = (a.h + TH - 1) / TH;
+    a.tiles_x = (a.w + SX_TW - 1) / SX_TW;
+    a.mtx = a.tiles_x;
+    a.mty = (a.h + 1) / 2;
+    if ((long)a.mtx * a.mty >= (1L << 20)) return CER_ESHAPE;
+    a.ntiles = a.tiles_x * tiles_y;
+    a.ny = a.cout / (WN_ * 32);
+    a.border_first = 0;
+    const long total = (long)a.ntiles * a.ny;
+    if (total >= (1L << 31)) return CER_ESHAPE;
+    const int cus = sxpc_num_cus();
+    const unsigned grid = (unsigned)(total < cus ? total : cus);
+    constexpr int smem = C::OFF_X + (EPI == SX_EPI_DELTA ? C::RED : C::DUMP);
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    const void* fn = (const void*)conv3x3_s16pc_kernel<WM_, WN_, MT, EPI, DISP, NG>;
+    static bool raised[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (smem > 64 * 1024 && !raised[dev]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return CER_EINVAL;
+        raised[dev] = true;
+    }
+    hipLaunchKernelGGL((conv3x3_s16pc_kernel<WM_, WN_, MT, EPI, DISP, NG>), dim3(grid), dim3(512), smem, st, a, (int)total);
+    CER_RETURN_IF_LAUNCH_FAILED();
+    return CER_OK;
+}
+
+// Serves: fp8-correction form; tensor sources of whole 32-channel chunks, at least 2 chunks (3 with a disparity source); a disparity
+// source only in the collapsed form with rim filters; epilogues RELU / GATES / GRU with frag16 outputs and the fused DELTA head.
+// Process-wide switch (like cer_cost_build_algo): 0 = conv_s16.hip's kernels (default), 1 = these.  Measured at the bench workload
+// (round 4, same box, 40 steps): 56.1 against 57.2 depth maps/s one at a time and 61.9 against 65.4 with three in flight - the
+// consumers' K-loop runs at 480 cycles per tap (384 = matrix-pipe floor) once the weight slices are requested three taps ahead, but
+// a 512-thread block streams the SAME 576 KB of z|r weights from L2 for 96 pixels that two lock-stepped 256-thread blocks of
+// conv_s16.hip share through the L1 for 256, the producers then queue behind those loads (VMEM issue: 13 k of their 31 k cycles per
+// tile), and a block that owns a whole CU leaves no room for another depth map's kernels.  Kept as an opt-in and as a test subject.
+static int g_sxpc_on = -1;
+extern "C" int cer_conv3x3_s16_pc(int on) {
+    if (g_sxpc_on < 0) g_sxpc_on = (getenv("CER_S16_PC") && atoi(getenv("CER_S16_PC")) != 0) ? 1 : 0;
+    const int prev = g_sxpc_on;
+    if (on == 0 || on == 1) g_sxpc_on = on;
+    return prev;
+}
+
+int sxpc_dispatch(S16Args& a, int epi, int tile_mt, hipStream_t st) {
+    if (!cer_conv3x3_s16_pc(-1)) return CER_ESHAPE;
+    const bool disp = a.kind[a.nsrc - 1] == 1;
+    const int ntens = disp ? a.nsrc - 1 : a.nsrc;
+    int ng = 0;
+    for (int s = 0; s < ntens; ++s) {
+        if (a.kind[s] != 2 || a.ch[s] % 32) return CER_ESHAPE;
+        ng += a.ch[s] >> 5;
+    }
+    if (disp && !(a.wpk_c && a.edge)) return CER_ESHAPE;
+    if (ng < (disp ? 3 : 2)) return CER_ESHAPE;
+    if (!disp && (ng & 1)) return CER_ESHAPE;              // chunk 0 of the next tile goes to buffer 0 behind b_{ng-1}: the last chunk must not live there
+    if (epi == CER_EPI_LINEAR || (epi == CER_EPI_RELU && !a.out_split)) return CER_ESHAPE;
+    (void)tile_mt;
+    if (a.cout % 128 == 0) {                               // 1 x 4 consumer waves, 6-row tiles (3 m-tiles per wave)
+        if (epi == CER_EPI_GATES && disp && ng == 4) return sxpc_launch<1, 4, 3, CER_EPI_GATES, 1, 4>(a, st);
+        if (epi == SX_EPI_DELTA && !disp && ng == 2) return sxpc_launch<1, 4, 3, SX_EPI_DELTA, 0, 2>(a, st);
+        return CER_ESHAPE;
+    }
+    if (a.cout == 64) {                                    // 2 x 2 consumer waves, 8-row tiles (2 m-tiles per wave)
+        if (epi == CER_EPI_GRU && disp && ng == 4) return sxpc_launch<2, 2, 2, CER_EPI_GRU, 1, 4>(a, st);
+        if (epi == CER_EPI_RELU && !disp && ng == 2) return sxpc_launch<2, 2, 2, CER_EPI_RELU, 0, 2>(a, st);
+    }
+    return CER_ESHAPE;
+}

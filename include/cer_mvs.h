@@ -43,6 +43,11 @@ int cer_device_count(void);
  * checked after the fact: cer_f16_scan_overflow ors `bit` into *flag if any half of a split-f16 buffer (frag16 tensors, split
  * feature rows; `bytes` % 16 == 0) sits at the f16 maximum or is not finite.  The host reads the flag when convenient. */
 int cer_overflow_flag(int* flag);
+/* Producer / consumer form of the GRU loop's fp8-correction convolutions (csrc/conv_s16pc.hip, round 4): process-wide switch,
+ * 0 = off (default: the kernels of csrc/conv_s16.hip; environment CER_S16_PC=1 turns it on at load), 1 = on, anything else = query;
+ * returns the previous setting.  Same operands and results (the hoisted `init` term is added in the epilogue instead of seeding the
+ * accumulators: last-bit differences); measured slower at the bench workload - see the note at the switch. */
+int cer_conv3x3_s16_pc(int on);
 int cer_f16_scan_overflow(const void* data, long bytes, int* flag, int bit, void* stream);
 
 /* ------------------------------------------------------------------------------------

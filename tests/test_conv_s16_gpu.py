@@ -288,3 +288,46 @@ def test_conv_s16_dynamic_range(dev):
     assert bool(((got - ref).abs() <= 2e-6 * mag + 2.0 ** (-24 - L.S16_RELU) * wsum).all())
     big = ops.to_frag16(torch.full((h * w, cin), 1e6, device=dev), h, w, L.S16_RELU)
     assert torch.isfinite(ops.conv3x3_s16(pc, [big], h, w, L.EPI_LINEAR)).all()
+
+
+def test_conv_s16_producer_consumer_form_matches(dev):
+    """csrc/conv_s16pc.hip (opt-in: cer_conv3x3_s16_pc(1)) against the default kernels: z|r gates, GRU blend, ReLU conv and the fused
+    delta head on a size with rim tiles, partial last tiles and several tiles per persistent block; the two forms differ only in where
+    the hoisted term is added (<= 2e-6 relative), and the producer / consumer form reproduces itself bit for bit over 100 launches."""
+    from cer_mvs_amd import _lib as L, ops
+    lib = L.load()
+    h, w = 118, 150
+    P = h * w
+    U, R, Dp = L.S16_UNIT, L.S16_RELU, L.S16_DISP
+    net = torch.tanh(hashed((1, 64, h, w), 701, -2, 2))
+    c2 = torch.relu(hashed((1, 64, h, w), 702, -1, 2))
+    disp = hashed((P,), 703, 0.0005, 0.0025).to(dev)
+    src = [(64, 2, U), (49, 1, Dp), (64, 2, R)]
+    pzr = ops.PackedConvS16(hashed((128, 177, 3, 3), 705, -0.05, 0.05), None, src, dev, corr_fp8=True)
+    pq = ops.PackedConvS16(hashed((64, 177, 3, 3), 706, -0.05, 0.05), None, src, dev, corr_fp8=True)
+    pr = ops.PackedConvS16(hashed((64, 64, 3, 3), 707, -0.05, 0.05), hashed((64,), 708, -0.1, 0.1), [(64, 2, R)], dev, corr_fp8=True)
+    pd = ops.PackedConvS16(hashed((256, 64, 3, 3), 709, -0.08, 0.08), hashed((256,), 710, -0.1, 0.1), [(64, 2, U)], dev, corr_fp8=True)
+    proj = ops.delta_proj_pack_s16(hashed((1, 256, 3, 3), 711, -0.05, 0.05), dev)
+    net_s, c2_s = frag(net, h, w, U), frag(c2, h, w, R)
+    init = ops.s16_layout(hashed((P, 128), 704, -0.3, 0.3).to(dev), h, w, L.S16_ACC32)
+    initq = ops.s16_layout(hashed((P, 64), 712, -0.3, 0.3).to(dev), h, w, L.S16_ACC32)
+
+    def run():
+        z, rh = ops.conv3x3_s16(pzr, [net_s, disp, c2_s], h, w, L.EPI_GATES, aux=net_s, init=init, log2s_out=U, log2s_aux=U)
+        new = ops.conv3x3_s16(pq, [rh, disp, c2_s], h, w, L.EPI_GRU, aux=net_s, aux2=z, init=initq, log2s_out=U, log2s_aux=U)
+        rl = ops.conv3x3_s16(pr, [c2_s], h, w, L.EPI_RELU, log2s_out=R)
+        T = ops.conv3x3_s16(pd, [net_s], h, w, L.EPI_DELTA, aux=proj)
+        return [unacc(z, h, w, L.S16_F32X8), unfrag(rh, h, w, U), unfrag(new, h, w, U), unfrag(rl, h, w, R), T.cpu().double()], [z, rh, new, rl, T]
+    prev = lib.cer_conv3x3_s16_pc(0)
+    try:
+        ref, _ = run()
+        lib.cer_conv3x3_s16_pc(1)
+        got, raw0 = run()
+        raw0 = [t.clone() for t in raw0]
+        for name, a_, b_ in zip(("z", "r*h", "h'", "relu", "taps"), got, ref):
+            assert rel_l1(a_, b_) < 2e-6, (name, rel_l1(a_, b_))
+        for _ in range(100):
+            _, raw = run()
+            assert all(torch.equal(x, y) for x, y in zip(raw, raw0))
+    finally:
+        lib.cer_conv3x3_s16_pc(prev)
