@@ -32,6 +32,25 @@ __device__ __forceinline__ void cer_split8(const float (&v)[8], cer_h8& hi, cer_
 }
 #endif
 
+// ---- schedule fuzzing (variant build -DCER_FUZZ=1, make variants/libcermvs_fuzz.so): a per-wave pseudo-random
+// s_sleep (0 .. 15 x 512 cycles) at every marked point - behind every barrier and in front of every LDS write phase of the kernels
+// that have shown timing-dependent output in some variant (conv3x3_s16_kernel, lookup_encode_kernel).  It shifts the waves of a block
+// against each other by up to several thousand cycles, far beyond what co-resident blocks or a second process do: a missing
+// happens-before between one wave's ds_read and another's ds_write then shows as run-to-run nondeterminism with a reproducer
+// (tests/test_determinism_gpu.py under CER_MVS_LIB=.../libcermvs_fuzz.so).  In the product build the macros expand to nothing.
+#ifndef CER_FUZZ
+#define CER_FUZZ 0
+#endif
+#if CER_FUZZ && defined(__HIPCC__)
+#define CER_FUZZ_INIT() unsigned cer_fuzz_state = __builtin_amdgcn_readfirstlane((unsigned)((blockIdx.x * 8u + (threadIdx.x >> 6)) * 2654435761u) ^ (unsigned)__builtin_readcyclecounter())
+#define CER_FUZZ_POINT() do { cer_fuzz_state = cer_fuzz_state * 1664525u + 1013904223u;                                   \
+                              const unsigned n_ = __builtin_amdgcn_readfirstlane((cer_fuzz_state >> 24) & 15u);          \
+                              for (unsigned i_ = 0; i_ < n_; ++i_) __builtin_amdgcn_s_sleep(8); } while (0)
+#else
+#define CER_FUZZ_INIT() do { } while (0)
+#define CER_FUZZ_POINT() do { } while (0)
+#endif
+
 // process-wide sticky overflow flag (cer_overflow_flag in capi.hip): a device int that saturating conversions or into, or null
 int* cer_overflow_flag_get();
 

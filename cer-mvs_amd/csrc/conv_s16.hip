@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN_, wn = wave % WN_;
     const int li = lane & 31, kg = lane >> 5;
+    CER_FUZZ_INIT();
 #if SX_TRACE
     unsigned long long trace_t[24];
     int trace_n = 0;
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
         }
     };
     auto stage_store = [&](int bufoff, int batch) {
+        CER_FUZZ_POINT();
         const int tid_ = tid ^ vary;
 #pragma unroll
         for (int k = 0; k < IB; ++k) {
@@ -239,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
         }
     };
     auto stage8_store = [&](int bufoff, int batch) {
+        CER_FUZZ_POINT();
 #pragma unroll
         for (int k = 0; k < IB8; ++k) {
             const int i = batch * IB8 + k;
@@ -248,6 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
     };
     // literal disparity features, group g (channels 16g .. 16g+15 of 100 * (unfold7x7(d) - d), core/update.py:80-85,97)
     auto gen_literal = [&](int g, int bufoff) {
+        CER_FUZZ_POINT();
         for (int n = tid ^ vary; n < NPIX; n += 256) {
             const int r = n / SX_HW, c = n - r * SX_HW;
             const int gy = ty0 + r - 1, gx = tx0 + c - 1;
@@ -305,6 +309,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
             *reinterpret_cast<half8*>(px + (((2 + kh) ^ key) * 16)) = lo;
             SX_LDS_STORE_WAIT();
         };
+        CER_FUZZ_POINT();
         for (int u = tid ^ vary; u < TH * SX_TW; u += 256) {
             half_unit(std::integral_constant<int, 0>{}, u);
             half_unit(std::integral_constant<int, 1>{}, u);
@@ -331,10 +336,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
     };
     // LDS-only release / acquire around the barrier: the bare s_barrier builtin orders nothing for the compiler (a generator's last
     // ds_write was once sunk below it), a full __syncthreads() would also wait for the weight and staging loads in flight (vmcnt)
+    //
+    // Happens-before argument for every LDS region of this kernel (B(g) = the barrier inside group g's tap
+    // loop, in front of its last tap; every barrier() is preceded by s_waitcnt lgkmcnt(0) in each wave, so a wave's LDS accesses
+    // issued before a barrier are COMPLETE when any wave leaves it):
+    //   * activation buffer g & 1, group g's operands.  WRITTEN by every wave during group g-1 (tensor batches behind taps 0-6, the
+    //     disparity generators at tap 6), i.e. after B(g-2) and before B(g-1).  Its previous contents, group g-2, are READ by the
+    //     rolling fragment loads of group g-2's taps 0-7 - the last ones are issued inside tap 7, in front of B(g-2); tap 8 of group
+    //     g-2 multiplies registers and rolls in group g-1's first fragments from the OTHER buffer.  So the last read of group g-2 by
+    //     any wave precedes B(g-2), and the first write of group g follows it.  Group g is read after B(g-1).
+    //   * collapsed disparity section: step t generates group t+1 into the other half, barrier, multiplies step t while rolling in
+    //     step t+1's fragments; the half written at step t+1 was last read by the rolling loads of step t-1, in front of step t's barrier.
+    //   * disparity tile ldsD: written once in the prologue (in front of the first barrier), read-only afterwards.
+    //   * DELTA epilogue: `red` overlays the activation buffers - barrier() after the main loop (all fragment reads complete), partial
+    //     tap planes, barrier(), reduction.
+    // The schedule-fuzz build (common.hpp CER_FUZZ, tools/fuzz_schedule.sh: random per-wave sleeps of up to 7.7 k cycles behind every
+    // barrier and in front of every LDS write phase) reproduces the first launch bit for bit over 10 000 launches of the five
+    // epilogues in both arithmetic forms: no missing edge was found in the form that ships.
     auto barrier = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");        // s_waitcnt lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        CER_FUZZ_POINT();
     };
 
     // ---- the group sequence: tensors chunk by chunk (two half-chunk groups of 9 taps), then the disparity source

@@ -86,6 +86,10 @@ __global__ __launch_bounds__(256) void lookup_kernel(const float* __restrict__ v
 // (A variant with the 3 x 11 windows and the 33-deep conv unrolled at compile time was 1 us faster stand-alone, no faster in the
 // pipeline, and produced intermittently wrong features when a second process shared the GPU - 17 of 70 two-process runs against
 // 0 of 130 for this form; the cause was narrowed to the unrolled window code but not found.  It was removed.)
+// Happens-before: `rows` is written in front of [B1](t) and read (windows) between [B1](t) and [B2](t);
+// the next tile's writes follow [B2](t).  `feats` is double-buffered: half t & 1 is written between [B1](t) and [B2](t) and read by the
+// conv behind [B2](t); it is written again between [B1](t+2) and [B2](t+2), and a wave reaches [B1](t+1) only after its conv of tile t.
+// The schedule-fuzz build (common.hpp CER_FUZZ) reproduces the first launch over 2 000 launches.
 #define LK_MAX_PRE 16      // float4 per thread of one 64-row tile: 64 * (LK_MAX_ROW / 4) / 256
 __global__ __launch_bounds__(256) void lookup_encode_kernel(const float* __restrict__ vol, const float* __restrict__ origin,
                                                             const float* __restrict__ disp, const float* __restrict__ wgt,
@@ -102,6 +106,7 @@ __global__ __launch_bounds__(256) void lookup_encode_kernel(const float* __restr
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id: lookup level, then output-channel group
     float4 pre[LK_MAX_PRE];
     float pre_d = 0.f, pre_o = 0.f;
+    CER_FUZZ_INIT();
     // float4 number t = tid + 256 i of the tile is (row pr, quad q) = (t / n4, t % n4): walked incrementally (no division per item)
     const int pr0 = threadIdx.x / n4, q0 = threadIdx.x - pr0 * n4, dpr = 256 / n4, dq = 256 - dpr * n4;
     auto request = [&](int tile) {                           // rows of `tile` -> registers (zeros past the last pixel)
@@ -126,6 +131,7 @@ __global__ __launch_bounds__(256) void lookup_encode_kernel(const float* __restr
         const int npix = (int)min((long)LK_PIX, P - p0);
         const bool active = pix < npix;
         const float c = active ? lk_index(pre_d, pre_o, incre, D) : 0.f;
+        CER_FUZZ_POINT();                                    // (in front of the LDS write phase)
         {
             int pr = pr0, q = q0;
 #pragma unroll
@@ -138,12 +144,14 @@ __global__ __launch_bounds__(256) void lookup_encode_kernel(const float* __restr
             }
         }
         __syncthreads();                                     // [B1] rows complete; the previous tile's windows were read before its [B2]
+        CER_FUZZ_POINT();
         if (tile + (int)gridDim.x < ntiles) request(tile + gridDim.x);
         float* ft = feats + (it & 1) * fstride;
         if (active)
             for (int lv = grp; lv < L; lv += 4)            // (straight into the feature tile: no per-thread array)
                 lk_window(&rows[pix * rsp], li.off[lv], li.len[lv], c / (float)(1 << lv), r, &ft[pix * FS + lv * taps]);
         __syncthreads();                                     // [B2] features complete; rows free for the next tile
+        CER_FUZZ_POINT();
         if (!active) continue;
         float acc[16];
 #pragma unroll

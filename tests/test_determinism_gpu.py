@@ -15,7 +15,9 @@ from test_oracle_golden import hashed
 
 pytestmark = pytest.mark.gpu
 
-LAUNCHES = 200
+import os
+
+LAUNCHES = int(os.environ.get("CER_DET_LAUNCHES", "200"))       # (the schedule-fuzz build is run with 500: tools/fuzz_schedule.sh)
 
 
 @pytest.fixture(scope="module")
