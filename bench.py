@@ -3,7 +3,10 @@
 
 A "step" is one test-mode RAFT.forward (one depth map: 1 reference + V source views already resident in
 HBM -> disparity in HBM) at BASELINE.json configs[1]: DTU 1600x1184, 10 source views, 32 GRU iterations
-(cascade (64,64,16),(-1,320,16)), synthetic images + closed-form weights, fp32 end to end.
+(cascade (64,64,16),(-1,320,16)), synthetic images + closed-form weights.  Tensors are fp32 end to end; the dense convolutions
+split their fp32 operands into f16 halves on the matrix cores (the JSON line's `dtype` and `gru_precision` say exactly how).
+With one GPU the timed steps are submitted to pipeline.DepthMapPipeline (`--streams`, default 3 depth maps in flight: the product's
+inference() default); `one_at_a_time` in the JSON line is the same forward with a single depth map in flight.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -22,7 +25,9 @@ the driver's keys it carries
   "roofline":     the dominant kernel (the z|r gate convolution, MFMA-bound) - algorithmic FLOPs per launch
                   divided by its average launch duration measured with HIP events on its stream,
   "cpu_baseline": the oracle (a CPU port of the reference's torch op sequence) timed on this box's host
-                  cores on a bounded sample of the same workload, extrapolated to depth-maps/s.
+                  cores on ONE WHOLE depth map of the same workload (median of 3 runs, thread count chosen by a small timed forward).
+N > 1 lines also carry "n1_one_at_a_time": rank 0's own single-GPU forward (one depth map at a time, unsharded), so that the
+strong-scaling ratio is taken against the regime the sharded modes run in (they keep one depth map in flight).
 """
 import argparse
 import json
@@ -283,6 +288,29 @@ def main():
     if modes is not None:
         modes[args.mode].update(value=args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps, headline=True)
     maps = args.steps * (world if (world > 1 and not shard) else 1)
+    # N > 1: the sharded modes keep ONE depth map in flight, the N = 1 headline three - the speed-up of N GPUs has to be taken against
+    # the single-GPU one-at-a-time forward (VERDICT r3 "weak" 7).  Rank 0 times it on its own GPU while the other ranks wait.
+    n1_ref = None
+    if world > 1:
+        if rank == 0:
+            m1 = RAFT(cascade=cascade, test_mode=True, precision=args.precision, gru_precision=args.gru_precision, encoder_backend=args.encoder)
+            m1.load_state_dict(sd)
+            m1 = m1.to(dev).eval()
+            with torch.no_grad():
+                for _ in range(3):
+                    m1(*inputs, scale=scale)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                k1 = max(3, min(args.steps, 10))
+                for _ in range(k1):
+                    m1(*inputs, scale=scale)
+                torch.cuda.synchronize()
+            t1 = (time.perf_counter() - t0) / k1
+            n1_ref = {"ms_per_depth_map": 1e3 * t1, "value": 1.0 / t1,
+                      "speedup_of_this_line": (maps / elapsed) * t1 if shard else None,
+                      "note": "rank 0's single-GPU forward of the same workload, one depth map at a time, unsharded: the base of the strong-scaling ratio"}
+            del m1
+        sync()
 
     result = None
     rec = None
@@ -445,6 +473,7 @@ def main():
                             else f"view-shard x{world} + all-reduce/stage") if shard else f"replica x{world}"),
                        **({"backend": "gloo (validation run, ranks may share a GPU)"} if (world > 1 and args.backend == "gloo") else {})},
             **({"modes": modes} if modes is not None else {}),
+            **({"n1_one_at_a_time": n1_ref} if n1_ref is not None else {}),
             **({"one_at_a_time": {"ms_per_depth_map": timed_run.one_at_a_time_ms, "value": 1e3 / timed_run.one_at_a_time_ms,
                                   "note": "the same forward with ONE depth map in flight (--streams 1): the latency of a depth map, and what "
                                           "`value` was in rounds 1-2.  `value` / `ms_per_step` above are the throughput with "

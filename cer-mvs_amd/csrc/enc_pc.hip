@@ -45,6 +45,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define PC_EPI_RAW 0
 #define PC_EPI_FMAP 1
 #define PC_EPI_CTX 2
+#define PC_EPI_FSPLIT 3                // feature maps straight into the cost volume's split-f16 operand planes (cost_lines.hip: feat_split_kernel)
 
 struct PcArgs {
     const float* srcA;                 // [N, h*w, CIN] channels-last
@@ -477,6 +478,7 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
         // tests in the common path hipcc turns every store into its own exec-mask branch).
         const int co = wn * 32 + li;
         float ssum = 0.f, ssq = 0.f;
+        bool fsat = false;
         // (one lane-dependent 32-bit offset per access pattern; everything else is uniform or immediate: the kernel has no registers to spare)
         float* Et_w = patch + cw * (32 * 36) + 4 * kg * 36 + li;                 // + ((r & 3) + 8 (r >> 2)) * 36
         const float* Et_r = patch + cw * (32 * 36) + (lane >> 3) * 36 + 4 * (lane & 7);   // + 8 jj * 36
@@ -494,6 +496,9 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
                     const int wob = a.wo + 2 * a.out_border;
                     o = a.out + (((long)img * (a.ho + 2 * a.out_border) + gy + a.out_border) * wob + tx0 + a.out_border) * COUT + wn * 32;
                     pstride = COUT;
+                } else if (EPI == PC_EPI_FSPLIT) {
+                    o = nullptr;                                                 // (8-byte plane stores below)
+                    pstride = 0;
                 } else {
                     constexpr int HALF = COUT / 2, HW_ = C::WN / 2;              // waves 0 .. WN/2-1: tanh -> out, the rest: relu -> out2
                     o = (wn < HW_ ? a.out : a.out2) + (((long)img * a.ho + gy) * a.wo + tx0) * HALF + (wn % HW_) * 32;
@@ -510,6 +515,8 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
                         }
                     } else if (EPI == PC_EPI_FMAP) {
                         v *= a.out_scale;
+                    } else if (EPI == PC_EPI_FSPLIT) {
+                        v *= a.out_scale * 64.0f;                                // x * 2^CL_LOG2S of cost_lines.hip (out_scale = 1/8: exact)
                     } else {
                         v = (wn < C::WN / 2) ? tanhf(v) : fmaxf(v, 0.f);
                     }
@@ -519,13 +526,36 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const float4 v4 = *reinterpret_cast<const float4*>(Et_r + 8 * jj * 36);       // (LDS operations of a wave execute in order)
-                    if (PC_ABL & 2) asm volatile("" :: "v"(v4.x), "v"(v4.y), "v"(v4.z), "v"(v4.w));
+                    if (EPI == PC_EPI_FSPLIT) {
+                        // planes p = hl * 4 + ks of block `img`: halves at ((img * 8 + p) * bt + t) * 16 + c; this lane holds channels
+                        // wn * 32 + 4 g4 + 0..3 of pixel tx0 + px: ks = 2 wn + (g4 >> 2), c = 4 (g4 & 3) .. + 3 -> 8 bytes per plane
+                        const int px = (lane >> 3) + 8 * jj, g4 = lane & 7;
+                        if (FULL || (gy < a.ho && tx0 + px < a.wo)) {
+                            cer_f2 x0 = (cer_f2){v4.x, v4.y}, x1 = (cer_f2){v4.z, v4.w};
+                            if (!(fabsf(v4.x) <= 65504.0f) || !(fabsf(v4.y) <= 65504.0f) || !(fabsf(v4.z) <= 65504.0f) || !(fabsf(v4.w) <= 65504.0f)) fsat = true;
+                            x0 = __builtin_elementwise_min(__builtin_elementwise_max(x0, (cer_f2){-65504.0f, -65504.0f}), (cer_f2){65504.0f, 65504.0f});
+                            x1 = __builtin_elementwise_min(__builtin_elementwise_max(x1, (cer_f2){-65504.0f, -65504.0f}), (cer_f2){65504.0f, 65504.0f});
+                            const cer_h2 h0 = __builtin_convertvector(x0, cer_h2), h1 = __builtin_convertvector(x1, cer_h2);
+                            const cer_h2 l0 = __builtin_convertvector(x0 - __builtin_convertvector(h0, cer_f2), cer_h2);
+                            const cer_h2 l1 = __builtin_convertvector(x1 - __builtin_convertvector(h1, cer_f2), cer_h2);
+                            typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+                            // uniform row base + one 32-bit lane offset (the kernel has no registers to spare)
+                            const int wob = a.wo + 2 * a.out_border, bt16 = (a.ho + 2 * a.out_border) * wob * 16;
+                            _Float16* rowb = reinterpret_cast<_Float16*>(a.out) + ((long)img * 8 + 2 * wn) * bt16 +
+                                             ((long)(gy + a.out_border) * wob + tx0 + a.out_border) * 16;
+                            const int loff = ((lane >> 3) + 8 * jj) * 16 + 4 * (g4 & 3) + (g4 >> 2) * bt16;
+                            *reinterpret_cast<half4_t*>(rowb + loff) = (half4_t){h0.x, h0.y, h1.x, h1.y};
+                            *reinterpret_cast<half4_t*>(rowb + loff + 4 * (long)bt16) = (half4_t){l0.x, l0.y, l1.x, l1.y};
+                        }
+                    } else if (PC_ABL & 2) asm volatile("" :: "v"(v4.x), "v"(v4.y), "v"(v4.z), "v"(v4.w));
                     else if (FULL || (gy < a.ho && tx0 + (lane >> 3) + 8 * jj < a.wo)) *reinterpret_cast<float4*>(o + lane_off + 8 * jj * pstride) = v4;
                 }
             }
         };
         if (ty0 + C::RPW <= a.ho && tx0 + 32 <= a.wo) epilogue(std::true_type{});
         else epilogue(std::false_type{});
+        if (EPI == PC_EPI_FSPLIT && a.out2 && __ballot(fsat) != 0ull && lane == 0)          // sticky: a feature beyond +-1023 was clamped (bit 1)
+            atomicOr(reinterpret_cast<int*>(a.out2), 1);
         if (EPI == PC_EPI_RAW && a.part) {
             const float s2 = ssum + __shfl_xor(ssum, 32), q2 = ssq + __shfl_xor(ssq, 32);
             if (kg == 0) {
@@ -595,7 +625,7 @@ extern "C" int cer_enc_pc_supported(int Cin, int Cout, int taps, int stride, int
         if (Cin == 64 && Cout == 64 && taps == 9 && stride == 1) return 1;
         return 0;
     }
-    if (epi == PC_EPI_FMAP) return Cin == 64 && Cout == 64 && taps == 1 && stride == 1;
+    if (epi == PC_EPI_FMAP || epi == PC_EPI_FSPLIT) return Cin == 64 && Cout == 64 && taps == 1 && stride == 1;
     if (epi == PC_EPI_CTX) return Cin == 64 && Cout == 128 && taps == 1 && stride == 1;
     return 0;
 }
@@ -636,6 +666,7 @@ extern "C" int cer_enc_pc_conv(const float* srcA, const float* statsA, const flo
     a.out_scale = out_scale;
     hipStream_t st = (hipStream_t)stream;
     if (epi == PC_EPI_FMAP) return pc_launch<64, 64, 1, 1, PC_EPI_FMAP>(a, N, st);
+    if (epi == PC_EPI_FSPLIT) return pc_launch<64, 64, 1, 1, PC_EPI_FSPLIT>(a, N, st);
     if (epi == PC_EPI_CTX) return pc_launch<64, 128, 1, 1, PC_EPI_CTX>(a, N, st);
     if (Cin == 32 && Cout == 32) return pc_launch<32, 32, 1, 9, PC_EPI_RAW>(a, N, st);
     if (Cin == 32 && taps == 9) return pc_launch<32, 64, 2, 9, PC_EPI_RAW>(a, N, st);

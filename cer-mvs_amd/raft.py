@@ -256,6 +256,25 @@ class RAFT(nn.Module):
         done.record(side)                      # (the caller waits for it right before the view reduction: the hoisted convs run meanwhile)
         return net, inp, f1, buf, (f1s, f2s), (done, lws)
 
+    DIRECT_SPLIT = _os.environ.get("CER_DIRECT_SPLIT", "1") == "1"
+
+    def _encode_direct_split(self, images, V, h, w):
+        """encode() whose feature head writes the cost volume's split-f16 operand planes directly -> (net, inp, (f1s, f2s, slots))."""
+        from .encoder_hip import HipEncoder
+        dev = images.device
+        if self._engines is None or self._engines[0] != dev:
+            self._engines = (dev, HipEncoder(self.fnet, dev), HipEncoder(self.cnet, dev))
+        _, eng_f, eng_c = self._engines
+        net, inp, _, _ = eng_c.context(images[0, :1], raw=True)
+        key = ("split", V, h, w, str(dev))
+        buf = self._src_buf.get(key)
+        if buf is None:                        # border texels are written once (zeros) and never touched again
+            buf = (torch.zeros(V, (h + 4) * (w + 4), 128, device=dev, dtype=torch.float16), torch.arange(V, device=dev, dtype=torch.int32))
+            self._src_buf = {key: buf}
+        f1s = torch.empty(h * w, 128, device=dev, dtype=torch.float16)
+        eng_f.features_split(images[0], f1s, buf[0], n_ref=1, border=2, scale=0.125, raw=True, flag=ops.overflow_flag(dev))
+        return net, inp, (f1s, buf[0], buf[1])
+
     # ---------------------------------------------------------------- forward
     def forward(self, images, poses, intrinsics, scale=None, do_report=False):
         if not images.is_cuda:
@@ -369,8 +388,19 @@ class RAFT(nn.Module):
         pipelined = (self.PIPELINE_BUILD and self.view_group is None and V >= 2 and self.encoder_backend == "hip" and self.precision == "fp32"
                      and self.encoder_type == "HR" and self.dim_fmap == 64 and D0 <= 64 and L.load().cer_cost_build_algo(-1) != 1)
         split = None
+        # single-GPU fast path: when every stage builds its volume on the epipolar-line tiles, the feature head writes the split-f16
+        # operand planes itself (encoder_hip.features_split): no fp32 feature maps, no feat_split pass
+        direct_split = (self.DIRECT_SPLIT and not pipelined and self.view_group is None and V >= 1 and self.encoder_backend == "hip"
+                        and self.precision == "fp32" and self.encoder_type == "HR" and self.dim_fmap == 64
+                        and L.load().cer_cost_build_algo(-1) != 1 and all(D_ <= 64 for D_, _, _ in self.stages()))
+        if direct_split:
+            from . import encoder_hip
+            direct_split = encoder_hip.ENGINE == "pc"
         if pipelined:
             net_l, inp_l, f1, f2, split, build_done = self._encode_pipelined(images, V, Pij, disp, D0, incre0, h, w)
+        elif direct_split:
+            net_l, inp_l, split = self._encode_direct_split(images, V, h, w)
+            f1, f2 = split[0], None                       # (cost_build takes the device from its first argument; the rows are never read)
         else:
             net_l, inp_l, f1, f2 = self.encode(images, views, raw=True)
         if ub.conv_mode == "s16":
@@ -400,7 +430,8 @@ class RAFT(nn.Module):
                 vol, origin = ops.cost_lines_reduce(disp, V, h, w, D, incre, True, ub.num_levels, pyramid_scale=1.0 / V, ws=build_done[1])
             elif views:
                 vol, origin = ops.cost_build(f1, f2, Pij, disp, D, incre, stage == 0, h, w, ub.num_levels, fold=True,
-                                             pyramid_scale=(1.0 / V) if (single and D <= 64) else None, split=split)
+                                             pyramid_scale=(1.0 / V) if (single and D <= 64) else None, split=split,
+                                             src_hw=(h, w) if f2 is None else None)
             else:                      # more ranks than views: contribute zeros
                 _, _, rs = ops.row_layout(D, ub.num_levels)
                 vol = torch.zeros(P, rs, device=dev)

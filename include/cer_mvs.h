@@ -404,6 +404,9 @@ int cer_enc_merge_f32(const float* a, const float* a_stats, const float* b, cons
  * merged_out (optional, stride 1, needs srcB) receives x once per pixel [N, h*w, Cin] for a later residual branch.
  * Same packed weights (cer_enc_conv_pack), same arithmetic (three f16 MFMA terms, two fp32 accumulators) and the same epilogues
  * (epi 0 RAW / 1 FMAP / 2 CTX) as cer_enc_conv_f16x3; stats_partial (RAW) is [N][cer_enc_pc_tiles(...)][Cout][2].
+ * epi 3 FSPLIT (64 -> 64 1x1 only): as FMAP, but the scaled map is written straight into the split-f16 operand planes of
+ * cer_cost_lines_f32 - `out` = [N][8 planes][(ho+2b)*(wo+2b)][16] halves, exactly what cer_feat_split_f16 makes of the FMAP output
+ * (border texels are not written: zero the buffer once); `out2`, if not NULL, is the device overflow flag (int*; bit 1 on saturation).
  * Shapes: cer_enc_pc_supported(Cin, Cout, taps, stride, epi) != 0 - the "HR" encoder's: 32->32 3x3; 32->64 3x3 / 1x1 stride 2;
  * 64->64 3x3; 64->64 1x1 FMAP; 64->128 1x1 CTX.  Everything else returns CER_ESHAPE (use cer_enc_conv_f16x3). */
 int cer_enc_pc_supported(int Cin, int Cout, int taps, int stride, int epi);

@@ -640,6 +640,30 @@ def test_stem_on_matrix_cores(dev, size, raw):
     assert rel_l1(outs["mfma"][0], outs["fp32"][0]) < 1e-6
 
 
+@pytest.mark.parametrize("size", [(72, 104), (128, 160), (100, 132)])
+def test_encoder_head_writes_split_planes_directly(dev, size):
+    """features_split (the fnet head's FSPLIT epilogue, csrc/enc_pc.hip) == feat_split(features(...)): the split-f16 operand planes of the
+    cost volume bit for bit - reference map and bordered source maps, partial tiles included - and the overflow flag stays clear."""
+    from cer_mvs_amd import RAFT, ops
+    from cer_mvs_amd.encoder_hip import HipEncoder
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+    images, _, _, _ = synthetic_scene(size[0], size[1], 3, seed=8)
+    model = RAFT(test_mode=True)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=13))
+    eng = HipEncoder(model.fnet, dev)
+    x = images[0].float().to(dev)
+    N = x.shape[0]
+    with torch.no_grad():
+        ref, src, h, w = eng.features(x, n_ref=1, raw=True)
+        want_ref, want_src = ops.feat_split(ref[0]), ops.feat_split(src)
+        f1s = torch.full((h * w, 128), float("nan"), device=dev, dtype=torch.float16)
+        f2s = torch.zeros(N - 1, (h + 4) * (w + 4), 128, device=dev, dtype=torch.float16)
+        assert eng.features_split(x, f1s, f2s, n_ref=1, raw=True, flag=ops.overflow_flag(dev)) == (h, w)
+    assert torch.equal(f1s.view(torch.int16), want_ref.view(torch.int16))
+    assert torch.equal(f2s.view(torch.int16), want_src.view(torch.int16))
+    assert not ops.check_overflow(dev)
+
+
 def test_encoder_engine_batch_invariance_at_tnt_size(dev):
     """BASELINE.json configs[2] size (3840x2160, 16 images per fnet launch): layer-1 activations are 16 x 1080 x 1920 x 32
     floats = 4.2 GB, i.e. element offsets beyond 2^31 bytes.  Instance norm is per image, so the batched launch must
