@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CER_MVS_LIB") or os.path.join(_HERE, "csrc", "libcermvs.so")
-ABI_VERSION = 1040
+ABI_VERSION = 1041
 CONV_MAX_SRC = 4
 EPI_LINEAR, EPI_RELU, EPI_GATES, EPI_GRU, EPI_DELTA = 0, 1, 2, 3, 4
 EPI_OUT_SPLIT, EPI_AUX_SPLIT = 0x100, 0x200       # cer_mvs.h: split32 activation layout flags, or-ed into `epi`
@@ -48,6 +48,8 @@ _SIGNATURES = {
     "cer_alt_corr_bwd_reduce_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "cer_cost_build_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _D, _I, _I, _I, _I, _F, _P]),
     "cer_cost_build_algo": (_I, [_I]),
+    "cer_cost_lines_form": (_I, [_I]),
+    "cer_cost_lines_stats": (_I, [_P, _I]),
     "cer_conv3x3_s16_pc": (_I, [_I]),
     "cer_overflow_flag": (_I, [_P]),
     "cer_f16_scan_overflow": (_I, [_P, _L, _P, _I, _P]),

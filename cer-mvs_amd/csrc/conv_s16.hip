@@ -38,7 +38,7 @@ struct SxStage {                           // what to put into the NEXT activati
 };
 
 template <int WM_, int WN_, int MT, int EPI, int F8>
-__global__ __launch_bounds__(256, 2) void conv3x3_s16_kernel(const S16Args a) {
+__global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : 2) void conv3x3_s16_kernel(const S16Args a) {
     constexpr int TH = WM_ * 2 * MT, HR = TH + 2;
     constexpr int ABUF = HR * (F8 ? SX_ROWB8 : SX_ROWB);
     constexpr int NPIX = HR * SX_HW, NITEM = NPIX * 4, ITEMS = (NITEM + 255) / 256;

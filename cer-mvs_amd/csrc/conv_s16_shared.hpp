@@ -23,6 +23,9 @@ typedef int intx8 __attribute__((ext_vector_type(8)));
 // generator variant produced intermittently wrong last tile rows and became clean with them; the cause was not identified (DESIGN.md 3g:
 // two candidate hardware hazards were excluded by micro-tests).  The form that ships never failed with or without them.
 #define SX_LDS_STORE_WAIT() asm volatile("s_nop 3" ::: "memory")
+#ifndef SX_OCC3
+#define SX_OCC3 0    // 1: the 64-channel fp8-correction kernels (q, corr2: 52.7 KB of LDS per block) aim at three blocks per CU (167 VGPRs, 8 spilled): measured q 70.0 vs 63.5 us, corr2 30.3 vs 32.7, end to end the same - off
+#endif
 #ifndef SX_TRACE
 #define SX_TRACE 0   // variant builds only (tools/trace_s16.py): per wave cycle stamps + HW_ID written to `aux2` (GATES: unused there)
 #endif

@@ -129,13 +129,22 @@ int cer_cost_build_algo(int algo);
  *   p = hl * 4 + ks (hl 0 / 1: hi = f16(xs) / lo = f16(xs - hi) of xs = x * 2^6; ks: 16-channel group), each [block_texels][16];
  *   a block = one view (block_texels = (h2+4)*(w2+4), zero border included and kept zero) or the reference map (h1*w1).
  *   |x| > 1023 saturates: *overflow_flag (device int, may be NULL) is or-ed with 1.
- * cer_cost_lines_workspace: bytes of `workspace` (per-view partial volumes [V,P,D] + tile parameters).
+ * cer_cost_lines_workspace: bytes of `workspace` (per-view partial volumes [V,P,D] + tile parameters + the hand-over list below).
+ * cer_cost_lines_form: which kernel builds the partial volumes: 0 (default) one line per 256-thread block (round 3); 1 = several
+ *   neighbouring lines of a segment per block sharing ONE band fetched through LDS (round 4 experiment: 2 x fewer texel bytes through
+ *   the CU's vector-memory path, but more vector instructions per sample - measured no faster; lines whose bands do not
+ *   fit its window are listed in the workspace and finished by the one-line kernel in the same call).  Same cells, weights and dot
+ *   products: the two forms agree bit for bit.  Process-wide like cer_cost_build_algo (CER_COST_LINES_FORM in the environment sets
+ *   the initial value); returns the previous setting, < 0 only queries.
  * cer_cost_lines_f32: arguments as cer_cost_build_f32 with the split rows in place of fmap1 / fmap2; mode 1 or 2 only.
  *   view_slot (device int [V], may be NULL = identity): view v's rows are block view_slot[v] of fmap2_split - the multi-GPU
  *   forward all-gathers every rank's split rows into one [G, ceil(V/G), ...] buffer and builds from it without a reordering copy.
  */
 int cer_feat_split_f16(const float* src, void* dst, long blocks, long block_texels, int C, int* overflow_flag, void* stream);
 long cer_cost_lines_workspace(int V, int h1, int w1, int D);
+int cer_cost_lines_form(int form);
+/* Diagnostics: 32 counters of the eight-line kernel (all zero unless the library was built with -DC8_STATS=1) to host memory. */
+int cer_cost_lines_stats(unsigned long long* out, int reset);
 int cer_cost_lines_f32(const void* fmap1_split, const void* fmap2_split, const int* view_slot, const float* Pij, const float* disp_in,
                        float* vol, float* origin_out, void* workspace,
                        int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride,

@@ -271,6 +271,11 @@ def _lines_case(dev, D, stage0, geom, h1, w1):
             c = torch.tensor([0.0, 0.0, 600.0])
             Pij[v, :3, :3] = K @ R @ torch.linalg.inv(K)
             Pij[v, :3, 3] = K @ (c - R @ c)
+        elif geom == "zoom":              # source view magnified 6x: neighbouring lines are 6 texels apart (eight-line form: todo list)
+            Pij[v, 0, 0] = Pij[v, 1, 1] = 6.0
+            Pij[v, 0, 2], Pij[v, 1, 2] = -2.5 * w1, -2.5 * h1
+            Pij[v, 0, 3] = (2500.0 if stage0 else 25000.0) * (v + 1)
+            Pij[v, 1, 3] = 300.0 * v
         else:   # wild: Z = 1 + m[11] * hyp crosses zero inside the range; one view entirely behind the camera
             Pij[v, 0, 3], Pij[v, 2, 3] = 4000.0, (-700.0, -1500.0, 0.0)[v]
             if v == 2:
@@ -279,16 +284,27 @@ def _lines_case(dev, D, stage0, geom, h1, w1):
     return f1, f2, Pij.to(dev), d0, V
 
 
-@pytest.mark.parametrize("geom", ["horizontal", "diagonal", "vertical", "wild", "rotation", "forward", "converging"])
+@pytest.mark.parametrize("geom", ["horizontal", "diagonal", "vertical", "wild", "rotation", "forward", "converging", "zoom"])
 @pytest.mark.parametrize("D,stage0", [(64, True), (44, False), (20, False)])
-def test_cost_lines_matches_walk(dev, D, stage0, geom):
+@pytest.mark.parametrize("form", [0, 1])
+def test_cost_lines_matches_walk(dev, D, stage0, geom, form):
     """The round-3 fold kernel (epipolar-line tiles: MFMA band products + 4-tap gather, csrc/cost_lines.hip) against the
     wave-per-pixel walk on the same inputs: epipolar lines of every direction (both tile axes, both band axes, both travel
     directions), a view whose projection blows up (Z crosses 0 inside the hypothesis range: direct per-sample path), no
     baseline, an epipole inside the image, image sizes with partial tiles and several segments, a row-slab offset,
-    accumulate mode and the fused pyramid."""
+    accumulate mode and the fused pyramid.  form 0: one line per block (the default); form 1: several lines per block sharing one band
+    (round 4 experiment; the "zoom" geometry spreads the lines of a block too far apart for its window and goes through its hand-over list)."""
     from cer_mvs_amd import _lib as L, ops
     lib = L.load()
+    prev_form = lib.cer_cost_lines_form(form)
+    try:
+        _cost_lines_matches_walk(dev, D, stage0, geom, lib)
+    finally:
+        lib.cer_cost_lines_form(prev_form)
+
+
+def _cost_lines_matches_walk(dev, D, stage0, geom, lib):
+    from cer_mvs_amd import ops
     for h1, w1 in ((19, 45), (70, 150)):
         f1, f2, Pij, d0, V = _lines_case(dev, D, stage0, geom, h1, w1)
         incre = 0.0025 / (64 if stage0 else 320)

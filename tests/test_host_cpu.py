@@ -49,7 +49,12 @@ def test_argument_errors_without_device():
     assert lib.cer_feat_split_f16(null, null, 1, 10, 64, null, null) == -1
     assert lib.cer_feat_split_f16(fake, fake, 1, 10, 32, null, null) == -2                                     # C != 64
     assert lib.cer_feat_split_f16(misaligned, fake, 1, 10, 64, null, null) == -3
-    assert lib.cer_cost_lines_workspace(10, 296, 400, 64) == 10 * 296 * 400 * 64 * 4 + 10 * 16 + 256 and lib.cer_cost_lines_workspace(0, 1, 1, 1) == -1
+    # partial volumes + tile parameters + the hand-over list of the eight-line form (one entry per one-line tile of a view)
+    tiles = max(13 * ((296 + 32 + 15) // 16 * 16), 10 * ((400 + 32 + 15) // 16 * 16))
+    assert lib.cer_cost_lines_workspace(10, 296, 400, 64) == 10 * 296 * 400 * 64 * 4 + 10 * 16 + 256 + 10 * (tiles + 1) * 8 + 64
+    assert lib.cer_cost_lines_workspace(0, 1, 1, 1) == -1
+    prev = lib.cer_cost_lines_form(-1)
+    assert prev in (0, 1) and lib.cer_cost_lines_form(1) == prev and lib.cer_cost_lines_form(prev) == 1 and lib.cer_cost_lines_form(-1) == prev
     args = (1, 4, 4, 4, 4, 64, 64, 112, dbl, 1)
     assert lib.cer_cost_lines_f32(null, null, null, null, null, null, null, null, *args, 1, 0, 0, 1.0, null) == -1
     assert lib.cer_cost_lines_f32(fake, fake, null, fake, fake, fake, fake, fake, *args, 0, 0, 0, 1.0, null) == -1      # mode 0: per-view volumes are the walk's
