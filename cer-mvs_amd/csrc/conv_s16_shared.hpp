@@ -24,7 +24,8 @@ typedef int intx8 __attribute__((ext_vector_type(8)));
 // two candidate hardware hazards were excluded by micro-tests).  The form that ships never failed with or without them.
 #define SX_LDS_STORE_WAIT() asm volatile("s_nop 3" ::: "memory")
 #ifndef SX_OCC3
-#define SX_OCC3 0    // 1: the 64-channel fp8-correction kernels (q, corr2: 52.7 KB of LDS per block) aim at three blocks per CU (167 VGPRs, 8 spilled): measured q 70.0 vs 63.5 us, corr2 30.3 vs 32.7, end to end the same - off
+#define SX_OCC3 0    // 1: the 64-channel fp8-correction kernels aim at three blocks per CU (167 VGPRs, 8 spilled; fits with 8-row tiles, tile_mt 2:
+                     // 52.7 KB of LDS per block).  Measured at 296 x 400: q 70.3 us against 65.2 (default, 12-row tiles, two blocks), corr2 32.1 / 32.3 - off
 #endif
 #ifndef SX_TRACE
 #define SX_TRACE 0   // variant builds only (tools/trace_s16.py): per wave cycle stamps + HW_ID written to `aux2` (GATES: unused there)
