@@ -19,10 +19,17 @@ typedef int intx8 __attribute__((ext_vector_type(8)));
 #define SX_DTW 24                          // disparity tile columns (halo + 3 each side)
 #define SX_EPI_DELTA 4
 #define SX_HID_LOG2 4                      // scale of the delta head's hidden activations (relu outputs)
-// Wait states (and a compiler memory barrier) behind the 16-byte LDS stores of the disparity generators: an EMPIRICAL margin.  One
-// generator variant produced intermittently wrong last tile rows and became clean with them; the cause was not identified (DESIGN.md 3g:
-// two candidate hardware hazards were excluded by micro-tests).  The form that ships never failed with or without them.
+// Wait states (and a compiler memory barrier) behind the 16-byte LDS stores of the disparity generators: an EMPIRICAL margin of round 3.
+// One generator variant produced intermittently wrong last tile rows and became clean with them; two candidate hardware hazards were
+// excluded by micro-tests then.  Round 4 found what fails on this chip - packed-fp32 instructions that take their low result from src1's
+// high half, next to f16 MFMA waves (tools/check_isa.py) - and the statement most likely only changed what hipcc emitted
+// around it; the variant is gone and cannot be re-checked.  The form that ships contains no such instruction with or without the
+// statement (-DSX_NO_STORE_WAIT: same scan result) and never failed either way.
+#ifndef SX_NO_STORE_WAIT
 #define SX_LDS_STORE_WAIT() asm volatile("s_nop 3" ::: "memory")
+#else
+#define SX_LDS_STORE_WAIT() do { } while (0)
+#endif
 #ifndef SX_OCC3
 #define SX_OCC3 0    // 1: the 64-channel fp8-correction kernels aim at three blocks per CU (167 VGPRs, 8 spilled; fits with 8-row tiles, tile_mt 2:
                      // 52.7 KB of LDS per block).  Measured at 296 x 400: q 70.3 us against 65.2 (default, 12-row tiles, two blocks), corr2 32.1 / 32.3 - off

@@ -224,3 +224,49 @@ def test_precision_margin_under_weight_gain(dev, gain, tail):
             assert choice == "s16"
     else:
         assert choice == "s16"
+
+
+def test_lookup_and_convs_reproduce_next_to_an_fp16_gemm(dev):
+    """Round 4's root cause of the intermittent failures of rounds 2 and 3: packed-fp32 instructions that take their low
+    result from the high half of src1 go wrong on MI355X while f16 / bf16 MFMA waves share the CU.  tests/test_isa_hazard_cpu.py keeps the
+    form out of the library; this is the dynamic side: the lookup, the z|r gate convolution (both arithmetic forms) and the encoder's
+    first layer run on one stream while an fp16 GEMM (hipBLASLt) runs on another, and every launch must reproduce the solo result."""
+    from cer_mvs_amd import _lib as L, ops
+    h, w, D = 296, 400, 64
+    P = h * w
+    U, R, Dp = L.S16_UNIT, L.S16_RELU, L.S16_DISP
+    vol = hashed((P, 112), 921, -8, 8).to(dev)
+    origin = torch.full((P,), 0.00125, device=dev)
+    incre = 0.0025 / 64
+    disp = hashed((P,), 922, 0.0, 60 * incre).to(dev)
+    wt, b = hashed((33, 64), 923, -0.5, 0.5).to(dev), hashed((64,), 924, -0.5, 0.5).to(dev)
+    net_s = ops.to_frag16(_nhwc(torch.tanh(hashed((1, 64, h, w), 925, -2, 2))).to(dev), h, w, U)
+    c2_s = ops.to_frag16(_nhwc(torch.relu(hashed((1, 64, h, w), 926, -1, 2))).to(dev), h, w, R)
+    dsp = hashed((P,), 927, 0.0005, 0.0025).to(dev)
+    src = [(64, 2, U), (49, 1, Dp), (64, 2, R)]
+    wzr = hashed((128, 177, 3, 3), 928, -0.05, 0.05)
+    pz = {f8: ops.PackedConvS16(wzr, None, src, dev, corr_fp8=f8) for f8 in (False, True)}
+    cases = {
+        "lookup": lambda: ops.lookup_encode(vol, origin, disp, wt, b, D, incre, 3, 5, out_split=2, log2s=4, img_w=w),
+        "gates s16": lambda: ops.conv3x3_s16(pz[False], [net_s, dsp, c2_s], h, w, L.EPI_GATES, aux=net_s, log2s_out=U, log2s_aux=U),
+        "gates s16f8": lambda: ops.conv3x3_s16(pz[True], [net_s, dsp, c2_s], h, w, L.EPI_GATES, aux=net_s, log2s_out=U, log2s_aux=U),
+    }
+    a16 = torch.randn(2048, 2048, device=dev, dtype=torch.float16)
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    for name, fn in cases.items():
+        solo = fn()
+        solo = [o.clone() for o in (solo if isinstance(solo, (tuple, list)) else (solo,))]
+        torch.cuda.synchronize()
+        bad = 0
+        for _ in range(10):
+            with torch.cuda.stream(sB):
+                for _ in range(30):
+                    a16 @ a16
+            outs = []
+            with torch.cuda.stream(sA):
+                for _ in range(10):
+                    o = fn()
+                    outs.append([t.clone() for t in (o if isinstance(o, (tuple, list)) else (o,))])
+            torch.cuda.synchronize()
+            bad += sum(0 if all(torch.equal(x, y) for x, y in zip(o, solo)) else 1 for o in outs)
+        assert bad == 0, f"{name}: {bad} of 100 launches next to an fp16 GEMM differ from the solo result"
