@@ -45,6 +45,13 @@ class DepthMapPipeline:
         k = self._next % len(self.streams)
         self._next += 1
         st = self.streams[k]
+        m = self.models[k]
+        if k and getattr(m, "gru_precision", None) == "auto" and m._auto_pending():
+            # one arithmetic form for all replicas: the first model's calibration decides.  If that model has not calibrated these weights
+            # yet (first submission, or right after refresh_weights), this submission goes to it
+            if not m.adopt_precision(self.models[0]) and self.models[0]._auto_pending():
+                k = 0
+                st = self.streams[0]
         st.wait_stream(torch.cuda.current_stream(self.device))       # inputs produced on the caller's stream
         with torch.cuda.stream(st), torch.no_grad():
             out = self.models[k](images, poses, intrinsics, scale=scale, **kw)

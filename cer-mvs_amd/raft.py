@@ -326,6 +326,19 @@ class RAFT(nn.Module):
     def _auto_pending(self):
         return self.update_block.conv_mode == "s16" and self._auto_sig != self._params_sig()
 
+    def adopt_precision(self, other):
+        """Take over another model's gru_precision="auto" decision instead of calibrating (the caller vouches that the weights are the
+        same: DepthMapPipeline's replicas are deep copies of its first model).  Keeps the replicas of a pipeline on ONE arithmetic form -
+        separate calibrations on different inputs could decide differently near the tolerance - and saves their calibration forwards.
+        Returns True if a decision was adopted."""
+        if (self.gru_precision != "auto" or other.gru_precision != "auto" or other.auto_choice is None or other._auto_pending()
+                or self.update_block.conv_mode != other.update_block.conv_mode):
+            return False
+        self.update_block.corr_fp8 = other.update_block.corr_fp8
+        self.auto_choice, self.auto_error = other.auto_choice, other.auto_error
+        self._auto_sig = self._params_sig()
+        return True
+
     def _forward_calibrating(self, images, poses, intrinsics, scale, do_report):
         """gru_precision="auto": this set of weights has not been calibrated yet - run the forward in both split-f16 forms, keep the
         fp8-correction form if it stays within AUTO_TOL of the fp32-class one on this input (all ranks of a view_group agree on the

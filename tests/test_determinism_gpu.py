@@ -270,3 +270,35 @@ def test_lookup_and_convs_reproduce_next_to_an_fp16_gemm(dev):
             torch.cuda.synchronize()
             bad += sum(0 if all(torch.equal(x, y) for x, y in zip(o, solo)) else 1 for o in outs)
         assert bad == 0, f"{name}: {bad} of 100 launches next to an fp16 GEMM differ from the solo result"
+
+
+def test_pipeline_replicas_adopt_the_first_models_precision_decision(dev, golden):
+    """gru_precision="auto" under DepthMapPipeline: the first model calibrates (its first submit), the replicas take over its decision instead of
+    calibrating on whatever input reaches them first - one arithmetic form per pipeline, one calibration per set of weights - and calibrate
+    again only after the weights changed."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.pipeline import DepthMapPipeline
+    from cer_mvs_amd.synthetic import fill_state_dict
+    g = golden("e2e_cfg1")
+    cascade = [tuple(int(x) for x in c) for c in g["cascade"]]
+    model = RAFT(cascade=cascade, test_mode=True)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(g["weight_seed"])))
+    model = model.to(dev).eval()
+    images, poses, intr, scale = cached_scene(int(g["H"]), int(g["W"]), int(g["V"]), int(g["scene_seed"]))
+    x = (images.to(dev), poses.to(dev), intr.to(dev), scale)
+    pipe = DepthMapPipeline(model, streams=3)
+    calls = []
+    for m in pipe.models:
+        orig = m._forward_calibrating
+        m._forward_calibrating = (lambda *a, _o=orig, _m=m, **k: (calls.append(id(_m)), _o(*a, **k))[1])
+    outs = list(pipe.map([x] * 7))
+    assert calls == [id(pipe.models[0])], "only the first model calibrates"
+    assert all(m.auto_choice == pipe.models[0].auto_choice and not m._auto_pending() for m in pipe.models)
+    assert all(torch.equal(o, outs[0]) for o in outs)
+    with torch.no_grad():
+        for p_ in pipe.models[0].parameters():
+            p_.mul_(1.0)                                   # in-place update: new version counters
+    pipe.refresh_weights()
+    calls.clear()
+    outs2 = list(pipe.map([x] * 4))
+    assert calls == [id(pipe.models[0])] and all(torch.equal(o, outs[0]) for o in outs2)
