@@ -15,15 +15,19 @@ run() {   # name, kernel regex, command...
   done
 }
 {
+  if [ -z "$PMC_ONLY_NEW" ]; then
   run enc_pc_32to32 "enc_pc_kernel<32, 32, 1, 9, 0, false>" python tools/bench_pc.py 32
   run enc_pc_32to32_dual "enc_pc_kernel<32, 32, 1, 9, 0, true>" python tools/bench_pc.py 32 dual
   run enc_pc_64to64 "enc_pc_kernel<64, 64, 1, 9, 0, false>" python tools/bench_pc.py 64
   run enc_pc_32to64_s2_dual "enc_pc_kernel<32, 64, 2, 9, 0, true>" python tools/bench_pc.py s2 dual
   run enc_stem_pc "enc_stem_pc_kernel" python tools/prof_enc.py pc fnet
   run conv3x3_gates_zr_f8 "conv3x3_s16_kernel<1, 4, 4, 2, 1>" python tools/bench_conv_s16.py --f8 --only "z|r" --rounds 1 --reps 1
-  run conv3x3_gru_q_f8 "conv3x3_s16_kernel<2, 2, 3, 3, 1>" python tools/bench_conv_s16.py --f8 --only "gru" --rounds 1 --reps 1
+  fi
+  run conv3x3_gru_q_f8 "conv3x3_s16_kernel<2, 2, ., 3, 1>" python tools/bench_conv_s16.py --f8 --only "gru" --rounds 1 --reps 1
   run conv3x3_delta_f8 "conv3x3_s16_kernel<1, 4, 4, 4, 1>" python tools/bench_conv_s16.py --f8 --only "delta" --rounds 1 --reps 1
-  run conv3x3_corr2_f8 "conv3x3_s16_kernel<2, 2, 3, 1, 1>" python tools/bench_conv_s16.py --f8 --only "corr2" --rounds 1 --reps 1
+  run conv3x3_corr2_f8 "conv3x3_s16_kernel<2, 2, ., 1, 1>" python tools/bench_conv_s16.py --f8 --only "corr2" --rounds 1 --reps 1
+  run cost_lines_kernel "cost_lines_kernel" python tools/prof_build.py
+  run lookup_encode "lookup_encode" python tools/prof_conv.py lookup --reps 1
 } | tee "$out/counters.txt"
 python tools/pmc_summary.py "$out/counters.txt" "$out/pmc_traffic.json" > /dev/null
 find "$out" -name "*.csv" -size +1M -delete
