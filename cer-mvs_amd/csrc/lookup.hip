@@ -87,24 +87,28 @@ __global__ __launch_bounds__(256) void lookup_kernel(const float* __restrict__ v
 // pipeline, and produced intermittently wrong features when a second process shared the GPU - 17 of 70 two-process runs against
 // 0 of 130 for this form; the cause was narrowed to the unrolled window code but not found.  It was removed.)
 // Happens-before: `rows` is written in front of [B1](t) and read (windows) between [B1](t) and [B2](t);
-// the next tile's writes follow [B2](t).  `feats` is double-buffered: half t & 1 is written between [B1](t) and [B2](t) and read by the
-// conv behind [B2](t); it is written again between [B1](t+2) and [B2](t+2), and a wave reaches [B1](t+1) only after its conv of tile t.
+// the next tile's writes follow [B2](t).  `feats` (ONE tile since round 4: the second half bought nothing) is written between [B1](t) and
+// [B2](t) and read by the conv behind [B2](t); it is written again behind [B1](t+1), which a wave passes only after EVERY wave has arrived
+// there - i.e. has finished its conv of tile t (the conv precedes the next tile's row stores and [B1](t+1) in every wave's program order).
 // The schedule-fuzz build (common.hpp CER_FUZZ) reproduces the first launch over 2 000 launches.
 #define LK_MAX_PRE 16      // float4 per thread of one 64-row tile: 64 * (LK_MAX_ROW / 4) / 256
-__global__ __launch_bounds__(256) void lookup_encode_kernel(const float* __restrict__ vol, const float* __restrict__ origin,
+// MAXPRE: float4 registers of the next tile's rows per thread (8 serve rows up to 128 floats - the model's 112 - and leave the kernel under
+// 128 VGPRs: four blocks per CU with the single feature tile; 16: any row the entry point accepts, three blocks per CU)
+template <int MAXPRE>
+__global__ __launch_bounds__(256, MAXPRE <= 8 ? 4 : 3) void lookup_encode_kernel(const float* __restrict__ vol, const float* __restrict__ origin,
                                                             const float* __restrict__ disp, const float* __restrict__ wgt,
                                                             const float* __restrict__ bias, float* __restrict__ out, long P, int D, int rs,
                                                             float incre, int L, int r, LevelInfo li, int out_split, float out_scale, int img_w,
                                                             int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float lk_smem[];
     const int rsp = rs + 4;
-    const int taps = 2 * r + 1, K = L * taps, FS = K | 1, fstride = LK_PIX * FS;     // (odd pixel stride: conflict-free columns)
+    const int taps = 2 * r + 1, K = L * taps, FS = K | 1;                         // (odd pixel stride: conflict-free columns)
     float* rows = lk_smem;                                   // [LK_PIX][rs + 4]
-    float* feats = lk_smem + LK_PIX * rsp;                   // [2][LK_PIX][FS]
+    float* feats = lk_smem + LK_PIX * rsp;                   // [LK_PIX][FS]  (one tile: see the happens-before note above)
     const int n4 = rs / 4, npre = (LK_PIX * n4 + 255) / 256;
     const int pix = threadIdx.x & 63;
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id: lookup level, then output-channel group
-    float4 pre[LK_MAX_PRE];
+    float4 pre[MAXPRE];
     float pre_d = 0.f, pre_o = 0.f;
     CER_FUZZ_INIT();
     // float4 number t = tid + 256 i of the tile is (row pr, quad q) = (t / n4, t % n4): walked incrementally (no division per item)
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void lookup_encode_kernel(const float* __restr
         if (pix < npix) { pre_d = disp[p0 + pix]; pre_o = origin[p0 + pix]; }    // ... and this thread's pixel's window position
         int pr = pr0, q = q0;
 #pragma unroll
-        for (int i = 0; i < LK_MAX_PRE; ++i) {            // (predicated, not `break`: pre[] must stay in registers)
+        for (int i = 0; i < MAXPRE; ++i) {                // (predicated, not `break`: pre[] must stay in registers)
             if (i < npre) {
                 pre[i] = pr < npix ? cer_ld4(src + (long)(threadIdx.x + 256 * i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 pr += dpr; q += dq;
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(256) void lookup_encode_kernel(const float* __restr
         {
             int pr = pr0, q = q0;
 #pragma unroll
-            for (int i = 0; i < LK_MAX_PRE; ++i) {
+            for (int i = 0; i < MAXPRE; ++i) {
                 if (i < npre) {
                     if (pr < LK_PIX) *reinterpret_cast<float4*>(&rows[pr * rsp + 4 * q]) = pre[i];
                     pr += dpr; q += dq;
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(256) void lookup_encode_kernel(const float* __restr
         __syncthreads();                                     // [B1] rows complete; the previous tile's windows were read before its [B2]
         CER_FUZZ_POINT();
         if (tile + (int)gridDim.x < ntiles) request(tile + gridDim.x);
-        float* ft = feats + (it & 1) * fstride;
+        float* ft = feats;
         if (active)
             for (int lv = grp; lv < L; lv += 4)            // (straight into the feature tile: no per-thread array)
                 lk_window(&rows[pix * rsp], li.off[lv], li.len[lv], c / (float)(1 << lv), r, &ft[pix * FS + lv * taps]);
@@ -247,7 +251,7 @@ extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, cons
     const int K = num_levels * (2 * radius + 1);
     const long ntiles = (P + LK_PIX - 1) / LK_PIX;
     if (ntiles >= (1L << 30)) return CER_ESHAPE;
-    const size_t smem = sizeof(float) * LK_PIX * ((size_t)(row_stride + 4) + 2 * (K | 1));
+    const size_t smem = sizeof(float) * LK_PIX * ((size_t)(row_stride + 4) + (K | 1));
     static int ncu = 0;
     if (ncu == 0) {
         int dev = 0;
@@ -255,10 +259,15 @@ extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, cons
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
         if (ncu <= 0) ncu = 256;
     }
-    const long resident = (long)ncu * (smem <= 50 * 1024 ? 3 : smem <= 76 * 1024 ? 2 : 1);
+    const bool small = row_stride <= 128;                    // 8 prefetch registers per thread suffice: the four-blocks-per-CU instantiation
+    const long resident = (long)ncu * (small && smem <= 39 * 1024 ? 4 : smem <= 50 * 1024 ? 3 : smem <= 76 * 1024 ? 2 : 1);
     const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);
-    hipLaunchKernelGGL(lookup_encode_kernel, dim3(grid), dim3(256), smem, (hipStream_t)stream, vol, origin, disp, w, b, out, P, D, row_stride,
-                       (float)incre, num_levels, radius, li, out_split, ldexpf(1.0f, log2s_out), img_w, (int)ntiles);
+    if (small)
+        hipLaunchKernelGGL(lookup_encode_kernel<8>, dim3(grid), dim3(256), smem, (hipStream_t)stream, vol, origin, disp, w, b, out, P, D, row_stride,
+                           (float)incre, num_levels, radius, li, out_split, ldexpf(1.0f, log2s_out), img_w, (int)ntiles);
+    else
+        hipLaunchKernelGGL(lookup_encode_kernel<LK_MAX_PRE>, dim3(grid), dim3(256), smem, (hipStream_t)stream, vol, origin, disp, w, b, out, P, D, row_stride,
+                           (float)incre, num_levels, radius, li, out_split, ldexpf(1.0f, log2s_out), img_w, (int)ntiles);
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }
