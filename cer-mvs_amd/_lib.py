@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CER_MVS_LIB") or os.path.join(_HERE, "csrc", "libcermvs.so")
-ABI_VERSION = 1041
+ABI_VERSION = 1050
 CONV_MAX_SRC = 4
 EPI_LINEAR, EPI_RELU, EPI_GATES, EPI_GRU, EPI_DELTA = 0, 1, 2, 3, 4
 EPI_OUT_SPLIT, EPI_AUX_SPLIT = 0x100, 0x200       # cer_mvs.h: split32 activation layout flags, or-ed into `epi`
@@ -48,9 +48,6 @@ _SIGNATURES = {
     "cer_alt_corr_bwd_reduce_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "cer_cost_build_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _D, _I, _I, _I, _I, _F, _P]),
     "cer_cost_build_algo": (_I, [_I]),
-    "cer_cost_lines_form": (_I, [_I]),
-    "cer_cost_lines_stats": (_I, [_P, _I]),
-    "cer_conv3x3_s16_pc": (_I, [_I]),
     "cer_overflow_flag": (_I, [_P]),
     "cer_f16_scan_overflow": (_I, [_P, _L, _P, _I, _P]),
     "cer_feat_split_f16": (_I, [_P, _P, _L, _L, _I, _P, _P]),
@@ -61,7 +58,7 @@ _SIGNATURES = {
     "cer_pyramid_f32": (_I, [_P, _L, _I, _I, _I, _F, _P]),
     "cer_corr_lookup_f32": (_I, [_P, _P, _P, _L, _P, _I, _L, _I, _I, _D, _I, _I, _P]),
     "cer_corr_encode_f32": (_I, [_P, _P, _P, _P, _I, _I, _L, _I, _P]),
-    "cer_lookup_encode_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _D, _I, _I, _I, _I, _I, _I, _P]),
+    "cer_lookup_encode_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _D, _I, _I, _I, _I, _I, _I, _P, _I, _F, _P]),
     "cer_conv3x3_packed_size": (_L, [_I, _I]),
     "cer_conv3x3_pack_f32": (_I, [_P, _P, _I, _I, _c.POINTER(_I), _c.POINTER(_I), _I]),
     "cer_conv3x3_f32": (_I, [_c.POINTER(ConvInputs), _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -110,6 +107,13 @@ _SIGNATURES = {
     "cer_multires_merge_f32": (_I, [_P, _I, _I, _P, _I, _I, _D, _P, _P]),
     "cer_resize_linear_f32": (_I, [_P, _I, _I, _P, _I, _I, _P]),
     "cer_geo_consistency_f32": (_I, [_P, _P, _P, _I, _I, _I, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+# include/cer_mvs_variants.h: exported by csrc/variants/libcermvs_optin.so only (round 4's opt-in kernel forms; CER_MVS_LIB selects the library)
+_VARIANT_SIGNATURES = {
+    "cer_cost_lines_form": (_I, [_I]),
+    "cer_cost_lines_stats": (_I, [_P, _I]),
+    "cer_conv3x3_s16_pc": (_I, [_I]),
 }
 
 _lib = None
@@ -234,10 +238,21 @@ def load():
             raise RuntimeError(f"cer-mvs_amd: {LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in _VARIANT_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     if lib.cer_abi_version() != ABI_VERSION:
         raise RuntimeError(f"cer-mvs_amd: ABI mismatch (library {lib.cer_abi_version()}, python {ABI_VERSION}); rebuild")
     _lib = lib
     return lib
+
+
+def has_variant_forms():
+    """True when the loaded library is the variant build that carries round 4's opt-in kernel forms (include/cer_mvs_variants.h)."""
+    lib = load()
+    return all(hasattr(lib, n) for n in _VARIANT_SIGNATURES)
 
 
 def check(rc, what):

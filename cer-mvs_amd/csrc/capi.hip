@@ -1,7 +1,7 @@
 // Library-level entry points of libcermvs.so (include/cer_mvs.h).
 #include "common.hpp"
 
-extern "C" int cer_abi_version(void) { return 1041; }
+extern "C" int cer_abi_version(void) { return 1050; }
 
 extern "C" const char* cer_error_string(int code) {
     switch (code) {

@@ -417,7 +417,13 @@ __global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : 2) void conv
         }
     }
     struct W8 { half8 h0, h1; union { intx8 v; uint4 q[2]; } q; };
-    W8 w8[2];                                              // F8: weights of the current and the next chunk step
+    // F8: weights of the current chunk step and of the next WR - 1.  The 64-output-channel kernels (2 x 2 waves, two m-tiles per wave) spend only
+    // 256 matrix-pipe cycles per wave on a chunk step - with two co-resident blocks ~500 cycles between a slice's request and its use, less
+    // than an L2 round trip: their chunk loop ran at 1.75 x its pipe floor (tools/trace_s16.py --conv q: 8.0 k cycles per chunk against
+    // 4.6 k; alone on a CU 388 per 16-channel step against 128).  They request two steps ahead (ring of three; 9 taps = 3 x 3: no slot swap):
+    // 6.7 k per chunk.
+    constexpr int WR = (F8 && WM_ == 2 && MT == 2 && SX_WRING3) ? 3 : 2;         // (three m-tiles per wave: 229 VGPRs already, and 384 pipe cycles per step)
+    W8 w8[WR];
     auto load_w8 = [&](W8& f, int cstep) {                 // (clamped: the steps past the tensors are never multiplied)
         const char* p = wlane8 + (long)min(cstep, (nsteps_t >> 1) - 1) * (2 * wstep);
         f.h0 = *reinterpret_cast<const half8*>(p);
@@ -428,6 +434,7 @@ __global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : 2) void conv
     // the steps of the disparity source follow the tensors' (same bytes per 16-channel step in both forms)
     if (F8 && ngroups_t > 0) {
         load_w8(w8[0], 0);
+        if constexpr (WR == 3) load_w8(w8[1], 1);
     } else {
         load_w(fw[0], 0);
         load_w(fw[1], 1);
@@ -579,17 +586,19 @@ __global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : 2) void conv
                 if (t == 8) barrier();
                 // weights one chunk step ahead (a chunk step lasts as long as two 16-channel steps); before the last chunk's last taps
                 // the first two slices of the disparity section instead
-                W8& wc = w8[t & 1];
-                W8& wn = w8[(t + 1) & 1];
-                if (t < 8 || !last) load_w8(wn, gi * 9 + t + 1);
+                W8& wc = w8[WR == 3 ? t % 3 : (t & 1)];
+                W8& wn = w8[WR == 3 ? (t + 2) % 3 : ((t + 1) & 1)];
+                if (WR == 3 ? (t < 7 || !last) : (t < 8 || !last)) load_w8(wn, gi * 9 + t + WR - 1);
                 if (t == 8 && last) { load_w(fw[0], nsteps_t); load_w(fw[1], nsteps_t + 1); }     // (the free weight slot's registers)
                 __builtin_amdgcn_sched_barrier(0);
                 if (t < 8) mma8_roll(wc, (xa[(t + 1) % 3] ^ vary) + bufC, ((t + 1) / 3) * SX_ROWB8);
                 else if (!last) mma8_roll(wc, (xa[0] ^ vary) + bufN, 0);
                 else mma8_last(wc, xh[1] + bufN, xl[1] + bufN, SX_ROWB);       // (collapsed disparity group or nothing: see the launcher)
             }
-            if (!last) {   // nine taps per chunk: the slot that holds the next step's weights becomes slot 0 again
-                const W8 tmp = w8[0]; w8[0] = w8[1]; w8[1] = tmp;
+            if constexpr (WR == 2) {
+                if (!last) {   // nine taps per chunk: the slot that holds the next step's weights becomes slot 0 again
+                    const W8 tmp = w8[0]; w8[0] = w8[1]; w8[1] = tmp;
+                }
             }
             SX_STAMP();
             ++gi;
@@ -1273,14 +1282,21 @@ extern "C" int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, con
         }
         return best_mt;
     };
+#ifdef SX_PROBE          // probe builds (tools/r05/mkprobe.sh): ONE kernel configuration - the 64-output-channel fp8-correction form - compiled in seconds
+    return sx_launch<2, 2, 2, 1>(a, epi, st);
+#else
     // the fp8-correction kernels evaluate a disparity source in the collapsed form with the rim correction only
     if (corr_fp8 && nd == 1 && !(packed_collapsed && edge_w)) return CER_ESHAPE;
-    // round 4: the GRU loop's fp8-correction convolutions run with producer / consumer wave roles (conv_s16pc.hip) unless a tile
-    // height is forced (tests and experiments that address the kernels of this file)
+#if CER_WITH_SXPC
+    // variants/libcermvs_optin.so only (round 4's producer / consumer form, experimental/conv_s16pc.hip: measured slower): taken
+    // when its switch cer_conv3x3_s16_pc is on and no tile height is forced.  It gets a COPY of the arguments (it edits the tiling fields
+    // before it can refuse a shape).
     if (corr_fp8 && tile_mt == 0) {
-        const int rc = sxpc_dispatch(a, epi, tile_mt, st);
+        S16Args b = a;
+        const int rc = sxpc_dispatch(b, epi, tile_mt, st);
         if (rc != CER_ESHAPE) return rc;
     }
+#endif
     if (Cout % 128 == 0) {
         int mt = tile_mt;
         if (mt != 2 && mt != 4) mt = pick(2, 2, 4, Cout / 128) == 2 ? 2 : 4;
@@ -1296,6 +1312,7 @@ extern "C" int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, con
     }
     if (mt < 2 || mt > 4) mt = pick(4, 2, 4, Cout / 64);
     return mt == 2 ? sx_launch<2, 2, 2, 0>(a, epi, st) : mt == 3 ? sx_launch<2, 2, 3, 0>(a, epi, st) : sx_launch<2, 2, 4, 0>(a, epi, st);
+#endif
 }
 
 // ---- layout conversion (model load / API boundaries / tests): plain fp32 [h*w, C] <-> the m-tile-major layouts of the s16 convs.

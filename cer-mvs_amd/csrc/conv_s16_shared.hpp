@@ -1,5 +1,5 @@
 // Shared pieces of the update block's s16 convolutions: csrc/conv_s16.hip (round 2/3: every wave runs every phase of a tile) and
-// csrc/conv_s16pc.hip (round 4: producer / consumer wave roles).  See conv_s16.hip for the arithmetic and the layouts.
+// csrc/experimental/conv_s16pc.hip (round 4: producer / consumer wave roles; variant library only).  See conv_s16.hip for the arithmetic and the layouts.
 #pragma once
 #include "common.hpp"
 #include <math.h>
@@ -33,6 +33,9 @@ typedef int intx8 __attribute__((ext_vector_type(8)));
 #ifndef SX_OCC3
 #define SX_OCC3 0    // 1: the 64-channel fp8-correction kernels aim at three blocks per CU (167 VGPRs, 8 spilled; fits with 8-row tiles, tile_mt 2:
                      // 52.7 KB of LDS per block).  Measured at 296 x 400: q 70.3 us against 65.2 (default, 12-row tiles, two blocks), corr2 32.1 / 32.3 - off
+#endif
+#ifndef SX_WRING3
+#define SX_WRING3 1  // the 64-output-channel fp8-correction kernels request their weight slices two chunk steps ahead (ring of three register slots)
 #endif
 #ifndef SX_TRACE
 #define SX_TRACE 0   // variant builds only (tools/trace_s16.py): per wave cycle stamps + HW_ID written to `aux2` (GATES: unused there)
@@ -86,6 +89,9 @@ __device__ __forceinline__ float sx_sigmoid(float x) { return __builtin_amdgcn_r
 __device__ __forceinline__ float sx_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
 
 
-// round 4 (conv_s16pc.hip): the producer / consumer form of the fp8-correction convolutions of the GRU loop.  Returns CER_ESHAPE when
-// the launch is not one it serves (the caller then takes the kernels of conv_s16.hip).
+#ifndef CER_WITH_SXPC
+#define CER_WITH_SXPC 0
+#endif
+// round 4 (experimental/conv_s16pc.hip, variants/libcermvs_optin.so only): the producer / consumer form of the fp8-correction convolutions of
+// the GRU loop.  Returns CER_ESHAPE when the launch is not one it serves (the caller then takes the kernels of conv_s16.hip).
 int sxpc_dispatch(S16Args& a, int epi, int tile_mt, hipStream_t st);

@@ -33,6 +33,7 @@
 // that of cost_build.hip, so cells and weights are bit-identical to the walk; only the 64-channel dot differs in rounding
 // (4e-8 relative L1 on the bench scene).  Measured, what shaped it and what is left: DESIGN.md section 3e.
 #include "common.hpp"
+#include <atomic>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -497,522 +498,12 @@ __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
     cl_tile(A, v, seg, jj);
 }
 
-// The lines cost_lines8_kernel left over (bands too wide for its window), one at a time in the one-line form
-__global__ __launch_bounds__(256, 3) void cost_lines_todo_kernel(const ClArgs A) {
-    const unsigned n = (unsigned)A.todo[0];
-    for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
-        const unsigned long long e = A.todo[1 + i];
-        __syncthreads();                                    // (the previous tile's LDS is dead)
-        cl_tile(A, (int)(e >> 40), (int)((e >> 20) & 0xFFFFFu), (int)(e & 0xFFFFFu));
-    }
-}
-
-// =====================================================================================================================
-// Round 4: EIGHT lines per block (cost_lines8_kernel).  The one-line form above is bound by the CU's vector-memory path: every
-// band texel is fetched once per (view, LINE) - 256 B per texel, 8.4 GB per stage-0 launch through the L1 at ~12 B/cycle/CU -
-// although neighbouring lines of a segment share all but one row of their bands.  Here a 512-thread block takes the 8 neighbouring
-// lines of a segment (wave w = line w):
-//   * ONE band for the block (the analysis of the one-line form over all 8 x 32 segments: three cross-wave min / max rounds
-//     through LDS): R' = R + 7 rows instead of 8 x R - 2.7 x fewer texel bytes per line; each line keeps its own row window
-//     (s_w, R_w) inside it;
-//   * the band is walked in windows of Wt columns (<= 96 texels, Wt x R_w <= 32): all 512 threads fetch window n + 1 as 16-byte
-//     pieces into registers while window n is multiplied, then write it to one of two LDS halves (272-B texel pitch:
-//     conflict-free fragment reads) - ONE s_barrier per window;
-//   * wave w reads the 32 texels of ITS rows from LDS as MFMA A fragments (the 32 reference pixels of its line stay in
-//     registers as B fragments for the whole tile), 12 MFMAs -> its private 4 KiB of dots -> gathers its own line's samples:
-//     no block barrier between the product and the gather, no shared cursor state;
-//   * a lane projects its next sample when it has consumed one (no descriptor table: 8 lines x 2048 samples x 12 B do not fit);
-//     the operations are those of the one-line form, expression for expression, so cells and weights are bit-identical and the
-//     dots come out of the same 12 MFMAs in the same order;
-//   * values collect in LDS ([line][hypothesis][pixel]) and leave as one 256-B row per pixel.
-// Blocks whose lines' bands do not fit the window (R_w > 16 or R' > 48) hand their lines to cost_lines_todo_kernel.
-// Happens-before: abuf[h] is written (commit) only after the barrier that ended the window which last read it; prod / val / pidx
-// regions are wave-private (LDS operations of one wave execute in order); red[] slots of the three analysis rounds are disjoint.
-#ifndef C8_STATS
-#define C8_STATS 0
+#ifndef CER_WITH_LINES8
+#define CER_WITH_LINES8 0
 #endif
-#ifndef C8_ABL
-#define C8_ABL 0
+#if CER_WITH_LINES8
+#include "experimental/cost_lines8.inc"
 #endif
-__device__ unsigned long long c8_stats[32];             // variant build -DC8_STATS=1 (make variants/libcermvs_c8stats.so; tools/stats_cost_lines.py)
-#if C8_STATS
-#define C8_STAT(i, x) atomicAdd(&c8_stats[i], (unsigned long long)(x))
-#define C8_CLK() __builtin_readcyclecounter()
-#else
-#define C8_STAT(i, x) do { } while (0)
-#define C8_CLK() 0ull
-#endif
-#define C8_PITCH 272
-#define C8_VP 33
-template <int NW, bool OUTD> struct C8Cfg {
-    static constexpr int CAP = 12 * NW;                     // texels of a window (3 sixteen-byte pieces per thread)
-    static constexpr int ABUF = CAP * C8_PITCH;
-    static constexpr int VAL = OUTD ? 0 : NW * 64 * C8_VP;  // floats of the value tile (OUTD: values go straight to the partial volume)
-    static constexpr int SMEM = 2 * ABUF + NW * 1024 * 4 + VAL * 4 + NW * 32 * 4 + NW * 16 * 4;
-};
-
-// NW = lines (= waves) per block: 8 (one block per CU: 154 KB of LDS) or 4 (two blocks per CU: 77 KB each)
-template <int NW, bool OUTD>
-__global__ __launch_bounds__(64 * NW, OUTD ? 3 : 2) void cost_lines8_kernel(const ClArgs A) {
-    constexpr int C8_CAP = C8Cfg<NW, OUTD>::CAP, C8_ABUF = C8Cfg<NW, OUTD>::ABUF;
-    extern __shared__ __attribute__((aligned(16))) char smem8[];
-    char* const abuf = smem8;
-    float* const prodAll = reinterpret_cast<float*>(smem8 + 2 * C8_ABUF);
-    float* const valAll = prodAll + NW * 1024;
-    int* const pidxAll = reinterpret_cast<int*>(valAll + C8Cfg<NW, OUTD>::VAL);
-    float* const red = reinterpret_cast<float*>(pidxAll + NW * 32);      // [NW waves][16]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, kg = lane >> 5;
-    const unsigned o = cl_xcd_order();
-    const int v = A.v0 + (int)(o / (unsigned)A.tpv8), rem = (int)(o % (unsigned)A.tpv8);
-    constexpr int BPG = 16 / NW;                            // blocks per 16-line group
-    const int h1 = A.h1, w1 = A.w1, h2 = A.h2, w2 = A.w2, D = A.D;
-    const int axis = (int)A.params[v * 4 + 0];
-    const float shear = A.params[v * 4 + 1];
-    const int La = axis ? h1 : w1, Hm = axis ? w1 : h1;
-    const int njm = Hm + 32, nseg = (La + 31) >> 5;
-    // order inside a view: 16 lines (two blocks) x all segments, like the one-line form's CL_LG groups
-    const int lg = (int)((unsigned)rem / (unsigned)(nseg * BPG)), rem2 = rem - lg * nseg * BPG;
-    const int seg = rem2 / BPG, jj0 = lg * 16 + (rem2 % BPG) * NW;
-    if (jj0 >= njm) return;
-    const float cm = 0.5f * (float)La;
-    const int a_first = seg * 32, a_last = min(seg * 32 + 31, La - 1);
-    const int sh_f = (int)rintf(shear * ((float)a_first - cm)), sh_l = (int)rintf(shear * ((float)a_last - cm));
-    const int sh_lo = min(sh_f, sh_l), sh_hi = max(sh_f, sh_l);
-    const int a_me = seg * 32 + li;
-    const int sh_me = (int)rintf(shear * ((float)a_me - cm));
-    {                                                       // any valid pixel in the 8 lines?  (block-uniform: every wave tests the same 32 slots)
-        bool any = false;
-        for (int l = 0; l < NW; ++l) {
-            const int jl = jj0 + l - sh_hi, bl_ = jl + sh_me;
-            any |= (jj0 + l < njm) && (jl <= Hm - 1 - sh_lo) && a_me < La && bl_ >= 0 && bl_ < Hm;
-        }
-        if (__ballot(any) == 0ull) return;
-    }
-    const unsigned long long c8_t0 = C8_CLK();
-    (void)c8_t0;
-    const int jj = jj0 + wave, j = jj - sh_hi;
-    const bool line_in = jj < njm && j <= Hm - 1 - sh_lo;
-    const int b_me = j + sh_me;
-    const bool valid = line_in && a_me < La && b_me >= 0 && b_me < Hm;
-    const bool active = __ballot(valid) != 0ull;            // (wave-uniform) this wave's line has pixels
-    const int x_me = axis ? b_me : a_me, y_me = axis ? a_me : b_me;
-    const long p_me = (long)min(max(y_me, 0), h1 - 1) * w1 + min(max(x_me, 0), w1 - 1);
-    int* const pidx = pidxAll + wave * 32;
-    float* const prod = prodAll + wave * 1024;
-    float* const val = valAll + (OUTD ? 0 : wave * 64 * C8_VP);
-    float* const pout = A.part + ((long)v * ((long)h1 * w1) + p_me) * D;      // (OUTD) this lane's pixel row of the partial volume
-    if (lane < 32) pidx[lane] = valid ? (int)p_me : -1;
-
-    const long ps1 = (long)h1 * w1 * 16, ps2 = (long)(h2 + 4) * (w2 + 4) * 16;
-    const _Float16* f1t = A.f1s + p_me * 16;
-    half8 bh[4], bl[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        bh[ks] = *reinterpret_cast<const half8*>(f1t + ks * ps1 + 8 * kg);
-        bl[ks] = *reinterpret_cast<const half8*>(f1t + (4 + ks) * ps1 + 8 * kg);
-    }
-
-    const float* m = A.Pij + v * 16;
-    const float px = (float)x_me, py = (float)(y_me + A.y0);
-    float origin = A.disp_in[p_me];
-    if (A.shift && origin < A.lim) origin = A.lim;
-    const float a0 = fmaf(m[1], py, m[0] * px) + m[2], a1 = fmaf(m[5], py, m[4] * px) + m[6], a2 = fmaf(m[9], py, m[8] * px) + m[10];
-    const float m3 = m[3], m7 = m[7], m11 = m[11];
-    const int half = D / 2;
-    const float incre = A.incre;
-    auto project = [&](int k, float& u, float& w) -> bool {      // same fp32 expressions as cost_build.hip / the reference
-        const float hyp = __fadd_rn(__fmul_rn((float)(k - half), incre), origin);
-        const float X = fmaf(m3, hyp, a0), Y = fmaf(m7, hyp, a1), Z = fmaf(m11, hyp, a2);
-        u = X / Z;
-        w = Y / Z;
-        const bool ok = (u == u) && (w == w);
-        u = fminf(fmaxf(u, -1e4f), 1e4f);
-        w = fminf(fmaxf(w, -1e4f), 1e4f);
-        return ok;
-    };
-
-    // ---- band analysis over the 8 lines: the one-line form's, with every wave-wide min / max followed by a round over the waves
-    const float INF = 3e38f;
-    float* const myred = red + wave * 16;
-    float ua, wa, ub, wb;
-    bool part0;
-    {
-        float ue, we;
-        const bool oke = project(kg ? D - 1 : 0, ue, we);
-        const float uo = __shfl_xor(ue, 32), wo = __shfl_xor(we, 32);
-        const bool oko = ((__ballot(oke) >> (lane ^ 32)) & 1ull) != 0ull;
-        ua = kg ? uo : ue; wa = kg ? wo : we;
-        ub = kg ? ue : uo; wb = kg ? we : wo;
-        part0 = valid && oke && oko;
-    }
-    {
-        const float mnu = cl_wmin(part0 ? fminf(ua, ub) : INF), mxu = cl_wmax(part0 ? fmaxf(ua, ub) : -INF);
-        const float mnw = cl_wmin(part0 ? fminf(wa, wb) : INF), mxw = cl_wmax(part0 ? fmaxf(wa, wb) : -INF);
-        if (lane == 0) { myred[0] = mnu; myred[1] = mxu; myred[2] = mnw; myred[3] = mxw; }
-    }
-    __syncthreads();
-    int smaj = 0;
-    bool any0 = false;
-    {
-        float mnu = INF, mxu = -INF, mnw = INF, mxw = -INF;
-        for (int q = 0; q < NW; ++q) {
-            mnu = fminf(mnu, red[q * 16 + 0]); mxu = fmaxf(mxu, red[q * 16 + 1]);
-            mnw = fminf(mnw, red[q * 16 + 2]); mxw = fmaxf(mxw, red[q * 16 + 3]);
-        }
-        any0 = mnu < 1e38f;
-        if (any0) smaj = (mxw - mnw) > (mxu - mnu) ? 1 : 0;
-    }
-    smaj = __builtin_amdgcn_readfirstlane(smaj);
-    const int Wmaj = smaj ? h2 : w2, Wmin = smaj ? w2 : h2;
-    // clip every segment to the columns of the (padded) map
-    float ma1 = 0.f, na1 = 0.f, mb1 = 0.f, nb1 = 0.f;
-    bool part1 = false;
-    if (any0) {
-        const float ma = smaj ? wa : ua, na = smaj ? ua : wa, mb = smaj ? wb : ub, nb = smaj ? ub : wb;
-        const float lo = -2.0f, hi = (float)Wmaj + 1.0f;
-        const float dm = mb - ma, dn = nb - na;
-        float t0 = 0.f, t1 = 1.f;
-        bool inside;
-        if (fabsf(dm) < 1e-6f) {
-            inside = ma >= lo && ma <= hi;
-        } else {
-            const float ta = (lo - ma) / dm, tb = (hi - ma) / dm;
-            t0 = fmaxf(0.f, fminf(ta, tb));
-            t1 = fminf(1.f, fmaxf(ta, tb));
-            inside = t0 <= t1;
-        }
-        part1 = part0 && inside;
-        ma1 = fmaf(t0, dm, ma); na1 = fmaf(t0, dn, na); mb1 = fmaf(t1, dm, ma); nb1 = fmaf(t1, dn, na);
-    }
-    {
-        const bool aFirst = ma1 <= mb1;
-        const float lmin = part1 ? (aFirst ? ma1 : mb1) : INF, lminN = aFirst ? na1 : nb1;
-        const float lmax = part1 ? (aFirst ? mb1 : ma1) : -INF, lmaxN = aFirst ? nb1 : na1;
-        const float gmin_w = cl_wmin(lmin), gmax_w = cl_wmax(lmax);
-        const unsigned long long pm1 = __ballot(part1);
-        float q0n = 0.f, q1n = 0.f;
-        if (pm1) {
-            const int l0 = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(part1 && lmin == gmin_w)) - 1);
-            const int l1 = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(part1 && lmax == gmax_w)) - 1);
-            q0n = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lminN), l0));
-            q1n = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lmaxN), l1));
-        }
-        const int fwc = __popcll(__ballot(part1 && mb1 > ma1)), bwc = __popcll(__ballot(part1 && mb1 < ma1));
-        // this line's own slope (the one-line form's); the block takes the slope of its longest line: the lines are near-parallel,
-        // whereas a slope through the extreme points of two DIFFERENT lines would tilt the band by their distance
-        float bm_w = (pm1 && gmax_w - gmin_w > 1e-3f) ? (q1n - q0n) / (gmax_w - gmin_w) : 0.f;
-        bm_w = fminf(fmaxf(bm_w, -4.f), 4.f);
-        if (lane == 0) {
-            myred[4] = gmin_w; myred[5] = gmax_w; myred[6] = q0n; myred[7] = q1n;
-            myred[8] = (float)fwc; myred[9] = (float)bwc; myred[12] = bm_w;
-        }
-    }
-    __syncthreads();
-    float gmin = INF, gmax = -INF, q0n = 0.f, bm = 0.f;
-    int dir = 1;
-    bool any1 = false;
-    {
-        float fws = 0.f, bws = 0.f, ext = -1.f;
-        for (int q = 0; q < NW; ++q) {                       // (the first wave that attains the extreme provides its across-coordinate)
-            const float g0 = red[q * 16 + 4], g1 = red[q * 16 + 5];
-            if (g0 < gmin) { gmin = g0; q0n = red[q * 16 + 6]; }
-            gmax = fmaxf(gmax, g1);
-            if (g0 < 1e38f && g1 - g0 > ext) { ext = g1 - g0; bm = red[q * 16 + 12]; }
-            fws += red[q * 16 + 8]; bws += red[q * 16 + 9];
-        }
-        any1 = gmin < 1e38f;
-        dir = fws >= bws ? 1 : -1;
-        if (!any1) bm = 0.f;
-    }
-    const float am = fabsf(bm);
-    {
-        const float oa = na1 - fmaf(bm, ma1 - gmin, q0n), ob = nb1 - fmaf(bm, mb1 - gmin, q0n);
-        const float omin_w = cl_wmin(part1 ? fminf(oa, ob) : INF), omax_w = cl_wmax(part1 ? fmaxf(oa, ob) : -INF);
-        if (lane == 0) { myred[10] = omin_w; myred[11] = omax_w; }
-    }
-    __syncthreads();
-    int Rp = 1, Rl = 1, s_w = 0, R_w = 2, nsub = 0, Wt = 2, cmin = 0, cmax = 0;
-    float bl0 = 0.f;
-    if (any1) {
-        float omin = INF;
-        for (int q = 0; q < NW; ++q) omin = fminf(omin, red[q * 16 + 10]);
-        for (int q = 0; q < NW; ++q) {
-            const float o0 = red[q * 16 + 10], o1 = red[q * 16 + 11];
-            if (o0 < 1e38f) {
-                const float dq = o0 - omin, sq = floorf(dq);
-                const int Rq = (int)floorf((o1 - o0) + (dq - sq) + 2.f * am + 0.02f) + 3;
-                Rp = max(Rp, (int)sq + Rq);
-                Rl = max(Rl, Rq);
-                if (q == wave) { s_w = (int)sq; R_w = Rq; }
-            }
-        }
-        cmin = min(max((int)floorf(gmin), -2), Wmaj + 1);
-        cmax = min(max((int)floorf(gmax) + 1, -2), Wmaj + 1);
-        bl0 = q0n - bm * gmin + omin - am - 0.01f;
-        if (Rl > 16 || Rp > C8_CAP / 2 || !(Rp >= 1)) {      // bands too wide for the window: the lines go to the one-line form
-            if (active && lane == 0) {
-                C8_STAT(12, 1);
-                const unsigned i = (unsigned)atomicAdd(A.todo, 1ull);
-                A.todo[1 + i] = ((unsigned long long)v << 40) | ((unsigned long long)seg << 20) | (unsigned long long)jj;
-            }
-            return;                                         // (block-uniform: Rl, Rp come from the shared reduction)
-        }
-        Wt = min(32 / Rl, C8_CAP / Rp);
-        if (cmax > cmin) nsub = (cmax - cmin + Wt - 2) / (Wt - 1);
-    }
-    smaj = __builtin_amdgcn_readfirstlane(smaj);
-    Rp = __builtin_amdgcn_readfirstlane(Rp);
-    s_w = __builtin_amdgcn_readfirstlane(s_w);
-    R_w = __builtin_amdgcn_readfirstlane(R_w);
-    nsub = __builtin_amdgcn_readfirstlane(nsub);
-    Wt = __builtin_amdgcn_readfirstlane(Wt);
-    cmin = __builtin_amdgcn_readfirstlane(cmin);
-    cmax = __builtin_amdgcn_readfirstlane(cmax);
-    dir = __builtin_amdgcn_readfirstlane(dir);
-    bm = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bm)));
-    bl0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bl0)));
-    const int wp = w2 + 4;
-    const int smajS = smaj ? wp : 1, sminS = smaj ? 1 : wp;
-    const _Float16* f2v = A.f2s + (long)(A.slot ? A.slot[v] : v) * 8 * ps2;
-    const int cstep = dir * (Wt - 1), cb0 = dir > 0 ? cmin : cmax - (Wt - 1);
-
-    // ---- this thread's pieces of a window: piece id -> (plane, band row, window column, half of the 32-B texel row); the pieces that
-    // are neighbours in memory go to neighbouring lanes (columns are contiguous for a band along x, rows for one along y)
-    const int npiece = Wt * Rp * 16;
-    int pc_colo[3], pc_row[3], pc_lds[3];
-    bool pc_on[3];
-    long pc_off[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const int id = tid + 64 * NW * q;
-        const int kgp = id & 1;
-        int x = id >> 1, colo, row;
-        if (smaj == 0) { colo = x % Wt; x /= Wt; row = x % Rp; x /= Rp; }
-        else { row = x % Rp; x /= Rp; colo = x % Wt; x /= Wt; }
-        const int plane = min(x, 7);
-        pc_on[q] = id < npiece;
-        pc_colo[q] = pc_on[q] ? colo : 0;                   // (idle pieces fetch the window's first texel and write nothing)
-        pc_row[q] = pc_on[q] ? row : 0;
-        pc_lds[q] = (colo * Rp + row) * C8_PITCH + (plane * 2 + kgp) * 16;
-        pc_off[q] = (long)plane * ps2 + kgp * 8;
-    }
-    uint4 stg0, stg1, stg2;
-    auto fetch = [&](int cbn, int q) -> uint4 {
-        const int col = cbn + pc_colo[q];
-        const int row = (int)floorf(fmaf(bm, (float)col, bl0)) + pc_row[q];
-        const int cc = min(max(col, -2), Wmaj + 1), rc = min(max(row, -2), Wmin + 1);
-        return *reinterpret_cast<const uint4*>(f2v + (long)((cc + 2) * smajS + (rc + 2) * sminS) * 16 + pc_off[q]);
-    };
-    auto issue = [&](int n) {                               // window n -> registers
-#if C8_ABL & 1
-        const int cbn = cb0 + (n & 1) * cstep;              // (ablation: the same two windows again and again - L1 hits)
-#else
-        const int cbn = cb0 + n * cstep;
-#endif
-        stg0 = fetch(cbn, 0);
-        stg1 = fetch(cbn, 1);
-        stg2 = fetch(cbn, 2);
-    };
-    auto commit = [&](int h) {
-        char* hb = abuf + h * C8_ABUF;
-        if (pc_on[0]) *reinterpret_cast<uint4*>(hb + pc_lds[0]) = stg0;
-        if (pc_on[1]) *reinterpret_cast<uint4*>(hb + pc_lds[1]) = stg1;
-        if (pc_on[2]) *reinterpret_cast<uint4*>(hb + pc_lds[2]) = stg2;
-    };
-    if (nsub > 0) issue(0);
-
-    // ---- this lane's samples: hypotheses kg, kg + 2, ... of pixel slot li, projected one at a time as the cursor advances
-    int k = (valid && active) ? kg : D;
-    unsigned pk = 3u << 30;
-    float fm = 0.f, fn = 0.f;
-    auto load_sample = [&]() {
-        if (k >= D) { pk = 3u << 30; return; }
-        float u, w;
-        const bool ok = project(k, u, w);
-        const float fu = floorf(u), fw = floorf(w);
-        const float du = ok ? u - fu : 0.f, dw = ok ? w - fw : 0.f;
-        const int iu = ok ? min(max((int)fu, -2), w2) : -2, iw = ok ? min(max((int)fw, -2), h2) : -2;
-        const int sc = smaj ? iw : iu, sr = smaj ? iu : iw;
-        const bool zero = iu < -1 || iu > w2 - 1 || iw < -1 || iw > h2 - 1;
-        const int b0 = (int)floorf(fmaf(bm, (float)sc, bl0)), b1 = (int)floorf(fmaf(bm, (float)(sc + 1), bl0));
-        const int r0 = sr - b0 - s_w, r1 = sr - b1 - s_w;
-        const bool fits = nsub > 0 && sc >= cmin && sc < cmax && r0 >= 0 && r0 + 1 < R_w && r1 >= 0 && r1 + 1 < R_w;
-        const int hi14 = fits ? (r0 + r1 * 32) : (sr + 4);
-        const int kind2 = zero ? 1 : (fits ? 0 : 2);
-        pk = (unsigned)(sc + 4) + ((unsigned)(hi14 & 0x3FFF) << 16) + ((unsigned)kind2 << 30);
-        fm = smaj ? dw : du;
-        fn = smaj ? du : dw;
-    };
-    load_sample();
-    auto direct_value = [&]() -> float {
-        const int sc = (int)(pk & 0xFFFFu) - 4, sr = (int)((pk >> 16) & 0x3FFFu) - 4;
-        const _Float16* t00 = f2v + (long)((sc + 2) * smajS + (sr + 2) * sminS) * 16;
-        return cl_direct(f1t, ps1, t00, ps2, smajS, sminS, 1.0f - fm, fm, 1.0f - fn, fn);
-    };
-    // this lane's texel of the wave's 32-texel tile (Wt columns x R_w rows of the line's own window)
-    const int colo_t = li / R_w, rowo_t = li - colo_t * R_w;
-    const int a_lds = (li < Wt * R_w ? (colo_t * Rp + s_w + rowo_t) * C8_PITCH : 0) + kg * 16;
-
-    // every load so far (the reference fragments among them) has landed: said explicitly and on every path, or hipcc's wait-count pass
-    // carries "bh / bl may be pending" into the loop and puts vmcnt(0) in front of each window's MFMAs - the wait for window n + 1's pieces
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    if (nsub > 0) {
-        commit(0);
-        if (nsub > 1) issue(1);
-    }
-    __syncthreads();
-    const unsigned long long c8_t1 = C8_CLK();
-    unsigned long long c8_comp = 0, c8_gath = 0, c8_wait = 0, c8_cmt = 0;
-    (void)c8_cmt;
-    unsigned c8_iters = 0, c8_direct = 0;
-    (void)c8_t1; (void)c8_comp; (void)c8_gath; (void)c8_wait; (void)c8_iters; (void)c8_direct;
-    if (lane == 0) {
-        if (wave == 0) { C8_STAT(0, 1); C8_STAT(2, nsub); C8_STAT(3, Wt); C8_STAT(4, Rp); }
-        if (active) { C8_STAT(1, 1); C8_STAT(5, R_w); }
-    }
-    for (int n = 0; n < nsub; ++n) {
-        const int cb = cb0 + n * cstep;
-        const unsigned long long c8_ta = C8_CLK();
-        unsigned long long c8_tb = c8_ta;
-        if (active) {
-            const char* ab = abuf + (n & 1) * C8_ABUF + a_lds;
-            half8 ahf[4], alf[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                ahf[ks] = *reinterpret_cast<const half8*>(ab + ks * 32);
-                alf[ks] = *reinterpret_cast<const half8*>(ab + (4 + ks) * 32);
-            }
-            floatx16 acc0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahf[ks], bh[ks], acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahf[ks], bl[ks], acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alf[ks], bh[ks], acc0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
-                prod[row * 32 + li] = acc0[r];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            c8_tb = C8_CLK();
-            const int cbe = cb + Wt - 2;                    // last cell column of the window
-            for (;;) {
-#if C8_STATS
-                ++c8_iters;
-#endif
-                const unsigned kind = pk >> 30;
-                const int scp = (int)(pk & 0xFFFFu);        // cell column + 4
-                const bool in = kind == 0 && scp >= cb + 4 && scp <= cbe + 4;
-                const bool behind = kind == 0 && (dir > 0 ? scp < cb + 4 : scp > cbe + 4);
-                const bool consume = in || behind || kind == 1 || kind == 2;
-                if (__ballot(consume) == 0ull) break;
-                float vv = 0.f;
-                if (in) {
-                    const int r0 = (int)((pk >> 16) & 31u), r1 = (int)((pk >> 21) & 31u);
-                    const int t0 = (scp - 4 - cb) * R_w + r0, t1 = (scp - 3 - cb) * R_w + r1;
-                    const float* d0 = prod + t0 * 32 + li;
-                    const float* d1 = prod + t1 * 32 + li;
-                    const float wm1 = fm, wm0 = 1.0f - fm, wn1 = fn, wn0 = 1.0f - fn;
-                    vv = d0[0] * (wn0 * wm0) + d1[0] * (wn0 * wm1) + d0[32] * (wn1 * wm0) + d1[32] * (wn1 * wm1);
-                }
-                if (__ballot(behind || kind == 2) != 0ull) {
-                    if (behind || kind == 2) {
-                        if (kind == 0) {
-                            const int sc = scp - 4;
-                            const int sr = (int)floorf(fmaf(bm, (float)sc, bl0)) + s_w + (int)((pk >> 16) & 31u);
-                            pk = (pk & 0xFFFFu) | ((unsigned)(sr + 4) << 16) | (2u << 30);
-                        }
-                        vv = direct_value();
-#if C8_STATS
-                        ++c8_direct;
-#endif
-                    }
-                }
-                if (consume) {
-                    if (OUTD) pout[k] = vv; else val[k * C8_VP + li] = vv;
-                    k += 2;
-                    load_sample();
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        const unsigned long long c8_tc = C8_CLK();
-        if (n + 1 < nsub) {
-            commit((n + 1) & 1);                            // window n + 1 has arrived; its half was last read in window n - 1
-            if (n + 2 < nsub) issue(n + 2);
-        }
-#if C8_STATS
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        const unsigned long long c8_td = C8_CLK();
-        c8_cmt += c8_td - c8_tc;
-#endif
-        __syncthreads();
-        c8_comp += c8_tb - c8_ta; c8_gath += c8_tc - c8_tb; c8_wait += C8_CLK() - c8_tc;
-    }
-    const unsigned long long c8_t2 = C8_CLK();
-    (void)c8_t2;
-    // ---- what the windows did not cover (no band, samples out of order): direct path
-    while (__ballot((pk >> 30) != 3u) != 0ull) {
-        if ((pk >> 30) != 3u) {
-            float vv = 0.f;
-            if ((pk >> 30) != 1u) {
-                if ((pk >> 30) == 0u) {
-                    const int sc = (int)(pk & 0xFFFFu) - 4;
-                    const int sr = (int)floorf(fmaf(bm, (float)sc, bl0)) + s_w + (int)((pk >> 16) & 31u);
-                    pk = (pk & 0xFFFFu) | ((unsigned)(sr + 4) << 16) | (2u << 30);
-                }
-                vv = direct_value();
-            }
-            if (OUTD) pout[k] = vv; else val[k * C8_VP + li] = vv;
-            k += 2;
-            load_sample();
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- rows out: lane = hypothesis (one coalesced D-float row per pixel)
-    const unsigned long long c8_t3 = C8_CLK();
-    (void)c8_t3;
-    if (active && !OUTD) {
-        float* pv = A.part + (long)v * ((long)h1 * w1) * D;
-        for (int i = 0; i < 32; ++i) {
-            const int p = pidx[i];
-            if (p >= 0 && lane < D) pv[(long)p * D + lane] = val[lane * C8_VP + i];
-        }
-    }
-#if C8_STATS
-    {
-        unsigned dsum = c8_direct;
-        for (int off = 32; off; off >>= 1) dsum += __shfl_xor(dsum, off);
-        if (lane == 0 && active) {
-            C8_STAT(6, c8_iters); C8_STAT(7, dsum); C8_STAT(16, c8_cmt); C8_STAT(10, c8_comp); C8_STAT(13, c8_gath); C8_STAT(11, c8_wait);
-            C8_STAT(9, c8_t1 - c8_t0); C8_STAT(14, c8_t3 - c8_t2); C8_STAT(15, C8_CLK() - c8_t3); C8_STAT(8, C8_CLK() - c8_t0);
-        }
-    }
-#endif
-}
-
-// statistics of the -DC8_STATS build (zeros otherwise): copies the 32 counters to host memory, optionally clearing them
-extern "C" int cer_cost_lines_stats(unsigned long long* out, int reset) {
-    if (!out) return CER_EINVAL;
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(c8_stats), sizeof(unsigned long long) * 32);
-    if (e != hipSuccess) return (int)e;
-    if (reset) {
-        unsigned long long z[32] = {};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(c8_stats), z, sizeof(z));
-        if (e != hipSuccess) return (int)e;
-    }
-    return CER_OK;
-}
 
 // ---- sum of the per-view partials (view order: deterministic) * scale, origin, pooled levels: wave per pixel, lane = hypothesis
 __global__ __launch_bounds__(256) void cost_lines_reduce_kernel(const float* __restrict__ part, const float* __restrict__ disp_in,
@@ -1031,7 +522,7 @@ __global__ __launch_bounds__(256) void cost_lines_reduce_kernel(const float* __r
         for (int v = 0; v < V; ++v) s += part[((long)v * P + p) * D + lane];
     float* orow = vol + p * rs;
     float cur = s * scale;
-    if (levels > 1) {
+    if (levels >= 1) {
         if (lane < D) orow[lane] = cur;
         int off = 0, n = D;
         for (int l = 1; l < levels; ++l) {                  // core/corr.py:94-97: (a + b) * 0.5 level by level; element j of level l on lane j << l
@@ -1058,19 +549,22 @@ extern "C" long cer_cost_lines_workspace(int V, int h1, int w1, int D) {
     return (long)V * h1 * w1 * D * 4 + (long)V * 16 + 256 + (long)V * (cl_tiles_per_view(h1, w1) + 1) * 8 + 64;
 }
 
+#if CER_WITH_LINES8
 // Which kernel builds the per-view partial volumes: 0 (default) the one-line form of round 3 (cost_lines_kernel), 1 the multi-line
-// form of round 4 (cost_lines8_kernel: measured slower - DESIGN.md 3k - and kept as an experiment).  Process-wide like
+// form of round 4 (cost_lines8_kernel: measured slower - DESIGN.md 3k - a variant-library experiment).  Process-wide like
 // cer_cost_build_algo; < 0 queries.  CER_COST_LINES_FORM in the environment sets the initial value.
-static int g_lines_form = -1;
+static std::atomic<int> g_lines_form{-1};
 extern "C" int cer_cost_lines_form(int form) {
-    if (g_lines_form < 0) {
+    int cur = g_lines_form.load();
+    if (cur < 0) {
         const char* e = getenv("CER_COST_LINES_FORM");
-        g_lines_form = (e && e[0] == '1') ? 1 : 0;
+        g_lines_form.compare_exchange_strong(cur, (e && e[0] == '1') ? 1 : 0);
     }
-    const int prev = g_lines_form;
-    if (form == 0 || form == 1) g_lines_form = form;
+    const int prev = g_lines_form.load();
+    if (form == 0 || form == 1) g_lines_form.store(form);
     return prev;
 }
+#endif
 
 static int cl_check(int V, int h1, int w1, int h2, int w2, int C, int D) {
     if (V <= 0 || h1 <= 0 || w1 <= 0 || h2 <= 0 || w2 <= 0 || D <= 0) return CER_EINVAL;
@@ -1120,6 +614,7 @@ extern "C" int cer_cost_lines_views_f32(const void* fmap1_split, const void* fma
         a.todo = (unsigned long long*)t + (long)v0 * (a.tpv + 1);     // this call's views own this stretch of the list
     }
     a.tpv8 = 0;
+#if CER_WITH_LINES8
     if (cer_cost_lines_form(-1) == 1) {
         // NW lines x one segment per block; lines whose bands do not fit its window are listed and done in the one-line form
         static int nw = 0, outd = 1;                         // lines per block: 4 (measured best) or 8 (CER_COST_LINES_NW=8); CER_COST_LINES_OUTD=0: values staged in LDS
@@ -1152,6 +647,7 @@ extern "C" int cer_cost_lines_views_f32(const void* fmap1_split, const void* fma
         CER_RETURN_IF_LAUNCH_FAILED();
         return CER_OK;
     }
+#endif
     hipLaunchKernelGGL(cost_lines_kernel<3>, dim3((unsigned)nblk), dim3(256), dyn, st, a);      // (<4>: 128 VGPRs with 6 spilled - measured slower at D = 44)
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
@@ -1162,14 +658,14 @@ extern "C" int cer_cost_lines_reduce_f32(const void* workspace, const float* dis
                                          int row_stride, double incre_d, int shift, int mode, int fuse_levels, float fuse_scale, void* stream) {
     if (!workspace || !disp_in || !vol) return CER_EINVAL;
     if (V <= 0 || h1 <= 0 || w1 <= 0 || D <= 0 || D > 64 || row_stride < D || (mode != 1 && mode != 2)) return CER_EINVAL;
-    if (fuse_levels > 1) {
+    if (fuse_levels >= 1) {                                 // (1: level 0 only, scaled - the compact rows of round 5; the lookup pools on the fly)
         if (mode != 1) return CER_EINVAL;
         int need = 0, n = D;
         for (int l = 0; l < fuse_levels; ++l) { need += n; n /= 2; }
         if (row_stride < need || fuse_levels > 6) return CER_ESHAPE;
     }
     const long P = (long)h1 * w1;
-    const float scale = (fuse_levels > 1 ? fuse_scale : 1.0f) / (float)(1 << (2 * CL_LOG2S));
+    const float scale = (fuse_levels >= 1 ? fuse_scale : 1.0f) / (float)(1 << (2 * CL_LOG2S));
     hipLaunchKernelGGL(cost_lines_reduce_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, disp_in, vol,
                        origin_out, V, P, D, row_stride, fuse_levels, scale, mode == 2 ? 1 : 0, (float)((D / 2) * incre_d), shift);
     CER_RETURN_IF_LAUNCH_FAILED();

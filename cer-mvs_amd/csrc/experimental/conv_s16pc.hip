@@ -737,11 +737,16 @@ static int sxpc_launch(S16Args& a, hipStream_t st) {
 // a 512-thread block streams the SAME 576 KB of z|r weights from L2 for 96 pixels that two lock-stepped 256-thread blocks of
 // conv_s16.hip share through the L1 for 256, the producers then queue behind those loads (VMEM issue: 13 k of their 31 k cycles per
 // tile), and a block that owns a whole CU leaves no room for another depth map's kernels.  Kept as an opt-in and as a test subject.
-static int g_sxpc_on = -1;
+#include <atomic>
+static std::atomic<int> g_sxpc_on{-1};
 extern "C" int cer_conv3x3_s16_pc(int on) {
-    if (g_sxpc_on < 0) g_sxpc_on = (getenv("CER_S16_PC") && atoi(getenv("CER_S16_PC")) != 0) ? 1 : 0;
-    const int prev = g_sxpc_on;
-    if (on == 0 || on == 1) g_sxpc_on = on;
+    int cur = g_sxpc_on.load();
+    if (cur < 0) {                                         // (first use: the environment decides; racing first users agree on the value)
+        int want = (getenv("CER_S16_PC") && atoi(getenv("CER_S16_PC")) != 0) ? 1 : 0;
+        g_sxpc_on.compare_exchange_strong(cur, want);
+    }
+    const int prev = g_sxpc_on.load();
+    if (on == 0 || on == 1) g_sxpc_on.store(on);
     return prev;
 }
 

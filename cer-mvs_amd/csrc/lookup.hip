@@ -11,11 +11,37 @@
 #define LK_PIX 64          // pixels per block
 #define LK_MAX_ROW 256     // max row_stride (floats)
 #define LK_MAX_TAPS 64     // max L*(2r+1)
+#ifndef LK_OCC4
+#define LK_OCC4 5          // blocks per CU the 4-prefetch-register instantiation (level-0-only rows) is compiled for
+#endif
 
 struct LevelInfo {
     int off[8];
     int len[8];
+    int pool;              // 1: the rows hold level 0 only; level l is formed on the fly (round 5, see lk_elem)
 };
+
+// LDS pitch of a staged row (floats): rs + 4 or + 8 so that pitch / 4 is odd - the 16-byte accesses of 8 consecutive lanes (one row each,
+// same column) then fall into 8 different 16-byte bank groups
+__host__ __device__ __forceinline__ int lk_pitch(int rs) { return rs + (((rs >> 2) & 1) ? 8 : 4); }
+
+// Element i of pyramid level lv formed from a level-0 row (core/corr.py:94-97: F.avg_pool2d([1,2]) level by level = (a + b) * 0.5, in the
+// association the build's fused epilogue / cer_pyramid_f32 use, so the value is BIT-IDENTICAL to the stored level).  The row is 16-byte
+// aligned and 2^lv * i is a multiple of 2^lv: one 8- / 16-byte LDS read per element.  Since round 5 the folded volume of RAFT.forward keeps
+// level 0 only: rows of D instead of 1.75 D floats (-43 % of the lookup's read bytes and of the build's volume write).
+__device__ __forceinline__ float lk_elem(const float* __restrict__ row, int lv, int i) {
+    if (lv == 0) return row[i];
+    if (lv == 1) {
+        const float2 v = *reinterpret_cast<const float2*>(row + 2 * i);
+        return (v.x + v.y) * 0.5f;
+    }
+    if (lv == 2) {
+        const float4 v = *reinterpret_cast<const float4*>(row + 4 * i);
+        return ((v.x + v.y) * 0.5f + (v.z + v.w) * 0.5f) * 0.5f;
+    }
+    const float4 u = *reinterpret_cast<const float4*>(row + 8 * i), v = *reinterpret_cast<const float4*>(row + 8 * i + 4);      // lv == 3 (at most 4 levels)
+    return (((u.x + u.y) * 0.5f + (u.z + u.w) * 0.5f) * 0.5f + ((v.x + v.y) * 0.5f + (v.z + v.w) * 0.5f) * 0.5f) * 0.5f;
+}
 
 __device__ __forceinline__ float lk_index(float disp, float origin, float incre, int D) {
     // core/corr.py:107 - true division then + D//2, lower clamp only
@@ -24,7 +50,8 @@ __device__ __forceinline__ float lk_index(float disp, float origin, float incre,
 }
 
 // one window of 2r+1 taps on level `lv` of the LDS row
-__device__ __forceinline__ void lk_window(const float* __restrict__ row, int off, int len, float x, int r, float* __restrict__ o) {
+// (pool: the row holds level 0 only and `lv` says which level to form; else `off` is the level's offset in the row)
+__device__ __forceinline__ void lk_window(const float* __restrict__ row, int off, int len, float x, int r, float* __restrict__ o, int pool = 0, int lv = 0) {
     // x = c / 2^lv (exact); taps at x + dx, dx = -r..r; zero outside [0, len-1] (grid_sample zeros padding, align_corners)
     const float fx = floorf(x);
     const float w = x - fx;
@@ -33,11 +60,11 @@ __device__ __forceinline__ void lk_window(const float* __restrict__ row, int off
     float prev = 0.f;
     {
         const int i = i0;
-        prev = (in_range && i >= 0 && i < len) ? row[off + i] : 0.f;
+        prev = (in_range && i >= 0 && i < len) ? (pool ? lk_elem(row, lv, i) : row[off + i]) : 0.f;
     }
     for (int j = 0; j < 2 * r + 1; ++j) {
         const int i = i0 + j + 1;
-        const float next = (in_range && i >= 0 && i < len) ? row[off + i] : 0.f;
+        const float next = (in_range && i >= 0 && i < len) ? (pool ? lk_elem(row, lv, i) : row[off + i]) : 0.f;
         o[j] = prev * (1.0f - w) + next * w;
         prev = next;
     }
@@ -52,7 +79,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(const float* __restrict__ v
     const int v = blockIdx.y;
     const long p0 = (long)blockIdx.x * LK_PIX;
     const int npix = (int)min((long)LK_PIX, P - p0);
-    const int rsp = rs + 4;                                  // padded LDS stride: rs % 32 == 16 or 0 -> +4 breaks the conflict pattern
+    const int rsp = lk_pitch(rs);                            // padded LDS stride
     // stage rows: rs/4 float4 per row
     const float* src = vol + ((long)v * P + p0) * rs;
     const int n4 = rs / 4;
@@ -71,7 +98,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(const float* __restrict__ v
     for (int lv = threadIdx.x >> 6; lv < L; lv += 4) {
         float o[32];
         const float x = c / (float)(1 << lv);
-        lk_window(&rows[pix * rsp], li.off[lv], li.len[lv], x, r, o);
+        lk_window(&rows[pix * rsp], li.off[lv], li.len[lv], x, r, o, li.pool, lv);
         float* dst = out + ((long)v * L * taps + (long)lv * taps) * P + p;
         for (int j = 0; j < taps; ++j) dst[(long)j * P] = o[j];
     }
@@ -92,24 +119,38 @@ __global__ __launch_bounds__(256) void lookup_kernel(const float* __restrict__ v
 // there - i.e. has finished its conv of tile t (the conv precedes the next tile's row stores and [B1](t+1) in every wave's program order).
 // The schedule-fuzz build (common.hpp CER_FUZZ) reproduces the first launch over 2 000 launches.
 #define LK_MAX_PRE 16      // float4 per thread of one 64-row tile: 64 * (LK_MAX_ROW / 4) / 256
-// MAXPRE: float4 registers of the next tile's rows per thread (8 serve rows up to 128 floats - the model's 112 - and leave the kernel under
-// 128 VGPRs: four blocks per CU with the single feature tile; 16: any row the entry point accepts, three blocks per CU)
+// Round 5: the PREVIOUS iteration's disparity update (core/update.py:114, core/raft.py:101: disp += 0.01 * delta, the 18-tap gather of
+// cer_delta_sum_f32) can ride on this launch: with `dT` given, wave 3 - idle while waves 0-2 form the three levels' windows - requests the
+// tap planes of a tile's pixels together with the tile's rows, forms  d' = d + 0.01 * (bias + sum of the taps)  in cer_delta_sum_f32's
+// order (bit-identical), writes it back to `disp` (in place: every pixel is read and written by exactly one thread of one block) and
+// publishes it to the block through LDS (`dnew`: written in front of [B1](t), read behind it, written again behind [B2](t)).
+struct LkDelta {
+    const float* T;        // [nhalf][9][P] tap planes of the fused delta head, or null: `disp` is used as it is
+    float* disp_rw;        // the disparity, updated in place
+    int nhalf, h;
+    float bias;
+};
+// MAXPRE: float4 registers of the next tile's rows per thread (4: level-0-only rows up to 64 floats - the model's since round 5; 8: rows up to
+// 128 floats - the stored pyramid's 112; 16: any row the entry point accepts)
 template <int MAXPRE>
-__global__ __launch_bounds__(256, MAXPRE <= 8 ? 4 : 3) void lookup_encode_kernel(const float* __restrict__ vol, const float* __restrict__ origin,
+__global__ __launch_bounds__(256, MAXPRE <= 4 ? LK_OCC4 : MAXPRE <= 8 ? 4 : 3) void lookup_encode_kernel(const float* __restrict__ vol, const float* __restrict__ origin,
                                                             const float* __restrict__ disp, const float* __restrict__ wgt,
                                                             const float* __restrict__ bias, float* __restrict__ out, long P, int D, int rs,
                                                             float incre, int L, int r, LevelInfo li, int out_split, float out_scale, int img_w,
-                                                            int ntiles) {
+                                                            int ntiles, LkDelta dl) {
     extern __shared__ __attribute__((aligned(16))) float lk_smem[];
-    const int rsp = rs + 4;
+    const int rsp = lk_pitch(rs);
     const int taps = 2 * r + 1, K = L * taps, FS = K | 1;                         // (odd pixel stride: conflict-free columns)
-    float* rows = lk_smem;                                   // [LK_PIX][rs + 4]
+    float* rows = lk_smem;                                   // [LK_PIX][rsp]
     float* feats = lk_smem + LK_PIX * rsp;                   // [LK_PIX][FS]  (one tile: see the happens-before note above)
+    float* dnew = feats + LK_PIX * FS;                       // [LK_PIX]  updated disparities of the tile (dl.T given)
     const int n4 = rs / 4, npre = (LK_PIX * n4 + 255) / 256;
     const int pix = threadIdx.x & 63;
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id: lookup level, then output-channel group
     float4 pre[MAXPRE];
     float pre_d = 0.f, pre_o = 0.f;
+    float tp[18];                                            // wave 3: the 2 x 9 taps of its pixel (zeros outside the image)
+    const bool fuse_delta = dl.T != nullptr;                 // (uniform)
     CER_FUZZ_INIT();
     // float4 number t = tid + 256 i of the tile is (row pr, quad q) = (t / n4, t % n4): walked incrementally (no division per item)
     const int pr0 = threadIdx.x / n4, q0 = threadIdx.x - pr0 * n4, dpr = 256 / n4, dq = 256 - dpr * n4;
@@ -117,7 +158,24 @@ __global__ __launch_bounds__(256, MAXPRE <= 8 ? 4 : 3) void lookup_encode_kernel
         const long p0 = (long)tile * LK_PIX;
         const int npix = (int)min((long)LK_PIX, P - p0);
         const float* src = vol + p0 * rs;
-        if (pix < npix) { pre_d = disp[p0 + pix]; pre_o = origin[p0 + pix]; }    // ... and this thread's pixel's window position
+        if (pix < npix) {                                    // ... and this thread's pixel's window position
+            pre_o = origin[p0 + pix];
+            if (!fuse_delta) {
+                pre_d = disp[p0 + pix];
+            } else if (grp == 3) {                           // (the other waves take the updated value from `dnew`)
+                pre_d = disp[p0 + pix];
+                const unsigned p = (unsigned)(p0 + pix);
+                const int y = (int)(p / (unsigned)img_w), x = (int)(p - (unsigned)y * (unsigned)img_w);
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                        const bool ok = hf < dl.nhalf && yy >= 0 && yy < dl.h && xx >= 0 && xx < img_w;
+                        tp[hf * 9 + tap] = ok ? dl.T[((long)hf * 9 + tap) * P + (long)yy * img_w + xx] : 0.f;
+                    }
+            }
+        }
         int pr = pr0, q = q0;
 #pragma unroll
         for (int i = 0; i < MAXPRE; ++i) {                // (predicated, not `break`: pre[] must stay in registers)
@@ -134,8 +192,17 @@ __global__ __launch_bounds__(256, MAXPRE <= 8 ? 4 : 3) void lookup_encode_kernel
         const long p0 = (long)tile * LK_PIX;
         const int npix = (int)min((long)LK_PIX, P - p0);
         const bool active = pix < npix;
-        const float c = active ? lk_index(pre_d, pre_o, incre, D) : 0.f;
+        float c = (active && !fuse_delta) ? lk_index(pre_d, pre_o, incre, D) : 0.f;
+        const float po = pre_o;                              // (request() below overwrites pre_o with the next tile's)
         CER_FUZZ_POINT();                                    // (in front of the LDS write phase)
+        if (fuse_delta && grp == 3 && active) {
+            float s = 0.f;                                   // cer_delta_sum_f32's order: half-major, taps in order (a tap outside the image adds + 0)
+#pragma unroll
+            for (int i = 0; i < 18; ++i) s += tp[i];
+            const float dn = pre_d + 0.01f * (s + dl.bias);
+            dl.disp_rw[p0 + pix] = dn;
+            dnew[pix] = dn;
+        }
         {
             int pr = pr0, q = q0;
 #pragma unroll
@@ -151,9 +218,10 @@ __global__ __launch_bounds__(256, MAXPRE <= 8 ? 4 : 3) void lookup_encode_kernel
         CER_FUZZ_POINT();
         if (tile + (int)gridDim.x < ntiles) request(tile + gridDim.x);
         float* ft = feats;
+        if (fuse_delta && active) c = lk_index(dnew[pix], po, incre, D);
         if (active)
             for (int lv = grp; lv < L; lv += 4)            // (straight into the feature tile: no per-thread array)
-                lk_window(&rows[pix * rsp], li.off[lv], li.len[lv], c / (float)(1 << lv), r, &ft[pix * FS + lv * taps]);
+                lk_window(&rows[pix * rsp], li.off[lv], li.len[lv], c / (float)(1 << lv), r, &ft[pix * FS + lv * taps], li.pool, lv);
         __syncthreads();                                     // [B2] features complete; rows free for the next tile
         CER_FUZZ_POINT();
         if (!active) continue;
@@ -220,7 +288,12 @@ static int level_info(int D, int rs, int L, int r, LevelInfo* li) {
         off += n;
         n /= 2;
     }
-    if (off > rs) return CER_ESHAPE;
+    // rows shorter than the whole pyramid hold level 0 only (round 5): the pooled levels are formed on the fly
+    li->pool = 0;
+    if (off > rs) {
+        if (rs < D) return CER_ESHAPE;
+        li->pool = 1;
+    }
     return CER_OK;
 }
 
@@ -232,18 +305,19 @@ extern "C" int cer_corr_lookup_f32(const float* vol, const float* origin, const 
     int rc = level_info(D, row_stride, num_levels, radius, &li);
     if (rc) return rc;
     hipLaunchKernelGGL(lookup_kernel, dim3((unsigned)((P + LK_PIX - 1) / LK_PIX), (unsigned)nv), dim3(256),
-                       sizeof(float) * LK_PIX * (row_stride + 4), (hipStream_t)stream, vol, origin,
+                       sizeof(float) * LK_PIX * lk_pitch(row_stride), (hipStream_t)stream, vol, origin,
                        disp, disp_view_stride, out, P, D, row_stride, (float)incre, num_levels, radius, li);
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }
 
-extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, const float* disp, const float* w, const float* b, float* out,
+extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, float* disp, const float* w, const float* b, float* out,
                                      long P, int D, int row_stride, double incre, int num_levels, int radius, int Cout, int out_split,
-                                     int log2s_out, int img_w, void* stream) {
+                                     int log2s_out, int img_w, const float* delta_taps, int delta_nhalf, float delta_bias, void* stream) {
     if (!vol || !origin || !disp || !w || !b || !out || P <= 0 || D <= 0) return CER_EINVAL;
     if (Cout != 64 || num_levels > 4) return CER_ESHAPE;
-    if (out_split == 2 && (img_w <= 0 || P % img_w != 0 || P >= (1L << 31))) return CER_ESHAPE;
+    if ((out_split == 2 || delta_taps) && (img_w <= 0 || P % img_w != 0 || P >= (1L << 31))) return CER_ESHAPE;
+    if (delta_taps && (delta_nhalf < 1 || delta_nhalf > 2)) return CER_ESHAPE;
     if (!cer_aligned16(vol) || !cer_aligned16(out)) return CER_EALIGN;
     LevelInfo li;
     int rc = level_info(D, row_stride, num_levels, radius, &li);
@@ -251,7 +325,7 @@ extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, cons
     const int K = num_levels * (2 * radius + 1);
     const long ntiles = (P + LK_PIX - 1) / LK_PIX;
     if (ntiles >= (1L << 30)) return CER_ESHAPE;
-    const size_t smem = sizeof(float) * LK_PIX * ((size_t)(row_stride + 4) + (K | 1));
+    const size_t smem = sizeof(float) * LK_PIX * ((size_t)lk_pitch(row_stride) + (K | 1) + 1);
     static int ncu = 0;
     if (ncu == 0) {
         int dev = 0;
@@ -259,15 +333,19 @@ extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, cons
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
         if (ncu <= 0) ncu = 256;
     }
-    const bool small = row_stride <= 128;                    // 8 prefetch registers per thread suffice: the four-blocks-per-CU instantiation
-    const long resident = (long)ncu * (small && smem <= 39 * 1024 ? 4 : smem <= 50 * 1024 ? 3 : smem <= 76 * 1024 ? 2 : 1);
+    LkDelta dl;
+    dl.T = delta_taps; dl.disp_rw = disp; dl.nhalf = delta_nhalf; dl.h = delta_taps ? (int)(P / img_w) : 0; dl.bias = delta_bias;
+    const int pre = row_stride <= 64 ? 4 : row_stride <= 128 ? 8 : LK_MAX_PRE;      // prefetch registers per thread: which instantiation
+    const int by_regs = pre == 4 ? LK_OCC4 : pre == 8 ? 4 : 3;
+    const int by_lds = (int)((160 * 1024) / (smem + 256));
+    const long resident = (long)ncu * (by_lds < 1 ? 1 : by_lds < by_regs ? by_lds : by_regs);
     const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);
-    if (small)
-        hipLaunchKernelGGL(lookup_encode_kernel<8>, dim3(grid), dim3(256), smem, (hipStream_t)stream, vol, origin, disp, w, b, out, P, D, row_stride,
-                           (float)incre, num_levels, radius, li, out_split, ldexpf(1.0f, log2s_out), img_w, (int)ntiles);
-    else
-        hipLaunchKernelGGL(lookup_encode_kernel<LK_MAX_PRE>, dim3(grid), dim3(256), smem, (hipStream_t)stream, vol, origin, disp, w, b, out, P, D, row_stride,
-                           (float)incre, num_levels, radius, li, out_split, ldexpf(1.0f, log2s_out), img_w, (int)ntiles);
+#define LK_LAUNCH(N) hipLaunchKernelGGL(lookup_encode_kernel<N>, dim3(grid), dim3(256), smem, (hipStream_t)stream, vol, origin, disp, w, b, out, P, D, row_stride, \
+                                        (float)incre, num_levels, radius, li, out_split, ldexpf(1.0f, log2s_out), img_w, (int)ntiles, dl)
+    if (pre == 4) LK_LAUNCH(4);
+    else if (pre == 8) LK_LAUNCH(8);
+    else LK_LAUNCH(LK_MAX_PRE);
+#undef LK_LAUNCH
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }

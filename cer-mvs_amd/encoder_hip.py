@@ -71,6 +71,12 @@ class HipEncoder:
                 down = _Conv(blk.downsample[0], device) if blk.downsample is not None else None
                 self.blocks.append((_Conv(blk.conv1, device), _Conv(blk.conv2, device), down))
         self.head = _Conv(enc.conv2, device)
+        # what the producer / consumer engine serves (csrc/enc_pc.hip: cer_enc_pc_supported): the trunk's convolutions are fixed by the
+        # encoder type, but the head is Conv2d(64, output_dim, 1) - `dim_fmap` / `dim_net + dim_inp` are constructor arguments of the
+        # reference's RAFT (core/raft.py:14-30).  Anything it refuses runs on the tiled engine (csrc/enc_conv.hip: any Cout % 64 == 0).
+        sup = lambda c, epi: bool(lib.cer_enc_pc_supported(c.cin, c.cout, c.taps, c.stride, epi))
+        self.pc_trunk = all(sup(c, 0) for blk in self.blocks for c in blk if c is not None)
+        self.pc_head = {epi: sup(self.head, epi) for epi in (1, 2, 3)}       # FMAP, CTX (tanh | relu halves), FSPLIT
 
     # ---- kernel faces
     def _stats(self, part, N, nblk, C, pixels):
@@ -183,15 +189,21 @@ class HipEncoder:
 
     def _head(self, x, N, h, w, epi, out, out2=None, border=0, scale=1.0):
         """final 1x1 conv of a (virtual or plain) trunk output into the consumers' layouts"""
-        if isinstance(x, _In):
+        if isinstance(x, _In) and self.pc_head.get(epi, False):
             self._pc(self.head, x, N, h, w, epi=epi, out=out, out2=out2, border=border, scale=scale)
-        else:
-            self._conv(self.head, x, N, h, w, None, False, epi=epi, out=out, out2=out2, border=border, scale=scale)
+            return
+        if isinstance(x, _In):                 # a head the producer / consumer kernels do not serve: materialise the merge, tiled engine
+            x = self._merge(x.A, x.sA, x.B, x.sB, N, h * w, x.C, (1 if x.rA else 0) | (2 if x.rB else 0) | 4)
+        self._conv(self.head, x, N, h, w, None, False, epi=epi, out=out, out2=out2, border=border, scale=scale)
 
     def _trunk_any(self, x, raw):
-        if ENGINE == "pc":
+        if ENGINE == "pc" and self.pc_trunk:
             return self._trunk_pc(x, raw)
         return self.trunk(x, raw)
+
+    def supports_split_head(self):
+        """``features_split`` is available: producer / consumer trunk and a 64 -> 64 feature head."""
+        return ENGINE == "pc" and self.pc_trunk and self.pc_head[3]
 
     def features_split(self, x, ref_split, src_split, n_ref=1, border=2, scale=0.125, raw=False, flag=None):
         """fnet head straight into the cost volume's split-f16 operand planes (ops.feat_split's layout, csrc/cost_lines.hip): the first
@@ -244,9 +256,6 @@ class HipEncoder:
         a, h, w = self._trunk_any(x, False)
         N, C = x.shape[0], self.head.cout
         out = torch.empty(N, h * w, C, device=self.device, dtype=torch.float32)
-        if C == 64 or not isinstance(a, _In):
-            self._head(a, N, h, w, 1, out, border=0, scale=1.0)
-        else:                                  # (the 128-channel context head exists as the tanh | relu epilogue only: materialise for the plain form)
-            m = self._merge(a.A, a.sA, a.B, a.sB, N, h * w, a.C, (1 if a.rA else 0) | (2 if a.rB else 0) | 4)
-            self._conv(self.head, m, N, h, w, None, False, epi=1, out=out, border=0, scale=1.0)
+        self._head(a, N, h, w, 1, out, border=0, scale=1.0)      # (heads the producer / consumer kernels do not have - e.g. a plain 128-channel
+                                                                #  output - go through the materialised merge inside _head)
         return out.view(N, h, w, C).permute(0, 3, 1, 2).contiguous()

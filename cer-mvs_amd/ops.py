@@ -7,15 +7,17 @@ import torch
 from . import _lib as L
 
 
-def row_layout(D, num_levels):
-    """Volume row layout [level0 | level1 | ...] -> (offsets, lengths, row_stride multiple of 4)."""
+def row_layout(D, num_levels, compact=False):
+    """Volume row layout [level0 | level1 | ...] -> (offsets, lengths, row_stride multiple of 4).  ``compact`` (round 5, the folded
+    volume of RAFT.forward): the row holds level 0 only - the lookup kernels form the pooled levels on the fly, bit-identically -
+    and the stride is D rounded up to 4."""
     offs, lens, n, off = [], [], D, 0
     for _ in range(num_levels):
         offs.append(off)
         lens.append(n)
         off += n
         n //= 2
-    return offs, lens, (off + 3) // 4 * 4
+    return offs, lens, ((D if compact else off) + 3) // 4 * 4
 
 
 def alt_corr_forward(fmap1, fmap2, coords, radius):
@@ -180,7 +182,7 @@ def _lines_workspace(V, h1, w1, D, device):
 
 
 def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, fold, vol=None, accumulate=False, src_hw=None, y0=0,
-               pyramid_scale=None, split=None):
+               pyramid_scale=None, split=None, compact=False):
     """fmap1 [P,C], fmap2 [V,(h2+4)*(w2+4),C] (NHWC, pre-scaled, 2-texel zero border), Pij [V,4,4], disp_in [P].
     (h1, w1): reference grid of this call, first image row ``y0`` (row slabs); ``src_hw``: source-map size (default h1, w1).
     Returns (vol [V,P,rs] or [P,rs], origin [P]).  Level 0 only; call ``pyramid`` next - unless ``pyramid_scale`` is given
@@ -189,7 +191,8 @@ def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, 
     selects the walk; ``split`` = (feat_split(fmap1), feat_split(fmap2)) if the caller already has them (they are the same for
     every stage of a forward), else they are made here; a third element ``slots`` (int32 [V], device) says that view v's split
     rows are block slots[v] of the second element (any leading shape; the sharded forward's gathered buffer) - ``fmap2`` may then
-    be None and ``V`` = len(slots)."""
+    be None and ``V`` = len(slots).  ``compact``: level-0-only rows (``row_layout``); with ``pyramid_scale`` the epilogue then only
+    scales (epipolar-line-tile kernel; the walk's fused epilogue always writes the pooled levels and refuses)."""
     if fmap2 is None:
         if split is None or len(split) < 3 or src_hw is None:
             raise ValueError("cost_build: without fmap2 the split rows, their view slots and src_hw are required")
@@ -201,13 +204,16 @@ def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, 
     h2, w2 = src_hw if src_hw is not None else (h1, w1)
     if P2 != (h2 + 4) * (w2 + 4):
         raise RuntimeError("cost_build: fmap2 must carry a 2-texel zero border ([V,(h+4)*(w+4),C])")
-    _, _, rs = row_layout(D, num_levels)
+    _, _, rs = row_layout(D, num_levels, compact)
     fuse = pyramid_scale is not None
     if fuse and (not fold or accumulate or D > 64):
         raise ValueError("cost_build: the fused pyramid needs fold=True, accumulate=False and D <= 64")
+    lib = L.load()
+    on_lines = fold and C == 64 and D <= 64 and (fmap2 is None or lib.cer_cost_build_algo(-1) != 1)
     late_scale = None
-    if fuse and num_levels < 2:          # nothing to pool: the kernels' fused epilogue is keyed on levels > 1, so scale afterwards
+    if fuse and (num_levels < 2 or (compact and not on_lines)):   # nothing to pool in the kernel: scale afterwards (the walk's fused epilogue is keyed on levels > 1)
         fuse, late_scale = False, float(pyramid_scale)
+    fuse_levels = 0 if not fuse else (1 if compact else num_levels)
     if vol is None:
         shape = (P, rs) if fold else (V, P, rs)
         if fuse:
@@ -215,15 +221,15 @@ def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, 
             # alignment pad of a row (rs - used, <= 3 floats) is cleared
             vol = torch.empty(shape, device=fmap1.device, dtype=torch.float32)
             offs, lens, _ = row_layout(D, num_levels)
-            if offs[-1] + lens[-1] < rs:
-                vol[..., offs[-1] + lens[-1]:] = 0
+            used = D if compact else offs[-1] + lens[-1]
+            if used < rs:
+                vol[..., used:] = 0
         else:
             vol = torch.zeros(shape, device=fmap1.device, dtype=torch.float32)     # pooled levels stay 0 until ``pyramid`` runs
     origin = torch.empty(P, device=fmap1.device, dtype=torch.float32)
     mode = (2 if accumulate else 1) if fold else 0
-    lib = L.load()
     slots = split[2] if (split is not None and len(split) > 2) else None
-    if fold and C == 64 and D <= 64 and (fmap2 is None or lib.cer_cost_build_algo(-1) != 1):
+    if on_lines:
         f1s, f2s = split[:2] if split is not None else (None, None)
         if f1s is None:
             f1s = feat_split(fmap1)
@@ -233,7 +239,7 @@ def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, 
         L.check(lib.cer_cost_lines_f32(L.dev_ptr(f1s, "fmap1_split", torch.float16), L.dev_ptr(f2s, "fmap2_split", torch.float16),
                                        L.dev_ptr(slots, "view_slot", torch.int32), L.dev_ptr(Pij, "Pij"), L.dev_ptr(disp_in, "disp_in"), L.dev_ptr(vol, "vol"),
                                        L.dev_ptr(origin, "origin"), L.dev_ptr(ws, "workspace", torch.uint8), V, h1, w1, h2, w2, C, D, rs,
-                                       float(incre), int(bool(shift)), mode, int(y0), num_levels if fuse else 0,
+                                       float(incre), int(bool(shift)), mode, int(y0), fuse_levels,
                                        float(pyramid_scale) if fuse else 1.0, L.cur_stream()), "cost_lines")
     else:
         if fmap2 is None:
@@ -244,7 +250,7 @@ def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, 
                                        num_levels if fuse else 0, float(pyramid_scale) if fuse else 1.0, L.cur_stream()),
                 "cost_build")
     if late_scale is not None:
-        pyramid(vol, D, num_levels, scale=late_scale)
+        pyramid(vol, D, 1 if compact else num_levels, scale=late_scale)
     return vol, origin
 
 
@@ -260,28 +266,29 @@ def cost_lines_views(f1s, f2s, slots, Pij, disp_in, V, v0, nv, h1, w1, D, incre,
                                               int(bool(shift)), int(y0), L.cur_stream()), "cost_lines_views")
 
 
-def cost_lines_reduce(disp_in, V, h1, w1, D, incre, shift, num_levels, pyramid_scale=None, vol=None, accumulate=False, ws=None):
+def cost_lines_reduce(disp_in, V, h1, w1, D, incre, shift, num_levels, pyramid_scale=None, vol=None, accumulate=False, ws=None, compact=False):
     """Second half: sum of the V partial volumes -> (vol [P, rs], origin [P]) with the fused view-mean scale + pooled levels when
-    ``pyramid_scale`` is given (as ``cost_build``)."""
+    ``pyramid_scale`` is given (as ``cost_build``; ``compact``: level-0-only rows, scale only)."""
     P = h1 * w1
-    _, _, rs = row_layout(D, num_levels)
-    fuse = pyramid_scale is not None and num_levels > 1 and not accumulate
+    _, _, rs = row_layout(D, num_levels, compact)
+    fuse = pyramid_scale is not None and (num_levels > 1 or compact) and not accumulate
     dev = disp_in.device
     if vol is None:
         vol = torch.empty(P, rs, device=dev, dtype=torch.float32) if fuse else torch.zeros(P, rs, device=dev, dtype=torch.float32)
         if fuse:
             offs, lens, _ = row_layout(D, num_levels)
-            if offs[-1] + lens[-1] < rs:
-                vol[..., offs[-1] + lens[-1]:] = 0
+            used = D if compact else offs[-1] + lens[-1]
+            if used < rs:
+                vol[..., used:] = 0
     origin = torch.empty(P, device=dev, dtype=torch.float32)
     if ws is None:
         ws = _lines_workspace(V, h1, w1, D, dev)
     L.check(L.load().cer_cost_lines_reduce_f32(L.dev_ptr(ws, "workspace", torch.uint8), L.dev_ptr(disp_in, "disp_in"), L.dev_ptr(vol, "vol"),
                                                L.dev_ptr(origin, "origin"), V, h1, w1, D, rs, float(incre), int(bool(shift)),
-                                               2 if accumulate else 1, num_levels if fuse else 0, float(pyramid_scale) if fuse else 1.0,
-                                               L.cur_stream()), "cost_lines_reduce")
+                                               2 if accumulate else 1, (1 if compact else num_levels) if fuse else 0,
+                                               float(pyramid_scale) if fuse else 1.0, L.cur_stream()), "cost_lines_reduce")
     if pyramid_scale is not None and not fuse:
-        pyramid(vol, D, num_levels, scale=float(pyramid_scale))
+        pyramid(vol, D, 1 if compact else num_levels, scale=float(pyramid_scale))
     return vol, origin
 
 
@@ -314,16 +321,21 @@ def corr_encode(feats, w_t, b, out=None):
     return out
 
 
-def lookup_encode(vol, origin, disp, w_t, b, D, incre, num_levels, radius, out=None, out_split=False, log2s=0, img_w=0):
+def lookup_encode(vol, origin, disp, w_t, b, D, incre, num_levels, radius, out=None, out_split=False, log2s=0, img_w=0, delta=None):
     """Folded volume [P,rs] -> relu(conv1x1(lookup)) [P,64] (``out_split``: True / 1 = split32 layout, see ``split32``;
-    2 = frag16 layout of an image ``img_w`` pixels wide with scale 2^log2s, see ``s16_layout``: ``out`` [s16_pixels, 64])."""
+    2 = frag16 layout of an image ``img_w`` pixels wide with scale 2^log2s, see ``s16_layout``: ``out`` [s16_pixels, 64]).
+    Rows shorter than the whole pyramid hold level 0 only (``row_layout(..., compact=True)``): the kernel forms the pooled levels itself.
+    ``delta`` = (T [nhalf,9,P], bias): the previous iteration's disparity update (``delta_sum``) is applied to ``disp`` IN PLACE by this
+    launch before the lookup reads it (needs ``img_w``)."""
     P, rs = vol.shape
     if out is None:
         rows = s16_pixels(P // img_w, img_w) if int(out_split) == 2 else P
         out = torch.zeros(rows, 64, device=vol.device, dtype=torch.float32)
+    T, nhalf, dbias = (delta[0], int(delta[0].shape[0]), float(delta[1])) if delta is not None else (None, 0, 0.0)
     L.check(L.load().cer_lookup_encode_f32(L.dev_ptr(vol, "vol"), L.dev_ptr(origin, "origin"), L.dev_ptr(disp, "disp"),
                                            L.dev_ptr(w_t, "w"), L.dev_ptr(b, "b"), L.dev_ptr(out, "out"), P, D, rs, float(incre),
-                                           num_levels, radius, 64, int(out_split), int(log2s), int(img_w), L.cur_stream()), "lookup_encode")
+                                           num_levels, radius, 64, int(out_split), int(log2s), int(img_w), L.dev_ptr(T, "delta_taps"), nhalf, dbias,
+                                           L.cur_stream()), "lookup_encode")
     return out
 
 

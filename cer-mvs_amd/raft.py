@@ -257,6 +257,7 @@ class RAFT(nn.Module):
         return net, inp, f1, buf, (f1s, f2s), (done, lws)
 
     DIRECT_SPLIT = _os.environ.get("CER_DIRECT_SPLIT", "1") == "1"
+    COMPACT_VOLUME = _os.environ.get("CER_COMPACT_VOLUME", "1") == "1"      # level-0-only rows of the folded volume (s16 loop; A/B switch)
 
     def _encode_direct_split(self, images, V, h, w):
         """encode() whose feature head writes the cost volume's split-f16 operand planes directly -> (net, inp, (f1s, f2s, slots))."""
@@ -407,8 +408,10 @@ class RAFT(nn.Module):
                         and self.precision == "fp32" and self.encoder_type == "HR" and self.dim_fmap == 64
                         and L.load().cer_cost_build_algo(-1) != 1 and all(D_ <= 64 for D_, _, _ in self.stages()))
         if direct_split:
-            from . import encoder_hip
-            direct_split = encoder_hip.ENGINE == "pc"
+            from .encoder_hip import HipEncoder
+            if self._engines is None or self._engines[0] != dev:
+                self._engines = (dev, HipEncoder(self.fnet, dev), HipEncoder(self.cnet, dev))
+            direct_split = self._engines[1].supports_split_head()
         if pipelined:
             net_l, inp_l, f1, f2, split, build_done = self._encode_pipelined(images, V, Pij, disp, D0, incre0, h, w)
         elif direct_split:
@@ -438,20 +441,24 @@ class RAFT(nn.Module):
         for stage, (D, incre, T) in enumerate(self.stages()):
             hoisted = hoisted_all[stage]
             single = self.view_group is None   # no cross-rank sum between the build and the pooling: fuse them
+            # round 5: the folded volume keeps LEVEL 0 ONLY (rows of D instead of 1.75 D floats); the lookup kernel forms the pooled levels
+            # on the fly, bit-identically (csrc/lookup.hip lk_elem) - less to write, to all-reduce (shard="views") and to read 32 times
+            compact = self.COMPACT_VOLUME
             if pipelined and stage == 0:          # the partial volumes were built under the encoders: only the view reduction is left
                 torch.cuda.current_stream().wait_event(build_done[0])
-                vol, origin = ops.cost_lines_reduce(disp, V, h, w, D, incre, True, ub.num_levels, pyramid_scale=1.0 / V, ws=build_done[1])
+                vol, origin = ops.cost_lines_reduce(disp, V, h, w, D, incre, True, ub.num_levels, pyramid_scale=1.0 / V, ws=build_done[1],
+                                                    compact=compact)
             elif views:
                 vol, origin = ops.cost_build(f1, f2, Pij, disp, D, incre, stage == 0, h, w, ub.num_levels, fold=True,
                                              pyramid_scale=(1.0 / V) if (single and D <= 64) else None, split=split,
-                                             src_hw=(h, w) if f2 is None else None)
+                                             src_hw=(h, w) if f2 is None else None, compact=compact)
             else:                      # more ranks than views: contribute zeros
-                _, _, rs = ops.row_layout(D, ub.num_levels)
+                _, _, rs = ops.row_layout(D, ub.num_levels, compact)
                 vol = torch.zeros(P, rs, device=dev)
                 origin = cdist.stage_origin(disp, D, incre, stage == 0)
             if not (single and views and D <= 64):
                 cdist.reduce_volume(vol, self.view_group)
-                ops.pyramid(vol, D, ub.num_levels, scale=1.0 / V)
+                ops.pyramid(vol, D, 1 if compact else ub.num_levels, scale=1.0 / V)
             if do_report and stage > 0:
                 report()
             ub.run(T, vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws)

@@ -401,9 +401,9 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
             d = st[g]
             vol, origin = ops.cost_build(d["f1s"], d["f2"], Pij, d["disp"], D, incre, stage == 0, d["hs"], w, ub.num_levels,
                                          fold=True, src_hw=(h, w), y0=d["e0"], pyramid_scale=(1.0 / V) if D <= 64 else None,
-                                         split=d["split"])
+                                         split=d["split"], compact=model.COMPACT_VOLUME)
             if D > 64:
-                ops.pyramid(vol, D, ub.num_levels, scale=1.0 / V)
+                ops.pyramid(vol, D, 1 if model.COMPACT_VOLUME else ub.num_levels, scale=1.0 / V)
             d["vol"], d["origin"] = vol, origin
         ub.packed(stage, dev)                  # host-side weight packing stays out of the recorded plans
         for it in range(T):

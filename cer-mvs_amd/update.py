@@ -216,22 +216,30 @@ class UpdateBlock(nn.Module):
             return ops.from_frag16(net_l, h, w, L.S16_UNIT)
         return ops.split32(net_l, inverse=True) if self.split_acts() else net_l
 
-    def step(self, vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws):
+    # s16 path: the disparity update of iteration i (the 18-tap gather of the fused delta head's tap planes, ``ops.delta_sum``) rides on the
+    # lookup launch of iteration i + 1 (csrc/lookup.hip, round 5): one launch less per iteration; the last iteration of a stage ends with
+    # the stand-alone kernel.  Off where something reads ``disp`` between two iterations (the row-slab exchange: ``run(after=...)``).
+    FUSE_DELTA = __import__("os").environ.get("CER_FUSE_DELTA", "1") == "1"      # (A/B switch)
+
+    def step(self, vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws, delta="now"):
         """One GRU iteration on the folded volume; updates ``net_l`` [P,64] (see ``prepare_net``) and ``disp`` [P] in place.
-        ``ws``: dict of scratch tensors (c1, c2, z, rn, hid) reused across iterations."""
+        ``ws``: dict of scratch tensors (c1, c2, z, rn, hid) reused across iterations.  ``delta`` (s16 path): "now" - the disparity update
+        is a launch of its own at the end of the step; "defer" - it is left pending in ``ws["T"]`` for the next step's lookup;
+        "apply+defer" - this step's lookup first applies the pending update of the previous step, and leaves its own pending."""
         p = self.packed(stage, net_l.device)
         hzr, hq = hoisted
         if self.conv_mode == "s16":
             U, R = L.S16_UNIT, L.S16_RELU
             ops.lookup_encode(vol, origin, disp, p["w0t"], p["b0"], D, incre, self.num_levels, self.radius, out=ws["c1"], out_split=2, log2s=R,
-                              img_w=w)
+                              img_w=w, delta=(ws["T"], p["d2b"]) if delta == "apply+defer" else None)
             ops.conv3x3_s16(p["s_corr2"], [ws["c1"]], h, w, L.EPI_RELU, out=ws["c2"], out_split=True, log2s_out=R)
             ops.conv3x3_s16(p["s_zr"], [net_l, disp, ws["c2"]], h, w, L.EPI_GATES, out=ws["z"], out2=ws["rn"], aux=net_l, init=hzr,
                             log2s_out=U, log2s_aux=U)
             ops.conv3x3_s16(p["s_q"], [ws["rn"], disp, ws["c2"]], h, w, L.EPI_GRU, out=net_l, aux=net_l, aux2=ws["z"], init=hq,
                             log2s_out=U, log2s_aux=U)
             ops.conv3x3_s16(p["s_d1"], [net_l], h, w, L.EPI_DELTA, out=ws["T"], aux=p["s_d2proj"])
-            ops.delta_sum(ws["T"], p["d2b"], disp, h, w, disp_out=disp, want_delta=False)
+            if delta == "now":
+                ops.delta_sum(ws["T"], p["d2b"], disp, h, w, disp_out=disp, want_delta=False)
             return
         if self.split_acts():
             ops.lookup_encode(vol, origin, disp, p["w0t"], p["b0"], D, incre, self.num_levels, self.radius, out=ws["c1"], out_split=True)
@@ -259,18 +267,25 @@ class UpdateBlock(nn.Module):
         are recorded (``_lib.LaunchPlan``), the rest replay them.  ``after(i)``: called after every iteration (the slab
         exchange of the sharded forward)."""
         plan = None
-        self.packed(stage, net_l.device)        # weight packing (host work) must not end up in the recorded plan
+        p = self.packed(stage, net_l.device)    # weight packing (host work) must not end up in the recorded plan
+        fuse = self.FUSE_DELTA and self.conv_mode == "s16" and after is None and iters >= 2
         for i in range(iters):
+            if fuse and i == 0:                 # nothing pending yet: through the checked wrappers, its update left pending
+                self.step(vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws, delta="defer")
+                continue
+            mode = "apply+defer" if fuse else "now"
             if not USE_PLANS:
-                self.step(vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws)
+                self.step(vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws, delta=mode)
             elif plan is None:
                 plan = L.LaunchPlan(keep=(vol, origin, net_l, disp, hoisted, ws))
                 with L.recording(plan):
-                    self.step(vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws)
+                    self.step(vol, origin, net_l, disp, hoisted, stage, h, w, D, incre, ws, delta=mode)
             else:
                 plan.replay()
             if after is not None:
                 after(i)
+        if fuse:                                # the last iteration's update
+            ops.delta_sum(ws["T"], p["d2b"], disp, h, w, disp_out=disp, want_delta=False)
         if self.conv_mode == "s16" and iters > 0 and self.CHECK_OVERFLOW:
             # the s16 layouts clamp ReLU-class activations beyond 4094 (65504 / 2^4): saturation must not be silent - scan what the
             # last iteration left in memory (2 x ~8 us; the delta head's hidden map is checked inside its kernel)

@@ -10,8 +10,9 @@
  *     enqueues work on it and returns (asynchronous), so it is hipGraph-capturable;
  *   - return 0 on success, a negative CER_E* for an argument error (nothing was launched),
  *     or a positive hipError_t from the launch; never throws.  Compute entry points keep no state between calls and are
- *     re-entrant; the library holds exactly two process-wide switches, both set through their own entry points and read by later
+ *     re-entrant; the library holds exactly two pieces of process-wide state, both set through their own entry points and read by later
  *     launches: the per-device overflow flag (cer_overflow_flag) and the cost-volume algorithm selector (cer_cost_build_algo).
+ *     (The opt-in kernel forms of round 4 and their switches live in variants/libcermvs_optin.so only: include/cer_mvs_variants.h.)
  *
  * Each function cites the reference interface (file:line under the reference tree) it
  * replaces.  INTEGRATION.md shows the binding a reference maintainer would add.
@@ -43,11 +44,6 @@ int cer_device_count(void);
  * checked after the fact: cer_f16_scan_overflow ors `bit` into *flag if any half of a split-f16 buffer (frag16 tensors, split
  * feature rows; `bytes` % 16 == 0) sits at the f16 maximum or is not finite.  The host reads the flag when convenient. */
 int cer_overflow_flag(int* flag);
-/* Producer / consumer form of the GRU loop's fp8-correction convolutions (csrc/conv_s16pc.hip, round 4): process-wide switch,
- * 0 = off (default: the kernels of csrc/conv_s16.hip; environment CER_S16_PC=1 turns it on at load), 1 = on, anything else = query;
- * returns the previous setting.  Same operands and results (the hoisted `init` term is added in the epilogue instead of seeding the
- * accumulators: last-bit differences); measured slower at the bench workload - see the note at the switch. */
-int cer_conv3x3_s16_pc(int on);
 int cer_f16_scan_overflow(const void* data, long bytes, int* flag, int bit, void* stream);
 
 /* ------------------------------------------------------------------------------------
@@ -130,21 +126,12 @@ int cer_cost_build_algo(int algo);
  *   a block = one view (block_texels = (h2+4)*(w2+4), zero border included and kept zero) or the reference map (h1*w1).
  *   |x| > 1023 saturates: *overflow_flag (device int, may be NULL) is or-ed with 1.
  * cer_cost_lines_workspace: bytes of `workspace` (per-view partial volumes [V,P,D] + tile parameters + the hand-over list below).
- * cer_cost_lines_form: which kernel builds the partial volumes: 0 (default) one line per 256-thread block (round 3); 1 = several
- *   neighbouring lines of a segment per block sharing ONE band fetched through LDS (round 4 experiment: 2 x fewer texel bytes through
- *   the CU's vector-memory path, but more vector instructions per sample - measured no faster; lines whose bands do not
- *   fit its window are listed in the workspace and finished by the one-line kernel in the same call).  Same cells, weights and dot
- *   products: the two forms agree bit for bit.  Process-wide like cer_cost_build_algo (CER_COST_LINES_FORM in the environment sets
- *   the initial value); returns the previous setting, < 0 only queries.
  * cer_cost_lines_f32: arguments as cer_cost_build_f32 with the split rows in place of fmap1 / fmap2; mode 1 or 2 only.
  *   view_slot (device int [V], may be NULL = identity): view v's rows are block view_slot[v] of fmap2_split - the multi-GPU
  *   forward all-gathers every rank's split rows into one [G, ceil(V/G), ...] buffer and builds from it without a reordering copy.
  */
 int cer_feat_split_f16(const float* src, void* dst, long blocks, long block_texels, int C, int* overflow_flag, void* stream);
 long cer_cost_lines_workspace(int V, int h1, int w1, int D);
-int cer_cost_lines_form(int form);
-/* Diagnostics: 32 counters of the eight-line kernel (all zero unless the library was built with -DC8_STATS=1) to host memory. */
-int cer_cost_lines_stats(unsigned long long* out, int reset);
 int cer_cost_lines_f32(const void* fmap1_split, const void* fmap2_split, const int* view_slot, const float* Pij, const float* disp_in,
                        float* vol, float* origin_out, void* workspace,
                        int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride,
@@ -188,13 +175,21 @@ int cer_corr_encode_f32(const float* feats, const float* w, const float* b, floa
 /* Same lookup on the folded (view-mean) volume fused with the first corr_encoder layer
  * (reference: core/update.py:103 mean, :61-62 Conv2d(33,64,1)+ReLU): out [P, Cout] NHWC.
  * w [Cin=L*(2r+1), Cout] (transposed 1x1 weight), b [Cout].  Cout == 64.
+ * Rows (both lookup entry points, round 5): row_stride >= the whole pyramid [level0 | level1 | ...] - the levels are read from the
+ *   row; D <= row_stride < the whole pyramid - the row holds LEVEL 0 ONLY and level l is formed on the fly as the pairwise means
+ *   ((a + b) * 0.5 level by level, core/corr.py:94-97) in the association cer_pyramid_f32 uses: bit-identical values, 43 % fewer
+ *   bytes read (RAFT.forward builds its folded volume that way: cer_cost_lines_reduce_f32 with fuse_levels = 1).
+ * delta_taps (may be NULL): the PREVIOUS GRU iteration's disparity update rides on this launch - core/update.py:114, core/raft.py:101:
+ *   disp[p] += 0.01 * (delta_bias + sum over delta_nhalf (1 or 2) x 9 tap planes T[half][tap][p + (ky-1, kx-1)], zero outside the
+ *   image), i.e. cer_delta_sum_f32 (same summation order: bit-identical), before the lookup of pixel p reads it; `disp` is then
+ *   updated IN PLACE (img_w must be given: rows of P / img_w pixels).  With NULL `disp` is only read.
  */
-int cer_lookup_encode_f32(const float* vol, const float* origin, const float* disp,
+int cer_lookup_encode_f32(const float* vol, const float* origin, float* disp,
                           const float* w, const float* b, float* out,
                           long P, int D, int row_stride, double incre, int num_levels, int radius, int Cout,
                           int out_split /* 0: fp32 [P, Cout]; 1: split32 layout (f16x3 convs); 2: frag16 layout of an image
                                            img_w pixels wide with scale 2^log2s_out (s16 convs) - both below */,
-                          int log2s_out, int img_w, void* stream);
+                          int log2s_out, int img_w, const float* delta_taps, int delta_nhalf, float delta_bias, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * 3x3, stride 1, zero-padded convolution as an implicit GEMM on exact-fp32 MFMA

@@ -291,11 +291,13 @@ def test_conv_s16_dynamic_range(dev):
 
 
 def test_conv_s16_producer_consumer_form_matches(dev):
-    """csrc/conv_s16pc.hip (opt-in: cer_conv3x3_s16_pc(1)) against the default kernels: z|r gates, GRU blend, ReLU conv and the fused
+    """csrc/experimental/conv_s16pc.hip (variants/libcermvs_optin.so only since round 5: cer_conv3x3_s16_pc(1)) against the default kernels: z|r gates, GRU blend, ReLU conv and the fused
     delta head on a size with rim tiles, partial last tiles and several tiles per persistent block; the two forms differ only in where
     the hoisted term is added (<= 2e-6 relative), and the producer / consumer form reproduces itself bit for bit over 100 launches."""
     from cer_mvs_amd import _lib as L, ops
     lib = L.load()
+    if not L.has_variant_forms():
+        pytest.skip("the producer / consumer form is not in the product library: run with CER_MVS_LIB=.../variants/libcermvs_optin.so (tools/r05/test_variants.sh)")
     h, w = 118, 150
     P = h * w
     U, R, Dp = L.S16_UNIT, L.S16_RELU, L.S16_DISP

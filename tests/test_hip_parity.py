@@ -177,6 +177,59 @@ def test_lookup_edge_cases(dev):
     assert rel_l1(out.cpu().view(1, -1, 1, P), ref) < 1e-5
 
 
+@pytest.mark.parametrize("D,L", [(64, 3), (44, 3), (20, 2), (40, 4), (64, 1)])
+def test_lookup_on_level0_rows_is_bit_identical(dev, D, L):
+    """Round 5: rows that hold level 0 only (row_stride < the whole pyramid) - both lookup kernels form the pooled levels on the fly, in
+    cer_pyramid_f32's association: bit for bit what they read from rows that store the levels (core/corr.py:94-97,102-143), incl. the
+    indices of test_lookup_edge_cases (below 0, beyond the row, integral) and a ragged P."""
+    from cer_mvs_amd import _lib as Lb, ops
+    h, w, r = 9, 21, 5
+    P, incre = h * w, 0.0025 / 320
+    _, _, rs = ops.row_layout(D, L)
+    _, _, rs0 = ops.row_layout(D, L, compact=True)
+    assert rs0 == (D + 3) // 4 * 4 and (rs0 < rs or L == 1)
+    full = torch.zeros(P, rs, device=dev)
+    full[:, :D] = hashed((P, D), 191, -30.0, 30.0).to(dev)
+    ops.pyramid(full, D, L, scale=0.1)
+    lvl0 = torch.zeros(P, rs0, device=dev)
+    lvl0[:, :D] = full[:, :D]
+    origin = hashed((P,), 192, 0.001, 0.002)
+    steps = hashed((P,), 193, -40.0, 90.0)
+    steps[0], steps[1], steps[2], steps[3] = -100.0, 1e6, 3.0, -22.0
+    disp = (origin + steps * incre).to(dev)
+    origin = origin.to(dev)
+    a = ops.corr_lookup(full, origin, disp, D, incre, L, r)
+    b = ops.corr_lookup(lvl0, origin, disp, D, incre, L, r)
+    assert torch.equal(a, b) and float(a.abs().sum()) > 0
+    K = L * (2 * r + 1)
+    w0t, b0 = hashed((K, 64), 194, -0.2, 0.2).to(dev), hashed((64,), 195, -0.1, 0.1).to(dev)
+    for kw in ({}, {"out_split": 2, "log2s": Lb.S16_RELU, "img_w": w}):
+        assert torch.equal(ops.lookup_encode(full, origin, disp, w0t, b0, D, incre, L, r, **kw),
+                           ops.lookup_encode(lvl0, origin, disp, w0t, b0, D, incre, L, r, **kw))
+
+
+@pytest.mark.parametrize("h,w,nhalf", [(9, 21, 2), (40, 150, 2), (7, 64, 1)])
+def test_lookup_applies_the_pending_disparity_update(dev, h, w, nhalf):
+    """Round 5: cer_lookup_encode_f32 with delta_taps = the previous iteration's cer_delta_sum_f32 (core/update.py:114, core/raft.py:101)
+    riding on the lookup launch: the disparity it leaves in place and the features it writes are bit for bit those of the two launches."""
+    from cer_mvs_amd import _lib as Lb, ops
+    P, D, L, r, incre = h * w, 64, 3, 5, 0.0025 / 64
+    _, _, rs0 = ops.row_layout(D, L, compact=True)
+    vol = hashed((P, rs0), 201, -30.0, 30.0).to(dev)
+    origin = hashed((P,), 202, 0.001, 0.002).to(dev)
+    disp0 = (origin.cpu() + hashed((P,), 203, -30.0, 40.0) * incre).to(dev)
+    T = hashed((nhalf, 9, P), 204, -0.02, 0.02).to(dev)
+    bias = 0.0123
+    w0t, b0 = hashed((L * (2 * r + 1), 64), 205, -0.2, 0.2).to(dev), hashed((64,), 206, -0.1, 0.1).to(dev)
+    d_ref, _ = ops.delta_sum(T, bias, disp0, h, w)
+    f_ref = ops.lookup_encode(vol, origin, d_ref, w0t, b0, D, incre, L, r, out_split=2, log2s=Lb.S16_RELU, img_w=w)
+    assert not torch.equal(d_ref, disp0)
+    for _ in range(3):
+        d = disp0.clone()
+        f = ops.lookup_encode(vol, origin, d, w0t, b0, D, incre, L, r, out_split=2, log2s=Lb.S16_RELU, img_w=w, delta=(T, bias))
+        assert torch.equal(d, d_ref) and torch.equal(f, f_ref)
+
+
 # ------------------------------------------------------------------------------------ conv kernels
 @pytest.mark.parametrize("mode", ["fp32", "f16x3"])
 @pytest.mark.parametrize("h,w,cout", [(8, 16, 64), (11, 21, 64), (9, 17, 128), (16, 32, 256), (5, 70, 128)])
@@ -296,6 +349,10 @@ def test_cost_lines_matches_walk(dev, D, stage0, geom, form):
     (round 4 experiment; the "zoom" geometry spreads the lines of a block too far apart for its window and goes through its hand-over list)."""
     from cer_mvs_amd import _lib as L, ops
     lib = L.load()
+    if form == 0 and not L.has_variant_forms():
+        return _cost_lines_matches_walk(dev, D, stage0, geom, lib)
+    if not L.has_variant_forms():
+        pytest.skip("the multi-line form is not in the product library: run with CER_MVS_LIB=.../variants/libcermvs_optin.so (tools/r05/test_variants.sh)")
     prev_form = lib.cer_cost_lines_form(form)
     try:
         _cost_lines_matches_walk(dev, D, stage0, geom, lib)
@@ -854,6 +911,32 @@ def test_end_to_end_ragged_sizes_match_oracle(dev, size, V):
         got = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale).cpu()
         ref = O.raft_forward({k: v.cpu() for k, v in sd.items()}, images, poses, intr, scale, cascade=cascade)
     assert got.shape == ref.shape == (1, 1, H // 4, W // 4)
+    assert rel_l1(got, ref) < TOL
+
+
+def test_non_default_feature_width_runs_on_the_general_kernels(dev):
+    """`dim_fmap` is a constructor argument of the reference's RAFT (core/raft.py:14-30).  The producer / consumer encoder
+    engine has a 64 -> 64 feature head only and the epipolar-line cost volume 64-channel operands only: a model with dim_fmap = 128 must
+    take the tiled engine's head (cer_enc_pc_supported is consulted) and the wave-per-pixel walk, and still match the oracle."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.encoder_hip import HipEncoder
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+    from oracle import cer_oracle as O
+    H, W, V = 72, 104, 2
+    cascade = [(64, 64, 2), (-1, 320, 2)]
+    images, poses, intr, scale = synthetic_scene(H, W, V, seed=27)
+    model = RAFT(cascade=cascade, dim_fmap=128, test_mode=True)
+    sd = fill_state_dict(model.state_dict(), seed=11)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    eng = HipEncoder(model.fnet, dev)
+    assert eng.pc_trunk and not eng.pc_head[1] and not eng.supports_split_head()
+    x = images[0].float() * (2 / 255.0) - 1
+    with torch.no_grad():
+        f = eng.forward_nchw(x.to(dev)).cpu()
+        assert rel_l1(f, O.encoder(x, sd, "fnet.", "instance")) < 1e-5
+        got = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale).cpu()
+        ref = O.raft_forward({k: v.cpu() for k, v in sd.items()}, images, poses, intr, scale, cascade=cascade)
     assert rel_l1(got, ref) < TOL
 
 

@@ -31,6 +31,24 @@ def test_library_exports_every_declared_symbol():
     assert lib.cer_abi_version() == _lib.ABI_VERSION
 
 
+def test_variant_only_entry_points_are_not_in_the_product_library():
+    """Round 5: the opt-in kernel forms of round 4 (measured slower) and their switches are declared in include/cer_mvs_variants.h and
+    exported by csrc/variants/libcermvs_optin.so only."""
+    from cer_mvs_amd import _lib
+    text = open(os.path.join(REPO, "include", "cer_mvs_variants.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    vsyms = sorted(set(re.findall(r"\b(cer_[a-z0-9_]+)\s*\(", text)))
+    assert vsyms == sorted(_lib._VARIANT_SIGNATURES)
+    product = ctypes.CDLL(os.path.join(REPO, "cer-mvs_amd", "csrc", "libcermvs.so"))
+    for s in vsyms:
+        assert not hasattr(product, s), f"{s} is a variant-only entry point but the product library exports it"
+    optin = os.path.join(REPO, "cer-mvs_amd", "csrc", "variants", "libcermvs_optin.so")
+    if os.path.exists(optin):
+        v = ctypes.CDLL(optin)
+        for s in vsyms + header_symbols():
+            assert hasattr(v, s), f"variants/libcermvs_optin.so does not export {s}"
+
+
 def test_argument_errors_without_device():
     from cer_mvs_amd import _lib
     lib = _lib.load()
@@ -53,8 +71,9 @@ def test_argument_errors_without_device():
     tiles = max(13 * ((296 + 32 + 15) // 16 * 16), 10 * ((400 + 32 + 15) // 16 * 16))
     assert lib.cer_cost_lines_workspace(10, 296, 400, 64) == 10 * 296 * 400 * 64 * 4 + 10 * 16 + 256 + 10 * (tiles + 1) * 8 + 64
     assert lib.cer_cost_lines_workspace(0, 1, 1, 1) == -1
-    prev = lib.cer_cost_lines_form(-1)
-    assert prev in (0, 1) and lib.cer_cost_lines_form(1) == prev and lib.cer_cost_lines_form(prev) == 1 and lib.cer_cost_lines_form(-1) == prev
+    if _lib.has_variant_forms():    # (variants/libcermvs_optin.so: the switch of round 4's multi-line form)
+        prev = lib.cer_cost_lines_form(-1)
+        assert prev in (0, 1) and lib.cer_cost_lines_form(1) == prev and lib.cer_cost_lines_form(prev) == 1 and lib.cer_cost_lines_form(-1) == prev
     args = (1, 4, 4, 4, 4, 64, 64, 112, dbl, 1)
     assert lib.cer_cost_lines_f32(null, null, null, null, null, null, null, null, *args, 1, 0, 0, 1.0, null) == -1
     assert lib.cer_cost_lines_f32(fake, fake, null, fake, fake, fake, fake, fake, *args, 0, 0, 0, 1.0, null) == -1      # mode 0: per-view volumes are the walk's
