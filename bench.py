@@ -220,6 +220,8 @@ def main():
             if S == 1:
                 for _ in range(args.warmup):
                     out = model(*inputs, scale=scale)
+                while model.gru_precision == "auto" and model._auto_pending():      # (the calibration forwards - RAFT.AUTO_INPUTS of them - stay out of the timed region)
+                    out = model(*inputs, scale=scale)
                 sync()
                 t0 = time.perf_counter()
                 for _ in range(args.steps):
@@ -232,6 +234,8 @@ def main():
                 from cer_mvs_amd.pipeline import DepthMapPipeline
                 pipe = DepthMapPipeline(model, streams=S)
                 for _ in range(max(args.warmup, S)):
+                    out = pipe.result(pipe.submit(*inputs, scale), wait_on_host=False)
+                while model.gru_precision == "auto" and any(m._auto_pending() for m in pipe.models):   # (calibration forwards + the replicas' adoption: untimed)
                     out = pipe.result(pipe.submit(*inputs, scale), wait_on_host=False)
                 sync()
                 out = model(*inputs, scale=scale)        # untimed: the caller's stream has its own allocator pool (first use = hipMalloc)
@@ -468,8 +472,10 @@ def main():
             "data": "synthetic",
             "gru_precision": {"requested": requested_precision, "timed": args.gru_precision,
                               **({"calibration_rel_l1_s16f8_vs_s16": model.auto_error, "tolerance": model.AUTO_TOL,
-                                  "note": "gru_precision='auto': the first forward of a set of weights runs in both split-f16 forms (inside the "
-                                          "warm-up); the fp8-correction form is kept only if the two agree within the tolerance"}
+                                  "calibration_inputs": model.AUTO_INPUTS,
+                                  "note": "gru_precision='auto': the first forwards of a set of weights (calibration_inputs of them, inside the "
+                                          "warm-up) run in both split-f16 forms; the fp8-correction form is kept only if the two agree within the "
+                                          "tolerance on every one of them (the figure is the worst)"}
                                  if requested_precision == "auto" else {})},
             "config": {"workload": args.workload, "image": f"{W}x{H}", "src_views": V, "cascade": cascade,
                        "gru_iters": sum(c[2] for c in cascade),

@@ -16,18 +16,48 @@ import torch
 
 
 class DepthMapPipeline:
-    def __init__(self, model, streams=3, device=None):
+    """``groups`` (round 5, sharded models - ``RAFT(view_group=...)``): one torch.distributed process group PER replica, all spanning the same
+    ranks (``[dist.new_group(ranks) for _ in range(streams)]``, created in the same order on every rank).  Depth map i then runs its
+    collectives - the feature all-gather / halo exchange of shard="slab", the volume all-reduce of shard="views" - on communicator
+    i mod streams: collectives of different depth maps never interleave on one communicator (on RCCL each group also has its own
+    internal stream, so they overlap), and every rank submits the same sequence, so per communicator the order is the same everywhere.
+    At G = 8 a slab conv covers 175-325 tiles on 512 block slots: that is where forwards in flight pay most."""
+
+    def __init__(self, model, streams=3, device=None, groups=None):
         if streams < 1:
             raise ValueError("DepthMapPipeline: streams must be >= 1")
         dev = device if device is not None else next(model.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("DepthMapPipeline: the model must live on a GPU (there is no CPU path)")
         self.device = dev
-        self.models = [model] + [copy.deepcopy(model) for _ in range(streams - 1)]
+        sharded = getattr(model, "view_group", None) is not None
+        if sharded and streams > 1:
+            if groups is None or len(groups) != streams:
+                raise ValueError("DepthMapPipeline: a sharded model (view_group) with several depth maps in flight needs `groups`: one process "
+                                 "group per replica (collectives of different depth maps must not share a communicator)")
+        elif groups is not None and not sharded:
+            raise ValueError("DepthMapPipeline: `groups` is for models built with a view_group")
+        self.models = [model]
+        for k in range(1, streams):
+            vg = getattr(model, "view_group", None)
+            if sharded:
+                model.view_group = None                    # (a ProcessGroup is not copyable: the replica gets its own below)
+                model.__dict__.pop("_slab_ex", None)       # (nor is the exchange object that holds one; it is rebuilt on the next forward)
+            try:
+                rep = copy.deepcopy(model)
+            finally:
+                if sharded:
+                    model.view_group = vg
+            if sharded:
+                rep.view_group = groups[k]
+            self.models.append(rep)
+        if sharded and groups is not None:
+            model.view_group = groups[0]
         for m in self.models:
             m.eval()
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(streams)]
         self._next = 0
+        self._closed = False
 
     def __len__(self):
         return len(self.streams)
@@ -42,6 +72,8 @@ class DepthMapPipeline:
     def submit(self, images, poses, intrinsics, scale, **kw):
         """Enqueue one test-mode forward on the next stream; returns a handle for ``result``.  The inputs must stay alive and
         unmodified until the result has been taken."""
+        if self._closed:
+            raise RuntimeError("DepthMapPipeline: submit() after close()")
         k = self._next % len(self.streams)
         self._next += 1
         st = self.streams[k]
@@ -102,6 +134,8 @@ class DepthMapPipeline:
         for st in self.streams:
             ops.release_lines_workspace(self.device, st)
         self.models = self.models[:1]
+        self.streams = self.streams[:1]                    # (len(pipe) and the stream list follow the models)
+        self._closed = True
 
     def __del__(self):
         try:

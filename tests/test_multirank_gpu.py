@@ -197,3 +197,56 @@ def test_two_process_forward_at_ragged_size(dev, tmp_path, shard, V):
     for r in range(world):
         got = torch.from_numpy(np.load(f"{out_path}.{r}.npy"))
         assert got.shape == ref.shape and rel_l1(got, ref) < 1e-5, (r, rel_l1(got, ref))
+
+
+def _worker_pipelined(rank, world, port, shard, name, out_path, streams):
+    import sys
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.pipeline import DepthMapPipeline
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    g = np.load(os.path.join(REPO, "tests", "golden", name + ".npz"))
+    H, W, V = int(g["H"]), int(g["W"]), int(g["V"])
+    cascade = [tuple(int(x) for x in c) for c in g["cascade"]]
+    images, poses, intr, scale = synthetic_scene(H, W, V, seed=int(g["scene_seed"]))
+    groups = [dist.new_group(ranks=list(range(world))) for _ in range(streams)]      # one communicator per depth map in flight
+    model = RAFT(cascade=cascade, test_mode=True, view_group=groups[0], shard=shard)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(g["weight_seed"])))
+    model = model.to(dev).eval()
+    try:
+        DepthMapPipeline(model, streams=streams)             # several in flight on ONE communicator: refused
+        raise AssertionError("a sharded pipeline without per-replica groups must be refused")
+    except ValueError:
+        pass
+    pipe = DepthMapPipeline(model, streams=streams, groups=groups)
+    assert [m.view_group for m in pipe.models] == groups
+    inputs = (images.to(dev), poses.to(dev), intr.to(dev))
+    with torch.no_grad():
+        handles = [pipe.submit(*inputs, scale) for _ in range(2 * streams + 1)]
+        outs = [pipe.result(h_).cpu().numpy() for h_ in handles]
+    torch.cuda.synchronize()
+    np.save(f"{out_path}.{rank}.npy", np.stack(outs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shard", ["slab", "views"])
+def test_two_process_pipelined_sharded_forward(dev, golden, tmp_path, shard):
+    """a SHARDED model with two depth maps in flight - pipeline.DepthMapPipeline(groups=...): one process group
+    (communicator) per replica, so collectives of different depth maps never interleave on one communicator.  Two real processes x
+    two streams, five forwards of the cfg1 capture's input: every result of every rank matches the reference capture."""
+    world, streams, name = 2, 2, "e2e_cfg1"
+    out_path = str(tmp_path / "disp")
+    mp.spawn(_worker_pipelined, args=(world, _free_port(), shard, name, out_path, streams), nprocs=world, join=True)
+    ref = torch.from_numpy(golden(name)["disp"])
+    for r in range(world):
+        outs = torch.from_numpy(np.load(f"{out_path}.{r}.npy"))
+        assert outs.shape[0] == 2 * streams + 1
+        for o in outs:
+            assert rel_l1(o, ref) < TOL

@@ -66,6 +66,54 @@ def scan(path):
         return len(cos), ninstr, hits
 
 
+SCANNER_VERSION = 2
+
+
+def sha256(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def sidecar_path(lib):
+    return lib + ".isa_scan.json"
+
+
+def write_sidecar(lib, ncos, n, hits):
+    """Record of a scan next to the library it scanned: a library that travels to a box without the toolchain (or is simply loaded
+    later) can be matched to a PASSED scan by its sha256 (verify_sidecar) - round 5, VERDICT r4 item 7(ii)."""
+    import json
+    rec = {"library": os.path.basename(lib), "sha256": sha256(lib), "code_objects": ncos, "packed_fp32_instructions": n,
+           "hazardous_forms": len(hits), "scanner_version": SCANNER_VERSION,
+           "form": "v_pk_{add,mul,fma,max,min}_f32 with the src1 bit of op_sel set (low result from src1's high half)"}
+    with open(sidecar_path(lib), "w") as f:
+        json.dump(rec, f, indent=1)
+    return rec
+
+
+def verify_sidecar(lib):
+    """True iff a scan record exists for exactly these bytes and it found nothing."""
+    import json
+    try:
+        with open(sidecar_path(lib)) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return False
+    return rec.get("sha256") == sha256(lib) and rec.get("hazardous_forms") == 0 and rec.get("scanner_version") == SCANNER_VERSION
+
+
+def have_objdump():
+    return os.path.exists(os.path.join(LLVM, "llvm-objdump"))
+
+
+def have_hipcc():
+    import shutil
+    return bool(shutil.which("hipcc")) or os.path.exists("/opt/rocm/bin/hipcc")
+
+
 def main(paths):
     bad = 0
     for p in paths:
