@@ -224,6 +224,8 @@ __global__ __launch_bounds__(512, 2) void enc_stem_pc_kernel(const float* __rest
         const float nsc = normalize ? (2.0f / 255.0f) * (float)(1 << SM_XLOG2) : (float)(1 << SM_XLOG2);
         const float nof = normalize ? -(float)(1 << SM_XLOG2) : 0.f;
         float4 px[2][3];
+        unsigned padbits = 0;                             // bit i: quad i of the requested patch is zero padding (a predicate of its own -
+                                                          // an in-band NaN marker would turn a real NaN in the image into padding instead of propagating it)
         auto request = [&](int k) {
             int n, t, ty, tx;
             work_tile(k, n, t, ty, tx);
@@ -237,10 +239,8 @@ __global__ __launch_bounds__(512, 2) void enc_stem_pc_kernel(const float* __rest
                 const bool ok = idx < ITEMS && iy >= 0 && iy < H && ix >= 0 && ix < W;     // (W % 4 == 0: a quad is inside or outside as a whole)
                 const float* p = im + (long)(ok ? iy : 0) * W + (ok ? ix : 0);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    px[i][c] = cer_ld4(p + c * plane);
-                    if (!ok) px[i][c] = make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);     // marker: the quad is zero padding (of the NORMALISED image)
-                }
+                for (int c = 0; c < 3; ++c) px[i][c] = cer_ld4(p + c * plane);
+                padbits = (padbits & ~(1u << i)) | ((ok ? 0u : 1u) << i);                   // the quad is zero padding (of the NORMALISED image)
             }
         };
         auto stage = [&](int k) {
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void enc_stem_pc_kernel(const float* __rest
             for (int i = 0; i < 2; ++i) {
                 const int idx = tid + 256 * i;
                 if (idx < ITEMS) {
-                    const bool pad = px[i][0].x != px[i][0].x;
+                    const bool pad = (padbits >> i) & 1u;
                     const float v[3][4] = {{px[i][0].x, px[i][0].y, px[i][0].z, px[i][0].w}, {px[i][1].x, px[i][1].y, px[i][1].z, px[i][1].w},
                                            {px[i][2].x, px[i][2].y, px[i][2].z, px[i][2].w}};
                     unsigned hw[8], lw[8];                                 // pixel j: words 2j (channels 0, 1), 2j + 1 (channel 2, zero)

@@ -111,7 +111,9 @@ def inference(test_loader, ckpt, output_folder, rescale=1, crop=None, do_report=
                 f.write(f"{np.quantile(im[im > 0], 0.1) / 2}\n")
 
     tic = [0.0]
-    with torch.no_grad():
+    n_flight = len(pipe)
+    try:
+      with torch.no_grad():
         for images, poses, intrinsics, image_names, scale in test_loader:
             poses = poses.cuda()
             images, intrinsics = scale_operation(images.squeeze(0), intrinsics.squeeze(0), rescale)
@@ -125,16 +127,16 @@ def inference(test_loader, ckpt, output_folder, rescale=1, crop=None, do_report=
             name = image_names[0][0] if isinstance(image_names[0], (list, tuple)) else image_names[0]
             nf = num_frames if num_frames is not None else getattr(getattr(test_loader, "dataset", None), "num_frames", images.shape[1])
             pending.append((pipe.submit(images, poses, intrinsics, scale, do_report=do_report), name, nf))
-            if len(pending) >= len(pipe):
+            if len(pending) >= n_flight:
                 finish(pending.pop(0))
         while pending:
             finish(pending.pop(0))
-    try:
-        pipe.check_overflow()                               # (reads the flag: covers the last forwards, whose snapshots nobody polled)
+      pipe.check_overflow()                                 # (reads the flag: covers the last forwards, whose snapshots nobody polled)
     except RuntimeError:
-        # the files of the last `streams` forwards were written before their flags could be read: remove them rather than leave
-        # saturated depth maps next to good ones
-        for path in written[-len(pipe):]:
+        # (ONE clean-up for both raise sites - the poll inside finish() and the final check.)  The files of the last
+        # `streams` forwards were written before their flags could be read: remove them rather than leave saturated depth maps next to
+        # good ones
+        for path in written[-n_flight:]:
             try:
                 Path(path).unlink()
             except OSError:

@@ -67,11 +67,16 @@ def main():
         wt = r(9, 256)
         run(lambda: ops.delta_tail(hid, wt, 0.1, disp, h, w, want_delta=False))
     elif args.what == "lookup":
-        vol = r(P, 112)
+        # the shipped form (round 5): level-0-only rows (64 floats), frag16 output for the s16 convolutions, the previous iteration's
+        # disparity update (18 tap-plane reads per pixel) riding on the launch; CER_PROF_LOOKUP_R04=1: round 4's form (112-float rows, no update)
+        r04 = __import__("os").environ.get("CER_PROF_LOOKUP_R04") == "1"
+        vol = r(P, 112 if r04 else 64)
         w0t, b0 = r(33, 64), r(64)
-        out = torch.empty(ops.s16_pixels(h, w), 64, device=dev)       # the shipped form: frag16 output for the s16 convolutions
+        out = torch.empty(ops.s16_pixels(h, w), 64, device=dev)
         org, dd = disp.clone(), disp + 0.0002 * torch.rand(P, device=dev)
-        run(lambda: ops.lookup_encode(vol, org, dd, w0t, b0, 64, 0.0025 / 64, 3, 5, out=out, out_split=2, log2s=L.S16_RELU, img_w=w))
+        T = 0.001 * r(2, 9, P)
+        run(lambda: ops.lookup_encode(vol, org, dd, w0t, b0, 64, 0.0025 / 64, 3, 5, out=out, out_split=2, log2s=L.S16_RELU, img_w=w,
+                                      delta=None if r04 else (T, 0.0)))
     elif args.what == "stem":
         import ctypes
         lib = L.load()
