@@ -2,15 +2,19 @@
 ``forward(images, poses, intrinsics, scale=None, do_report=False)``, same state_dict keys
 (fnet.*, cnet.*, update_block.*; a ``module.`` prefix from DataParallel checkpoints is accepted).
 
-Test-mode forward = encoders on PyTorch-ROCm, then per cascade stage one fused cost-volume build
-(view-mean folded) and T x 6 HIP kernels; see DESIGN.md for the data layout.  Differences from the
+Test-mode forward = both encoders on the channels-last HIP engine (encoder_hip.py: producer / consumer convolutions, csrc/enc_pc.hip;
+``encoder_backend="miopen"`` selects the PyTorch-ROCm modules), then per cascade stage one fused cost-volume build (view-mean folded,
+level-0 rows) and T x 5 HIP kernels (lookup incl. the previous iteration's disparity update, corr2, z|r, q, fused delta head); see
+DESIGN.md for the data layout.  Differences from the
 reference that a caller can observe, all deliberate (SURVEY.md §8(a) "quirks"):
   * `images` and `poses` are NOT mutated in place (reference: raft.py:35,40-41);
   * `scale` may be a float or a tensor on any device (reference: raft.py:108 calls scale.cuda());
   * computation is fp32 end to end by default (``precision="fp32"``); the reference's GPU path runs
     encoders + GRU under fp16 autocast (raft.py:9,55), selectable with ``precision="amp"`` for the
-    encoders only.  ``gru_precision`` picks the arithmetic of the update block's 3x3 convolutions:
-    "s16f8" (default: split-f16 operands, x*w = xh*wh + (xh*wl + xl*wh) into one fp32 accumulator with the main term on the f16
+    encoders only.  ``gru_precision`` picks the arithmetic of the update block's 3x3 convolutions: "auto" (default: the first
+    AUTO_INPUTS forwards of a set of weights run in both split-f16 forms and "s16f8" is kept only if it stays within AUTO_TOL of
+    "s16" on every one of them - see __init__),
+    "s16f8" (split-f16 operands, x*w = xh*wh + (xh*wl + xl*wh) into one fp32 accumulator with the main term on the f16
     matrix instruction and the two 2^-11 correction terms on the block-scaled fp8 one - 4e-6 relative L1 from fp32 end to end,
     csrc/conv_s16.hip), "s16" (all three terms in f16: fp32-class, 2e-7), "f16x3" (round-1 kernels: two fp32 accumulators) or
     "fp32" (exact v_mfma_f32_16x16x4_f32).
@@ -130,7 +134,7 @@ class RAFT(nn.Module):
             out.append((nIncre, 0.0025 / incre, nIters))
         return out
 
-    # ---------------------------------------------------------------- encoders (PyTorch-ROCm)
+    # ---------------------------------------------------------------- encoders (HIP engine by default; encoder_backend="miopen": PyTorch-ROCm)
     def _apply(self, fn, *a, **k):
         self._engines = None            # weights moved / cast: repack on next use
         return super()._apply(fn, *a, **k)
