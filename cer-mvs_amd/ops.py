@@ -543,8 +543,9 @@ def s16_layout(x, h, w, layout, log2s=0, inverse=False, out=None):
     cer_mvs.h) as a [s16_pixels(h, w), C] tensor, or back (``inverse``)."""
     C = x.shape[1]
     if out is None:
-        out = torch.zeros(s16_pixels(h, w), C, device=x.device, dtype=torch.float32) if not inverse else \
-            torch.empty(h * w, C, device=x.device, dtype=torch.float32)
+        # (the padding pixels of the m-tile-major layouts must be zero; when the image is whole m-tiles - 296 x 400 - there are none to clear)
+        alloc = torch.empty if (inverse or s16_pixels(h, w) == h * w) else torch.zeros
+        out = alloc(h * w if inverse else s16_pixels(h, w), C, device=x.device, dtype=torch.float32)
     if x.shape[0] != (s16_pixels(h, w) if inverse else h * w):
         raise ValueError(f"s16_layout: {tuple(x.shape)} does not match a {h}x{w} image")
     L.check(L.load().cer_s16_layout_f32(L.dev_ptr(x, "src"), L.dev_ptr(out, "dst"), h, w, C, int(layout), int(log2s), int(bool(inverse)),
@@ -650,10 +651,11 @@ def conv3x3_s16(pc, srcs, h, w, epi, out=None, out2=None, aux=None, aux2=None, i
         aux, log2s_aux = aux
         if out is None:
             out = torch.empty(pc.cout // 128, 9, P, device=dev, dtype=torch.float32)
+    alloc = torch.empty if PP == P else torch.zeros         # (padding pixels of the m-tile-major layouts stay zero; whole-m-tile images have none)
     if out is None:
-        out = torch.zeros(PP, oc, device=dev, dtype=torch.float32)
+        out = alloc(PP, oc, device=dev, dtype=torch.float32)
     if epi == L.EPI_GATES and out2 is None:
-        out2 = torch.zeros(PP, oc, device=dev, dtype=torch.float32)
+        out2 = alloc(PP, oc, device=dev, dtype=torch.float32)
     for name, t in (("out", out), ("out2", out2), ("aux", aux if epi != L.EPI_DELTA else None), ("aux2", aux2), ("init", init)):
         if t is not None and epi != L.EPI_DELTA and t.shape[0] != PP:
             raise ValueError(f"conv3x3_s16: {name} must have {PP} (padded) pixel rows, got {tuple(t.shape)}")
