@@ -129,6 +129,7 @@ struct LkDelta {
     float* disp_rw;        // the disparity, updated in place
     int nhalf, h;
     float bias;
+    int* flag;             // sticky overflow flag of the device (cer_overflow_flag) or null: bit 4 = a frag16 output value had to be clamped
 };
 // MAXPRE: float4 registers of the next tile's rows per thread (4: level-0-only rows up to 64 floats - the model's since round 5; 8: rows up to
 // 128 floats - the stored pyramid's 112; 16: any row the entry point accepts)
@@ -242,6 +243,12 @@ __global__ __launch_bounds__(256, MAXPRE <= 4 ? LK_OCC4 : MAXPRE <= 8 ? 4 : 3) v
             const unsigned y = p / (unsigned)img_w, x = p - y * (unsigned)img_w;
             const long mt = (long)(y >> 1) * ((img_w + 15) >> 4) + (x >> 4);
             char* dst = reinterpret_cast<char*>(out) + ((mt * 4 + grp) * 2) * 1024 + (((y & 1) << 4) | (x & 15)) * 16;
+            // saturation is never silent: the largest value of this thread's 16 outputs is checked against the clamp here -
+            // round 5: the tensor's buffer is reused for r * h later in the iteration, so nothing can scan it after the fact
+            float amax = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) amax = fmaxf(amax, acc[j]);
+            if (dl.flag && __ballot(!(amax * out_scale <= 65504.0f)) != 0ull && (threadIdx.x & 63) == 0) atomicOr(dl.flag, 4);
 #pragma unroll
             for (int j = 0; j < 16; j += 8) {
                 cer_h2 h[4], l[4];
@@ -335,6 +342,7 @@ extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, floa
     }
     LkDelta dl;
     dl.T = delta_taps; dl.disp_rw = disp; dl.nhalf = delta_nhalf; dl.h = delta_taps ? (int)(P / img_w) : 0; dl.bias = delta_bias;
+    dl.flag = out_split == 2 ? cer_overflow_flag_get() : nullptr;
     const int pre = row_stride <= 64 ? 4 : row_stride <= 128 ? 8 : LK_MAX_PRE;      // prefetch registers per thread: which instantiation
     const int by_regs = pre == 4 ? LK_OCC4 : pre == 8 ? 4 : 3;
     const int by_lds = (int)((160 * 1024) / (smem + 256));

@@ -19,6 +19,7 @@ from . import ops
 
 
 USE_PLANS = True         # replay recorded launches for GRU iterations 2..T (False: every iteration through the checked wrappers)
+ALIAS_RN_C1 = __import__("os").environ.get("CER_ALIAS_RN_C1", "1") == "1"      # (A/B switch, see UpdateBlock.workspace)
 
 
 class ConvGRU(nn.Module):
@@ -289,7 +290,7 @@ class UpdateBlock(nn.Module):
         if self.conv_mode == "s16" and iters > 0 and self.CHECK_OVERFLOW:
             # the s16 layouts clamp ReLU-class activations beyond 4094 (65504 / 2^4): saturation must not be silent - scan what the
             # last iteration left in memory (2 x ~8 us; the delta head's hidden map is checked inside its kernel)
-            ops.scan_overflow(ws["c1"])
+            # (c1 is checked by the lookup kernel itself since round 5: its buffer holds r * h by now - ALIAS_RN_C1)
             ops.scan_overflow(ws["c2"])
 
     def workspace(self, h, w, device):
@@ -305,6 +306,11 @@ class UpdateBlock(nn.Module):
                     cache.pop(next(iter(cache)))
                 z = lambda c: torch.zeros(ops.s16_pixels(h, w), c, device=device, dtype=torch.float32)
                 cache[key] = {"c1": z(64), "c2": z(64), "z": z(64), "rn": z(64), "T": torch.empty(2, 9, P, device=device, dtype=torch.float32)}
+                if ALIAS_RN_C1:
+                    # r*h is written by the z|r launch, after the only reader of c1 (the corr2 launch) has run, and read by the q launch,
+                    # before the next lookup writes c1 again: the two tensors can share their 30 MB (round 5: the iteration's working set
+                    # - 283 MB at 296 x 400 - sits just above the 256 MB Infinity Cache)
+                    cache[key]["rn"] = cache[key]["c1"]
             return cache[key]
         e = lambda c: torch.empty(P, c, device=device, dtype=torch.float32)
         return {"c1": e(64), "c2": e(64), "z": e(64), "rn": e(64), "hid": e(256),

@@ -208,6 +208,27 @@ def test_lookup_on_level0_rows_is_bit_identical(dev, D, L):
                            ops.lookup_encode(lvl0, origin, disp, w0t, b0, D, incre, L, r, **kw))
 
 
+def test_lookup_flags_a_saturated_output_itself(dev):
+    """Round 5: the lookup's frag16 output (c1, ReLU class: 65504 / 2^4 = 4094) shares its buffer with r * h later in the iteration, so
+    it cannot be scanned after the fact any more - the kernel checks what it clamps: a clean launch leaves the flag alone, one output
+    beyond the limit raises bit 4 (saturation is never silent)."""
+    from cer_mvs_amd import _lib as Lb, ops
+    h, w, D, L, r = 9, 21, 64, 3, 5
+    P, incre = h * w, 0.0025 / 64
+    vol = hashed((P, 64), 211, -30.0, 30.0).to(dev)
+    origin = torch.full((P,), 0.00125, device=dev)
+    disp = hashed((P,), 212, 0.0, 60 * incre).to(dev)
+    w0t, b0 = hashed((33, 64), 213, -0.2, 0.2).to(dev), hashed((64,), 214, -0.1, 0.1).to(dev)
+    ops.check_overflow(dev)
+    ops.lookup_encode(vol, origin, disp, w0t, b0, D, incre, L, r, out_split=2, log2s=Lb.S16_RELU, img_w=w)
+    assert ops.check_overflow(dev) == 0
+    b_hot = b0.clone()
+    b_hot[17] = 5000.0                                         # one output channel beyond 4094 at every pixel
+    ops.lookup_encode(vol, origin, disp, w0t, b_hot, D, incre, L, r, out_split=2, log2s=Lb.S16_RELU, img_w=w)
+    assert ops.check_overflow(dev) & 4
+    assert ops.check_overflow(dev) == 0                         # (reading clears it)
+
+
 @pytest.mark.parametrize("h,w,nhalf", [(9, 21, 2), (40, 150, 2), (7, 64, 1)])
 def test_lookup_applies_the_pending_disparity_update(dev, h, w, nhalf):
     """Round 5: cer_lookup_encode_f32 with delta_taps = the previous iteration's cer_delta_sum_f32 (core/update.py:114, core/raft.py:101)
