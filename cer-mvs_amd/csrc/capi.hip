@@ -39,3 +39,18 @@ extern "C" int cer_overflow_flag(int* flag) {
     g_overflow_flag[dev] = flag;
     return CER_OK;
 }
+
+// ---- number of CUs of the current device (cached): what persistent grids and tile-height choices are sized for
+#include <atomic>
+int cer_num_cus() {
+    static std::atomic<int> dev_cus[CER_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CER_MAX_DEVICES) dev = 0;
+    int n = dev_cus[dev].load();
+    if (n == 0) {
+        int v = 0;
+        n = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        dev_cus[dev].store(n);
+    }
+    return n;
+}

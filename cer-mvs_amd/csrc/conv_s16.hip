@@ -1201,16 +1201,7 @@ static int sx_launch(S16Args& a, int epi, hipStream_t st) {
     return CER_OK;
 }
 
-static int sx_num_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
+static int sx_num_cus() { return cer_num_cus(); }
 
 extern "C" int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, const void* packed_w, const void* packed_collapsed,
                                const void* edge_w, int log2S, const float* bias, const float* init, float* out, float* out2, const float* aux, const float* aux2, int h,

@@ -596,11 +596,9 @@ static int pc_launch(PcArgs a, int nimg, hipStream_t st) {
     const long total = (long)a.nblk * nimg;
     if (total >= (1L << 31)) return CER_ESHAPE;
     a.total_tiles = (int)total;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const int cus = cer_num_cus();                         // (persistent: one block per CU the launch may count on)
     const unsigned grid = (unsigned)(total < cus ? total : cus);
     const bool dual = a.srcB != nullptr;
     const void* fn = dual ? (const void*)enc_pc_kernel<CIN, COUT, STRIDE, TAPS, EPI, true> : (const void*)enc_pc_kernel<CIN, COUT, STRIDE, TAPS, EPI, false>;

@@ -434,13 +434,7 @@ extern "C" int cer_enc_stem_s16(const float* images, const void* packed_w, const
     const long per_img = (long)cer_enc_stem_s16_tiles(ho, wo);
     const long total = per_img * N;
     if (total >= (1L << 31)) return CER_ESHAPE;
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
+    const int ncu = cer_num_cus();
     if (W % 4 == 0 && cer_aligned16(images) && !getenv("CER_STEM_TILED")) {       // producer / consumer form: 16-byte image loads
         int dev = 0;
         (void)hipGetDevice(&dev);

@@ -333,13 +333,7 @@ extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, floa
     const long ntiles = (P + LK_PIX - 1) / LK_PIX;
     if (ntiles >= (1L << 30)) return CER_ESHAPE;
     const size_t smem = sizeof(float) * LK_PIX * ((size_t)lk_pitch(row_stride) + (K | 1) + 1);
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
+    const int ncu = cer_num_cus();
     LkDelta dl;
     dl.T = delta_taps; dl.disp_rw = disp; dl.nhalf = delta_nhalf; dl.h = delta_taps ? (int)(P / img_w) : 0; dl.bias = delta_bias;
     dl.flag = out_split == 2 ? cer_overflow_flag_get() : nullptr;
