@@ -34,6 +34,7 @@
 // (4e-8 relative L1 on the bench scene).  Measured, what shaped it and what is left: DESIGN.md section 3e.
 #include "common.hpp"
 #include <atomic>
+#include <string.h>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -161,6 +162,38 @@ __device__ __noinline__ float cl_direct(const _Float16* __restrict__ f1t, long p
     return d[0] * (wn0 * wm0) + d[1] * (wn0 * wm1) + d[2] * (wn1 * wm0) + d[3] * (wn1 * wm1);
 }
 
+// ---- cycle statistics of the one-line kernel (variant build -DCL_STATS=1: tools/r05/mkvariant.sh clstats cost_lines.hip -DCL_STATS=1;
+// tools/r05/stats_cost_lines1.py).  Wave 0's view of a tile's phases, summed over all tiles with atomics.
+#ifndef CL_STATS
+#define CL_STATS 0
+#endif
+#if CL_STATS
+#define CL_SLOTS 4096
+__device__ unsigned long long cl_stats[CL_SLOTS][16];      // hashed by block: no contention on the counters; the host sums the slots
+#define CL_CLK() __builtin_readcyclecounter()
+// (durations are collected in registers of thread 0 and added ONCE per tile, behind its last store: atomics inside the chunk loop would sit in
+// the same vmcnt queue as the fragment loads)
+#define CL_STAT(i_, v_) do { if (threadIdx.x == 0) cl_acc[i_] += (unsigned long long)(v_); } while (0)
+#define CL_FLUSH() do { if (threadIdx.x == 0) for (int q_ = 0; q_ < 16; ++q_) if (cl_acc[q_]) atomicAdd(&cl_stats[blockIdx.x & (CL_SLOTS - 1)][q_], cl_acc[q_]); } while (0)
+extern "C" int cer_cost_lines1_stats(unsigned long long* out, int reset) {
+    if (!out) return CER_EINVAL;
+    static unsigned long long hostbuf[CL_SLOTS][16];
+    hipError_t e = hipMemcpyFromSymbol(hostbuf, HIP_SYMBOL(cl_stats), sizeof(hostbuf));
+    if (e != hipSuccess) return (int)e;
+    for (int q = 0; q < 16; ++q) { out[q] = 0; for (int sl = 0; sl < CL_SLOTS; ++sl) out[q] += hostbuf[sl][q]; }
+    if (reset) {
+        memset(hostbuf, 0, sizeof(hostbuf));
+        e = hipMemcpyToSymbol(HIP_SYMBOL(cl_stats), hostbuf, sizeof(hostbuf));
+        if (e != hipSuccess) return (int)e;
+    }
+    return CER_OK;
+}
+#else
+#define CL_CLK() 0ull
+#define CL_STAT(i_, v_) do { } while (0)
+#define CL_FLUSH() do { } while (0)
+#endif
+
 struct ClArgs {
     const _Float16* f1s;      // [8 planes][P][16]   reference map of this call's pixel grid (cer_feat_split_f16 layout)
     const _Float16* f2s;      // [V][8 planes][(h2+4)*(w2+4)][16]   zero border included
@@ -190,6 +223,10 @@ __device__ __forceinline__ void cl_tile(const ClArgs& A, const int v, const int 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kg = lane >> 5;
     const int h1 = A.h1, w1 = A.w1, h2 = A.h2, w2 = A.w2, D = A.D;
+    const unsigned long long cl_t0 = CL_CLK();
+#if CL_STATS
+    unsigned long long cl_acc[16] = {0};
+#endif
     const int axis = (int)A.params[v * 4 + 0];
     const float shear = A.params[v * 4 + 1];
     const int La = axis ? h1 : w1, Hm = axis ? w1 : h1;     // extent along / across the tile axis
@@ -318,6 +355,8 @@ __device__ __forceinline__ void cl_tile(const ClArgs& A, const int v, const int 
     }
     }
     __syncthreads();
+    const unsigned long long cl_t1 = CL_CLK();
+    CL_STAT(0, 1); CL_STAT(3, cl_t1 - cl_t0);
     smaj = bandI[0]; nchunks = bandI[1]; R = bandI[2]; Wc = bandI[3]; cmin = bandI[4]; cmax = bandI[5]; dir = bandI[6];
     bm = bandF[0]; bl0 = bandF[1];
     smaj = __builtin_amdgcn_readfirstlane(smaj);
@@ -375,6 +414,8 @@ __device__ __forceinline__ void cl_tile(const ClArgs& A, const int v, const int 
         *reinterpret_cast<float4*>(desc + (k * CL_DP + li) * 4) = make_float4(__uint_as_float(packed), smaj ? dw : du, smaj ? du : dw, 0.f);
     }
 
+    const unsigned long long cl_t2 = CL_CLK();
+    CL_STAT(4, cl_t2 - cl_t1);
     // ---- per-lane sample cursor
     int k = valid ? k0 : D;
     unsigned pk = 3u << 30;                                 // kind 3: done
@@ -395,6 +436,7 @@ __device__ __forceinline__ void cl_tile(const ClArgs& A, const int v, const int 
 
     for (int n = 0; n < nchunks; ++n) {
         const int cb = cb0 + n * cstep;
+        const unsigned long long cl_ta = CL_CLK();
         // ---- dots of this wave's 32 texels with the 32 pixels: 12 MFMAs
         floatx16 acc0;
 #pragma unroll
@@ -412,7 +454,9 @@ __device__ __forceinline__ void cl_tile(const ClArgs& A, const int v, const int 
             const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
             prod[row * 32 + li] = acc0[r];
         }
+        const unsigned long long cl_tb = CL_CLK();
         __syncthreads();
+        const unsigned long long cl_tc = CL_CLK();
         // ---- gather: every lane consumes its samples whose cell lies in this chunk; zeros and direct-path samples as they come
         const int cbe = cb + Wc - 2, cbR = (cb - 4) * R;    // last cell column of the chunk; band index of (column c, row r) = c R + r - cb R
         for (;;) {
@@ -447,8 +491,11 @@ __device__ __forceinline__ void cl_tile(const ClArgs& A, const int v, const int 
                 load_sample();
             }
         }
+        const unsigned long long cl_td = CL_CLK();
         __syncthreads();
+        CL_STAT(1, 1); CL_STAT(5, cl_tb - cl_ta); CL_STAT(6, cl_tc - cl_tb); CL_STAT(7, cl_td - cl_tc); CL_STAT(8, CL_CLK() - cl_td);
     }
+    const unsigned long long cl_t3 = CL_CLK();
     // ---- what the chunks did not cover (no band, samples out of order): direct path
     while (__ballot((pk >> 30) != 3u) != 0ull) {
         if ((pk >> 30) != 3u) {
@@ -467,12 +514,16 @@ __device__ __forceinline__ void cl_tile(const ClArgs& A, const int v, const int 
         }
     }
     __syncthreads();
+    const unsigned long long cl_t4 = CL_CLK();
+    CL_STAT(9, cl_t4 - cl_t3);
     // ---- rows out: wave w writes pixel slots w, w + 4, ...; lane = hypothesis (one coalesced D-float row per store)
     float* pv = A.part + (long)v * ((long)h1 * w1) * D;
     for (int i = wave; i < 32; i += 4) {
         const int p = pidx[i];
         if (p >= 0 && lane < D) pv[(long)p * D + lane] = desc[(lane * CL_DP + i) * 4 + 3];
     }
+    CL_STAT(10, CL_CLK() - cl_t4); CL_STAT(2, CL_CLK() - cl_t0);
+    CL_FLUSH();
 }
 
 // XCD-aware order (blocks are dealt round-robin over the 8 XCDs): each XCD gets a contiguous range of (view, segment, line):
