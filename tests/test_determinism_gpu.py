@@ -120,6 +120,19 @@ def test_lookup_and_cost_volume_are_deterministic(dev):
         d1 = torch.full((h * w,), 0.0012, device=dev)
         look = lambda: ops.lookup_encode(vol, origin, d1, pk["w0t"], pk["b0"], D, incre, ub.num_levels, ub.radius, out_split=2, log2s=L.S16_RELU, img_w=w)
         assert _repeat(look) == 0
+        # round 5: the forms RAFT.forward runs - level-0-only rows (pooled levels formed in LDS) and the previous iteration's disparity update
+        # riding on the launch (wave 3 publishes the new disparities to the block through LDS: a new happens-before edge, csrc/lookup.hip)
+        build_c = lambda: ops.cost_build(f1, f2, Pij, disp, D, incre, True, h, w, 3, fold=True, pyramid_scale=1.0 / V, split=split, compact=True)
+        assert _repeat(build_c) == 0
+        volc, _ = build_c()
+        assert torch.equal(volc[:, :D], vol[:, :D])
+        T = hashed((2, 9, h * w), 941, -0.02, 0.02).to(dev)
+
+        def look5():
+            d = d1.clone()
+            return d, ops.lookup_encode(volc, origin, d, pk["w0t"], pk["b0"], D, incre, ub.num_levels, ub.radius, out_split=2, log2s=L.S16_RELU, img_w=w,
+                                        delta=(T, 0.003))
+        assert _repeat(look5) == 0
     assert not ops.check_overflow(dev)
 
 
