@@ -167,6 +167,7 @@ __device__ __noinline__ float cl_direct(const _Float16* __restrict__ f1t, long p
 #ifndef CL_STATS
 #define CL_STATS 0
 #endif
+
 #if CL_STATS
 #define CL_SLOTS 4096
 __device__ unsigned long long cl_stats[CL_SLOTS][16];      // hashed by block: no contention on the counters; the host sums the slots
@@ -699,7 +700,7 @@ extern "C" int cer_cost_lines_views_f32(const void* fmap1_split, const void* fma
         return CER_OK;
     }
 #endif
-    hipLaunchKernelGGL(cost_lines_kernel<3>, dim3((unsigned)nblk), dim3(256), dyn, st, a);      // (<4>: 128 VGPRs with 6 spilled - measured slower at D = 44)
+    hipLaunchKernelGGL(cost_lines_kernel<3>, dim3((unsigned)nblk), dim3(256), dyn, st, a);      // (<4> at D <= 44: 128 VGPRs with 16 spilled dwords - 895 against 795 us, re-measured in round 5)
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }
