@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CER_MVS_LIB") or os.path.join(_HERE, "csrc", "libcermvs.so")
-ABI_VERSION = 1050
+ABI_VERSION = 1060
 CONV_MAX_SRC = 4
 EPI_LINEAR, EPI_RELU, EPI_GATES, EPI_GRU, EPI_DELTA = 0, 1, 2, 3, 4
 EPI_OUT_SPLIT, EPI_AUX_SPLIT = 0x100, 0x200       # cer_mvs.h: split32 activation layout flags, or-ed into `epi`
@@ -56,9 +56,9 @@ _SIGNATURES = {
     "cer_cost_lines_reduce_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _D, _I, _I, _I, _F, _P]),
     "cer_cost_lines_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _D, _I, _I, _I, _I, _F, _P]),
     "cer_pyramid_f32": (_I, [_P, _L, _I, _I, _I, _F, _P]),
-    "cer_corr_lookup_f32": (_I, [_P, _P, _P, _L, _P, _I, _L, _I, _I, _D, _I, _I, _P]),
+    "cer_corr_lookup_f32": (_I, [_P, _P, _P, _L, _P, _I, _L, _I, _I, _D, _I, _I, _I, _P]),
     "cer_corr_encode_f32": (_I, [_P, _P, _P, _P, _I, _I, _L, _I, _P]),
-    "cer_lookup_encode_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _D, _I, _I, _I, _I, _I, _I, _P, _I, _F, _P]),
+    "cer_lookup_encode_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _D, _I, _I, _I, _I, _I, _I, _P, _I, _F, _I, _P]),
     "cer_conv3x3_packed_size": (_L, [_I, _I]),
     "cer_conv3x3_pack_f32": (_I, [_P, _P, _I, _I, _c.POINTER(_I), _c.POINTER(_I), _I]),
     "cer_conv3x3_f32": (_I, [_c.POINTER(ConvInputs), _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

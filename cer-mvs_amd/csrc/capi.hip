@@ -1,7 +1,8 @@
 // Library-level entry points of libcermvs.so (include/cer_mvs.h).
 #include "common.hpp"
+#include <string.h>
 
-extern "C" int cer_abi_version(void) { return 1050; }
+extern "C" int cer_abi_version(void) { return 1060; }
 
 extern "C" const char* cer_error_string(int code) {
     switch (code) {
@@ -51,6 +52,23 @@ int cer_num_cus() {
         int v = 0;
         n = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
         dev_cus[dev].store(n);
+    }
+    return n;
+}
+
+// ---- LDS bytes per CU of the current device (cached): residency estimates of the persistent grids (160 KiB on gfx950)
+int cer_lds_per_cu() {
+    static std::atomic<int> dev_lds[CER_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CER_MAX_DEVICES) dev = 0;
+    int n = dev_lds[dev].load();
+    if (n == 0) {
+        int v = 0;
+        n = (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) == hipSuccess && v > 0) ? v : 64 * 1024;
+        // (some ROCm releases report the per-workgroup limit here: a gfx950 CU has 160 KiB whatever the attribute says)
+        hipDeviceProp_t prop;
+        if (n < 160 * 1024 && hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) n = 160 * 1024;
+        dev_lds[dev].store(n);
     }
     return n;
 }

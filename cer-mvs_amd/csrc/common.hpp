@@ -55,6 +55,8 @@ __device__ __forceinline__ void cer_split8(const float (&v)[8], cer_h8& hi, cer_
 int* cer_overflow_flag_get();
 // CUs of the current device (capi.hip; cached per device)
 int cer_num_cus();
+// LDS bytes per CU of the current device (capi.hip; cached per device)
+int cer_lds_per_cu();
 
 static inline bool cer_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

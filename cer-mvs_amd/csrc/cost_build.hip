@@ -141,8 +141,9 @@ __global__ __launch_bounds__(256) void cost_build_kernel(const float* __restrict
                 acc[i] = keep + __shfl_xor(send, hb);
             }
         }
-        if (levels > 1) {
-            // fused pyramid (host guarantees SUM, !accumulate, D <= 64): level 0 = view sum * scale, then avg-pool pairs
+        if (levels >= 1) {
+            // fused epilogue (host guarantees SUM, !accumulate, D <= 64): level 0 = view sum * scale (levels == 1: that is all - the
+            // compact rows of round 5, same meaning as in cer_cost_lines_reduce_f32), then avg-pool pairs
             // (core/corr.py:94-97) with one exchange per level: element j of level l lives on lane j << l
             float cur = acc[0] * scale;
             if (lane < nk) orow[lane] = cur;
@@ -194,7 +195,7 @@ extern "C" int cer_cost_build_f32(const float* fmap1, const float* fmap2, const 
                                   float* origin_out, int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride, double incre,
                                   int shift, int mode, int y0, int fuse_levels, float fuse_scale, void* stream) {
     if (!fmap1 || !fmap2 || !Pij || !disp_in || !vol) return CER_EINVAL;
-    if (fuse_levels > 1) {                                 // fused pyramid: view-sum fold of a single 64-hypothesis block only
+    if (fuse_levels >= 1) {                                // fused epilogue (1: scale only): view-sum fold of a single 64-hypothesis block only
         if (mode != 1 || D > 64) return CER_EINVAL;
         int need = 0, n = D;
         for (int l = 0; l < fuse_levels; ++l) { need += n; n /= 2; }

@@ -285,9 +285,12 @@ __global__ __launch_bounds__(256, MAXPRE <= 4 ? LK_OCC4 : MAXPRE <= 8 ? 4 : 3) v
     }
 }
 
-static int level_info(int D, int rs, int L, int r, LevelInfo* li) {
+// level0_only (round 6, ADVICE r5: explicit, no longer inferred from the stride): the rows hold level 0 only and the pooled levels are formed
+// on the fly (lk_elem: at most 4 levels); otherwise the rows hold the whole pyramid [level0 | level1 | ...] and must be long enough for it
+static int level_info(int D, int rs, int L, int r, int level0_only, LevelInfo* li) {
     if (L <= 0 || L > 8 || r < 0 || r > 15 || L * (2 * r + 1) > LK_MAX_TAPS) return CER_ESHAPE;
-    if (rs % 4 != 0 || rs > LK_MAX_ROW) return CER_ESHAPE;
+    if (rs % 4 != 0 || rs > LK_MAX_ROW || rs < D) return CER_ESHAPE;
+    if (level0_only != 0 && level0_only != 1) return CER_EINVAL;
     int off = 0, n = D;
     for (int l = 0; l < L; ++l) {
         li->off[l] = off;
@@ -295,21 +298,17 @@ static int level_info(int D, int rs, int L, int r, LevelInfo* li) {
         off += n;
         n /= 2;
     }
-    // rows shorter than the whole pyramid hold level 0 only (round 5): the pooled levels are formed on the fly
-    li->pool = 0;
-    if (off > rs) {
-        if (rs < D) return CER_ESHAPE;
-        li->pool = 1;
-    }
+    li->pool = level0_only;
+    if (level0_only ? L > 4 : off > rs) return CER_ESHAPE;
     return CER_OK;
 }
 
 extern "C" int cer_corr_lookup_f32(const float* vol, const float* origin, const float* disp, long disp_view_stride, float* out, int nv,
-                                   long P, int D, int row_stride, double incre, int num_levels, int radius, void* stream) {
+                                   long P, int D, int row_stride, double incre, int num_levels, int radius, int level0_only, void* stream) {
     if (!vol || !origin || !disp || !out || nv <= 0 || P <= 0 || D <= 0) return CER_EINVAL;
     if (!cer_aligned16(vol)) return CER_EALIGN;
     LevelInfo li;
-    int rc = level_info(D, row_stride, num_levels, radius, &li);
+    int rc = level_info(D, row_stride, num_levels, radius, level0_only, &li);
     if (rc) return rc;
     hipLaunchKernelGGL(lookup_kernel, dim3((unsigned)((P + LK_PIX - 1) / LK_PIX), (unsigned)nv), dim3(256),
                        sizeof(float) * LK_PIX * lk_pitch(row_stride), (hipStream_t)stream, vol, origin,
@@ -320,14 +319,14 @@ extern "C" int cer_corr_lookup_f32(const float* vol, const float* origin, const 
 
 extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, float* disp, const float* w, const float* b, float* out,
                                      long P, int D, int row_stride, double incre, int num_levels, int radius, int Cout, int out_split,
-                                     int log2s_out, int img_w, const float* delta_taps, int delta_nhalf, float delta_bias, void* stream) {
+                                     int log2s_out, int img_w, const float* delta_taps, int delta_nhalf, float delta_bias, int level0_only, void* stream) {
     if (!vol || !origin || !disp || !w || !b || !out || P <= 0 || D <= 0) return CER_EINVAL;
     if (Cout != 64 || num_levels > 4) return CER_ESHAPE;
     if ((out_split == 2 || delta_taps) && (img_w <= 0 || P % img_w != 0 || P >= (1L << 31))) return CER_ESHAPE;
     if (delta_taps && (delta_nhalf < 1 || delta_nhalf > 2)) return CER_ESHAPE;
     if (!cer_aligned16(vol) || !cer_aligned16(out)) return CER_EALIGN;
     LevelInfo li;
-    int rc = level_info(D, row_stride, num_levels, radius, &li);
+    int rc = level_info(D, row_stride, num_levels, radius, level0_only, &li);
     if (rc) return rc;
     const int K = num_levels * (2 * radius + 1);
     const long ntiles = (P + LK_PIX - 1) / LK_PIX;
@@ -339,7 +338,7 @@ extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, floa
     dl.flag = out_split == 2 ? cer_overflow_flag_get() : nullptr;
     const int pre = row_stride <= 64 ? 4 : row_stride <= 128 ? 8 : LK_MAX_PRE;      // prefetch registers per thread: which instantiation
     const int by_regs = pre == 4 ? LK_OCC4 : pre == 8 ? 4 : 3;
-    const int by_lds = (int)((160 * 1024) / (smem + 256));
+    const int by_lds = (int)((long)cer_lds_per_cu() / (long)(smem + 256));
     const long resident = (long)ncu * (by_lds < 1 ? 1 : by_lds < by_regs ? by_lds : by_regs);
     const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);
 #define LK_LAUNCH(N) hipLaunchKernelGGL(lookup_encode_kernel<N>, dim3(grid), dim3(256), smem, (hipStream_t)stream, vol, origin, disp, w, b, out, P, D, row_stride, \

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .raft import RAFT
+from .raft import RAFT, SaturationError
 
 
 def scale_operation(images, intrinsics, s):
@@ -41,26 +41,13 @@ def disp_to_depth(res):
 
 
 def write_pfm(file, image, scale=1):
-    """Greyscale/colour float32 PFM, rows bottom-up, negative scale = little endian
-    (reference: utils/frame_utils.py:138-163)."""
-    if image.dtype.name != "float32":
-        raise Exception("Image dtype must be float32.")
-    image = np.flipud(image)
-    if image.ndim == 3 and image.shape[2] == 3:
-        color = True
-    elif image.ndim == 2 or (image.ndim == 3 and image.shape[2] == 1):
-        color = False
-    else:
-        raise Exception("Image must have H x W x 3, H x W x 1 or H x W dimensions.")
-    import sys
-    endian = image.dtype.byteorder
-    if endian == "<" or (endian == "=" and sys.byteorder == "little"):
-        scale = -scale
-    with open(file, "wb") as f:
-        f.write(b"PF\n" if color else b"Pf\n")
-        f.write(b"%d %d\n" % (image.shape[1], image.shape[0]))
-        f.write(b"%f\n" % scale)
-        image.tofile(f)
+    """float32 PFM as the reference writes it (utils/frame_utils.py:138-163): 'Pf' (H x W or H x W x 1) / 'PF' (H x W x 3), 'W H',
+    the scale (negated = little endian), rows bottom-up."""
+    if image.dtype != np.float32 or not (image.ndim == 2 or (image.ndim == 3 and image.shape[2] in (1, 3))):
+        raise ValueError("write_pfm: float32 H x W, H x W x 1 or H x W x 3 expected")
+    rows = np.ascontiguousarray(np.flipud(image).astype("<f4"))
+    head = (b"PF\n" if (image.ndim == 3 and image.shape[2] == 3) else b"Pf\n") + b"%d %d\n" % (image.shape[1], image.shape[0]) + b"%f\n" % -scale
+    Path(file).write_bytes(head + rows.tobytes())
 
 
 def inference(test_loader, ckpt, output_folder, rescale=1, crop=None, do_report=False, write_min_depth=None,
@@ -132,8 +119,9 @@ def inference(test_loader, ckpt, output_folder, rescale=1, crop=None, do_report=
         while pending:
             finish(pending.pop(0))
       pipe.check_overflow()                                 # (reads the flag: covers the last forwards, whose snapshots nobody polled)
-    except RuntimeError:
-        # (ONE clean-up for both raise sites - the poll inside finish() and the final check.)  The files of the last
+    except SaturationError:
+        # (ONE clean-up for both raise sites - the poll inside finish() and the final check; ADVICE r5: for THIS error only -
+        # an out-of-memory or loader error must not delete depth maps that were written correctly.)  The files of the last
         # `streams` forwards were written before their flags could be read: remove them rather than leave saturated depth maps next to
         # good ones
         for path in written[-n_flight:]:

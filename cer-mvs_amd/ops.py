@@ -20,6 +20,25 @@ def row_layout(D, num_levels, compact=False):
     return offs, lens, ((D if compact else off) + 3) // 4 * 4
 
 
+def _level0_only(vol, D, num_levels, level0_only):
+    """The row form of a volume for the lookup entry points (an explicit argument of the C ABI since 1060).  Given, it is
+    used; else the mark the builders of this module leave on the volumes they return (``vol.level0_only``) - a view of a volume
+    loses it; else the stride decides where it can: rows shorter than the whole pyramid hold level 0 only, and a stride that fits
+    both forms (D <= 5) is refused instead of guessed."""
+    if level0_only is not None:
+        return int(bool(level0_only))
+    mark = getattr(vol, "level0_only", None)
+    if mark is not None:
+        return int(bool(mark))
+    offs, lens, rs_full = row_layout(D, num_levels)
+    rs = vol.shape[-1]
+    if rs < offs[-1] + lens[-1]:
+        return 1
+    if num_levels > 1 and rs == row_layout(D, num_levels, compact=True)[2]:
+        raise ValueError(f"lookup: a row stride of {rs} floats fits both row forms at D = {D}, {num_levels} levels: pass level0_only")
+    return 0
+
+
 def alt_corr_forward(fmap1, fmap2, coords, radius):
     B, H1, W1, C = fmap1.shape
     _, H2, W2, _ = fmap2.shape
@@ -192,7 +211,7 @@ def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, 
     every stage of a forward), else they are made here; a third element ``slots`` (int32 [V], device) says that view v's split
     rows are block slots[v] of the second element (any leading shape; the sharded forward's gathered buffer) - ``fmap2`` may then
     be None and ``V`` = len(slots).  ``compact``: level-0-only rows (``row_layout``); with ``pyramid_scale`` the epilogue then only
-    scales (epipolar-line-tile kernel; the walk's fused epilogue always writes the pooled levels and refuses)."""
+    scales (both builders: ``fuse_levels = 1``)."""
     if fmap2 is None:
         if split is None or len(split) < 3 or src_hw is None:
             raise ValueError("cost_build: without fmap2 the split rows, their view slots and src_hw are required")
@@ -210,10 +229,7 @@ def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, 
         raise ValueError("cost_build: the fused pyramid needs fold=True, accumulate=False and D <= 64")
     lib = L.load()
     on_lines = fold and C == 64 and D <= 64 and (fmap2 is None or lib.cer_cost_build_algo(-1) != 1)
-    late_scale = None
-    if fuse and (num_levels < 2 or (compact and not on_lines)):   # nothing to pool in the kernel: scale afterwards (the walk's fused epilogue is keyed on levels > 1)
-        fuse, late_scale = False, float(pyramid_scale)
-    fuse_levels = 0 if not fuse else (1 if compact else num_levels)
+    fuse_levels = 0 if not fuse else (1 if compact else num_levels)      # (1 = scale only, in both builders since ABI 1060)
     if vol is None:
         shape = (P, rs) if fold else (V, P, rs)
         if fuse:
@@ -247,10 +263,9 @@ def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, 
         L.check(lib.cer_cost_build_f32(L.dev_ptr(fmap1, "fmap1"), L.dev_ptr(fmap2, "fmap2"), L.dev_ptr(Pij, "Pij"),
                                        L.dev_ptr(disp_in, "disp_in"), L.dev_ptr(vol, "vol"), L.dev_ptr(origin, "origin"),
                                        V, h1, w1, h2, w2, C, D, rs, float(incre), int(bool(shift)), mode, int(y0),
-                                       num_levels if fuse else 0, float(pyramid_scale) if fuse else 1.0, L.cur_stream()),
+                                       fuse_levels, float(pyramid_scale) if fuse else 1.0, L.cur_stream()),
                 "cost_build")
-    if late_scale is not None:
-        pyramid(vol, D, 1 if compact else num_levels, scale=late_scale)
+    vol.level0_only = bool(compact)        # the row form, for the lookup wrappers (``_level0_only``)
     return vol, origin
 
 
@@ -289,6 +304,7 @@ def cost_lines_reduce(disp_in, V, h1, w1, D, incre, shift, num_levels, pyramid_s
                                                float(pyramid_scale) if fuse else 1.0, L.cur_stream()), "cost_lines_reduce")
     if pyramid_scale is not None and not fuse:
         pyramid(vol, D, 1 if compact else num_levels, scale=float(pyramid_scale))
+    vol.level0_only = bool(compact)
     return vol, origin
 
 
@@ -299,15 +315,16 @@ def pyramid(vol, D, num_levels, scale=1.0):
     return vol
 
 
-def corr_lookup(vol, origin, disp, D, incre, num_levels, radius, per_view_disp=False):
-    """vol [nv,P,rs] or [P,rs]; origin [P]; disp [P] (or [nv,P]) -> [nv, L*(2r+1), P]."""
+def corr_lookup(vol, origin, disp, D, incre, num_levels, radius, per_view_disp=False, level0_only=None):
+    """vol [nv,P,rs] or [P,rs]; origin [P]; disp [P] (or [nv,P]) -> [nv, L*(2r+1), P].  ``level0_only``: see ``_level0_only``."""
+    l0 = _level0_only(vol, D, num_levels, level0_only)
     if vol.dim() == 2:
         vol = vol[None]
     nv, P, rs = vol.shape
     out = torch.empty(nv, num_levels * (2 * radius + 1), P, device=vol.device, dtype=torch.float32)
     L.check(L.load().cer_corr_lookup_f32(L.dev_ptr(vol, "vol"), L.dev_ptr(origin, "origin"), L.dev_ptr(disp, "disp"),
                                          P if per_view_disp else 0, L.dev_ptr(out, "out"), nv, P, D, rs, float(incre),
-                                         num_levels, radius, L.cur_stream()), "corr_lookup")
+                                         num_levels, radius, l0, L.cur_stream()), "corr_lookup")
     return out
 
 
@@ -321,13 +338,16 @@ def corr_encode(feats, w_t, b, out=None):
     return out
 
 
-def lookup_encode(vol, origin, disp, w_t, b, D, incre, num_levels, radius, out=None, out_split=False, log2s=0, img_w=0, delta=None):
+def lookup_encode(vol, origin, disp, w_t, b, D, incre, num_levels, radius, out=None, out_split=False, log2s=0, img_w=0, delta=None,
+                  level0_only=None):
     """Folded volume [P,rs] -> relu(conv1x1(lookup)) [P,64] (``out_split``: True / 1 = split32 layout, see ``split32``;
     2 = frag16 layout of an image ``img_w`` pixels wide with scale 2^log2s, see ``s16_layout``: ``out`` [s16_pixels, 64]).
-    Rows shorter than the whole pyramid hold level 0 only (``row_layout(..., compact=True)``): the kernel forms the pooled levels itself.
+    ``level0_only`` (default: the builder's mark on ``vol``, see ``_level0_only``): the rows hold level 0 only (``row_layout(...,
+    compact=True)``) and the kernel forms the pooled levels itself.
     ``delta`` = (T [nhalf,9,P], bias): the previous iteration's disparity update (``delta_sum``) is applied to ``disp`` IN PLACE by this
     launch before the lookup reads it (needs ``img_w``)."""
     P, rs = vol.shape
+    l0 = _level0_only(vol, D, num_levels, level0_only)
     if out is None:
         rows = s16_pixels(P // img_w, img_w) if int(out_split) == 2 else P
         out = torch.zeros(rows, 64, device=vol.device, dtype=torch.float32)
@@ -335,7 +355,7 @@ def lookup_encode(vol, origin, disp, w_t, b, D, incre, num_levels, radius, out=N
     L.check(L.load().cer_lookup_encode_f32(L.dev_ptr(vol, "vol"), L.dev_ptr(origin, "origin"), L.dev_ptr(disp, "disp"),
                                            L.dev_ptr(w_t, "w"), L.dev_ptr(b, "b"), L.dev_ptr(out, "out"), P, D, rs, float(incre),
                                            num_levels, radius, 64, int(out_split), int(log2s), int(img_w), L.dev_ptr(T, "delta_taps"), nhalf, dbias,
-                                           L.cur_stream()), "lookup_encode")
+                                           l0, L.cur_stream()), "lookup_encode")
     return out
 
 

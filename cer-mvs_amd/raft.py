@@ -37,6 +37,12 @@ from .update import UpdateBlock
 _SIDE_STREAMS = {}
 
 
+class SaturationError(RuntimeError):
+    """A split-f16 kernel clamped an operand.  A RuntimeError subclass of its own so that callers which clean up after
+    THIS condition (``inference``: the depth maps written before the flag could be read) do not do so for unrelated RuntimeErrors -
+    an out-of-memory error, a loader failure, a shape error."""
+
+
 class RAFT(nn.Module):
     def __init__(self, cascade=[(64, 64, 8), (-1, 320, 8)], encoder_type="HR", dim_fmap=64, dim_net=64, dim_inp=64,
                  test_mode=False, precision="fp32", view_group=None, gru_precision="auto", encoder_backend="hip", shard="slab"):
@@ -117,7 +123,7 @@ class RAFT(nn.Module):
 
     def _raise_overflow(self, bits):
         what = "; ".join(v for k, v in self._OVERFLOW_WHAT.items() if bits & k)
-        raise RuntimeError(f"cer-mvs_amd: a split-f16 kernel saturated an operand ({what}): the result of that forward is not fp32-class. "
+        raise SaturationError(f"cer-mvs_amd: a split-f16 kernel saturated an operand ({what}): the result of that forward is not fp32-class. "
                            "Use RAFT(..., gru_precision='f16x3') / _lib.load().cer_cost_build_algo(1), or overflow_policy='fallback'.")
 
     def refresh_weights(self):
@@ -475,6 +481,7 @@ class RAFT(nn.Module):
             else:                      # more ranks than views: contribute zeros
                 _, _, rs = ops.row_layout(D, ub.num_levels, compact)
                 vol = torch.zeros(P, rs, device=dev)
+                vol.level0_only = bool(compact)
                 origin = cdist.stage_origin(disp, D, incre, stage == 0)
             if not (single and views and D <= 64):
                 cdist.reduce_volume(vol, self.view_group)

@@ -297,20 +297,23 @@ class UpdateBlock(nn.Module):
         """Scratch tensors of the loop for an h x w image (s16 path: m-tile-major layouts over whole m-tiles, ops.s16_pixels)."""
         P = h * w
         if self.conv_mode == "s16":
-            # persistent per (size, device): the padding pixels of the m-tile-major layouts are zero-filled once and never written
-            # (4 x 30 MB of memsets per forward otherwise); every data pixel is overwritten by the first iteration of a forward
+            # persistent per (size, device): allocated (and zero-filled) once - 4 x 30 MB of memsets per forward otherwise; every data
+            # pixel is overwritten by the first iteration of a forward, the padding slots are never consumed (see below)
             key = (h, w, str(device))
             cache = self.__dict__.setdefault("_ws_cache", {})
             if key not in cache:
                 while len(cache) >= 8:            # (row slabs of different heights share a process in the simulated-rank tests)
                     cache.pop(next(iter(cache)))
                 z = lambda c: torch.zeros(ops.s16_pixels(h, w), c, device=device, dtype=torch.float32)
-                cache[key] = {"c1": z(64), "c2": z(64), "z": z(64), "rn": z(64), "T": torch.empty(2, 9, P, device=device, dtype=torch.float32)}
-                if ALIAS_RN_C1:
-                    # r*h is written by the z|r launch, after the only reader of c1 (the corr2 launch) has run, and read by the q launch,
-                    # before the next lookup writes c1 again: the two tensors can share their 30 MB (round 5: the iteration's working set
-                    # - 283 MB at 296 x 400 - sits just above the 256 MB Infinity Cache)
-                    cache[key]["rn"] = cache[key]["c1"]
+                cache[key] = {"c1": z(64), "c2": z(64), "z": z(64), "T": torch.empty(2, 9, P, device=device, dtype=torch.float32)}
+                # r*h is written by the z|r launch, after the only reader of c1 (the corr2 launch) has run, and read by the q launch,
+                # before the next lookup writes c1 again: with ALIAS_RN_C1 the two tensors ARE ONE 30 MB buffer (ws["rn"] is ws["c1"];
+                # round 5: the iteration's working set - 283 MB at 296 x 400 - sits just above the 256 MB Infinity Cache).  Legal because
+                # nothing reads c1 behind the z|r launch of an iteration.  (The padding slots of these tensors need NOT stay zero: the
+                # epilogues store whole m-tiles, and every consumer masks pixels outside the image while it stages;
+                # tests/test_conv_s16_gpu.py::test_rn_may_share_c1s_buffer runs a forward on a garbage-filled workspace.)  Tools that
+                # want two independent buffers set CER_ALIAS_RN_C1=0.
+                cache[key]["rn"] = cache[key]["c1"] if ALIAS_RN_C1 else z(64)
             return cache[key]
         e = lambda c: torch.empty(P, c, device=device, dtype=torch.float32)
         return {"c1": e(64), "c2": e(64), "z": e(64), "rn": e(64), "hid": e(256),

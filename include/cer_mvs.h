@@ -98,9 +98,11 @@ int cer_alt_corr_bwd_reduce_f32(const float* fmap1, const long* order, const flo
  *   mode 2: as mode 1 but adds into the existing vol (accumulate across calls)
  * (h1, w1) is the reference-pixel grid this call covers and y0 the image row of its first row: a multi-GPU rank that owns
  * a row slab passes its slab height and first row (fmap1 / disp_in / vol then hold only those rows); y0 = 0 otherwise.
- * fuse_levels > 1 (mode 1, D <= 64 only): the epilogue also scales level 0 by fuse_scale (1/V: the view mean) and writes
- * the avg-pooled levels 1..fuse_levels-1 behind it - what cer_pyramid_f32(vol, ..., fuse_levels, fuse_scale) would do in a
- * second pass (core/corr.py:94-97); 0 or 1 = level 0 only, unscaled.
+ * fuse_levels >= 1 (mode 1, D <= 64 only; else CER_EINVAL): the epilogue also scales level 0 by fuse_scale (1/V: the view mean)
+ * and writes the avg-pooled levels 1..fuse_levels-1 behind it - what cer_pyramid_f32(vol, ..., fuse_levels, fuse_scale) would do in
+ * a second pass (core/corr.py:94-97).  fuse_levels = 1: level 0 only, SCALED (the level-0-only rows the lookup pools on the fly);
+ * fuse_levels = 0: level 0 only, unscaled, fuse_scale ignored, mode 2 allowed.  The same meaning in all three builders
+ * (cer_cost_build_f32, cer_cost_lines_f32, cer_cost_lines_reduce_f32) since ABI 1060: before, this entry point treated 1 like 0.
  * origin_out [P] may be NULL.  C % 64 == 0.  `incre` is the reference's Python float (core/raft.py:81): the kernel
  * uses (float)incre for the hypothesis spacing and (float)((D/2)*incre) for the shift limit, as torch does.
  */
@@ -162,7 +164,7 @@ int cer_pyramid_f32(float* vol, long rows, int D, int row_stride, int num_levels
  */
 int cer_corr_lookup_f32(const float* vol, const float* origin, const float* disp, long disp_view_stride,
                         float* out, int nv, long P, int D, int row_stride, double incre, int num_levels, int radius,
-                        void* stream);
+                        int level0_only /* see cer_lookup_encode_f32 */, void* stream);
 /* disp is [P] shared by all views (disp_view_stride = 0; RAFT.forward passes V identical copies,
  * core/raft.py:99) or [nv, P] (disp_view_stride = P). */
 
@@ -175,10 +177,12 @@ int cer_corr_encode_f32(const float* feats, const float* w, const float* b, floa
 /* Same lookup on the folded (view-mean) volume fused with the first corr_encoder layer
  * (reference: core/update.py:103 mean, :61-62 Conv2d(33,64,1)+ReLU): out [P, Cout] NHWC.
  * w [Cin=L*(2r+1), Cout] (transposed 1x1 weight), b [Cout].  Cout == 64.
- * Rows (both lookup entry points, round 5): row_stride >= the whole pyramid [level0 | level1 | ...] - the levels are read from the
- *   row; D <= row_stride < the whole pyramid - the row holds LEVEL 0 ONLY and level l is formed on the fly as the pairwise means
- *   ((a + b) * 0.5 level by level, core/corr.py:94-97) in the association cer_pyramid_f32 uses: bit-identical values, 43 % fewer
- *   bytes read (RAFT.forward builds its folded volume that way: cer_cost_lines_reduce_f32 with fuse_levels = 1).
+ * Rows (both lookup entry points): level0_only = 0 - the row holds the whole pyramid [level0 | level1 | ...] (row_stride >= its length,
+ *   else CER_ESHAPE) and the levels are read from it; level0_only = 1 (round 5; an explicit argument since ABI 1060 - it used to be
+ *   inferred from row_stride, which is ambiguous for D <= 5) - the row holds LEVEL 0 ONLY (row_stride >= D) and level l is formed on the
+ *   fly as the pairwise means ((a + b) * 0.5 level by level, core/corr.py:94-97) in the association cer_pyramid_f32 uses: bit-identical
+ *   values, 43 % fewer bytes read (RAFT.forward builds its folded volume that way: cer_cost_lines_reduce_f32 with fuse_levels = 1);
+ *   at most 4 levels in that form (CER_ESHAPE beyond).
  * delta_taps (may be NULL): the PREVIOUS GRU iteration's disparity update rides on this launch - core/update.py:114, core/raft.py:101:
  *   disp[p] += 0.01 * (delta_bias + sum over delta_nhalf (1 or 2) x 9 tap planes T[half][tap][p + (ky-1, kx-1)], zero outside the
  *   image), i.e. cer_delta_sum_f32 (same summation order: bit-identical), before the lookup of pixel p reads it; `disp` is then
@@ -189,7 +193,8 @@ int cer_lookup_encode_f32(const float* vol, const float* origin, float* disp,
                           long P, int D, int row_stride, double incre, int num_levels, int radius, int Cout,
                           int out_split /* 0: fp32 [P, Cout]; 1: split32 layout (f16x3 convs); 2: frag16 layout of an image
                                            img_w pixels wide with scale 2^log2s_out (s16 convs) - both below */,
-                          int log2s_out, int img_w, const float* delta_taps, int delta_nhalf, float delta_bias, void* stream);
+                          int log2s_out, int img_w, const float* delta_taps, int delta_nhalf, float delta_bias, int level0_only,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------
  * 3x3, stride 1, zero-padded convolution as an implicit GEMM on exact-fp32 MFMA

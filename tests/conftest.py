@@ -11,6 +11,26 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "variants: exercises an opt-in kernel form that is NOT in libcermvs.so (DESIGN.md 3i, 3k); deselected "
+                                       "unless CER_MVS_LIB points at cer-mvs_amd/csrc/variants/libcermvs_optin.so (make -C cer-mvs_amd/csrc "
+                                       "variants/libcermvs_optin.so)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """The opt-in kernel forms left the product library in round 5; their cases are not part of the default suite (a skip
+    must mean something) - they are collected only when the variant library is the one under test."""
+    if "libcermvs_optin" in os.environ.get("CER_MVS_LIB", ""):
+        return
+    keep, drop = [], []
+    for it in items:
+        is_var = it.get_closest_marker("variants") is not None
+        cs = getattr(it, "callspec", None)
+        if cs is not None and it.name.startswith("test_cost_lines_matches_walk") and cs.params.get("form") == 1:
+            is_var = True
+        (drop if is_var else keep).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 def pytest_sessionstart(session):

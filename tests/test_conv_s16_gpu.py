@@ -290,6 +290,7 @@ def test_conv_s16_dynamic_range(dev):
     assert torch.isfinite(ops.conv3x3_s16(pc, [big], h, w, L.EPI_LINEAR)).all()
 
 
+@pytest.mark.variants
 def test_conv_s16_producer_consumer_form_matches(dev):
     """csrc/experimental/conv_s16pc.hip (variants/libcermvs_optin.so only since round 5: cer_conv3x3_s16_pc(1)) against the default kernels: z|r gates, GRU blend, ReLU conv and the fused
     delta head on a size with rim tiles, partial last tiles and several tiles per persistent block; the two forms differ only in where
@@ -333,3 +334,33 @@ def test_conv_s16_producer_consumer_form_matches(dev):
             assert all(torch.equal(x, y) for x, y in zip(raw, raw0))
     finally:
         lib.cer_conv3x3_s16_pc(prev)
+
+
+def test_rn_may_share_c1s_buffer(dev, monkeypatch):
+    """ADVICE r5 on update.ALIAS_RN_C1 (r * h written into the lookup output's buffer).  (1) Whole forwards are bit-identical with the
+    two tensors aliased and apart.  (2) What the m-tile-major scratch tensors hold in their PADDING slots (slots past the image's last
+    row / column; the epilogues store whole m-tiles, so relu(conv) of a virtual pixel does land there) never reaches a result: every
+    consumer masks pixels outside the image while it stages (conv_s16.hip: `valid`), so a workspace whose tensors were pre-filled with
+    garbage gives the same bits.  Ragged size: 9 x 21 pixels at feature resolution = 5 x 2 m-tiles of 2 x 16 slots, 131 of 320 padding."""
+    from cer_mvs_amd import RAFT, ops, update
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+    H, W, V = 36, 84, 3
+    h, w = H // 4, W // 4
+    cascade = [(64, 64, 3), (-1, 320, 3)]
+    images, poses, intr, scale = synthetic_scene(H, W, V, seed=2)
+    outs = {}
+    for alias, poison in ((True, False), (False, False), (True, True)):
+        monkeypatch.setattr(update, "ALIAS_RN_C1", alias)
+        model = RAFT(cascade=cascade, test_mode=True, gru_precision="s16f8")
+        model.load_state_dict(fill_state_dict(model.state_dict(), seed=5))
+        model = model.to(dev).eval()
+        ws = model.update_block.workspace(h, w, dev)
+        assert (ws["rn"].data_ptr() == ws["c1"].data_ptr()) == alias and ws["c1"].shape[0] == ops.s16_pixels(h, w) > h * w
+        if poison:
+            for name in ("c1", "c2", "z", "rn"):
+                ws[name].view(torch.int32).fill_(0x5BCD5BCD)          # f16 halves of 249.6 / as fp32 1.16e17: finite garbage everywhere
+        with torch.no_grad():
+            outs[(alias, poison)] = model(images.to(dev), poses.to(dev), intr.to(dev), scale=scale).clone()
+    assert torch.equal(outs[(True, False)], outs[(False, False)])
+    assert torch.equal(outs[(True, False)], outs[(True, True)])
+    assert float(outs[(True, False)].abs().sum()) > 0

@@ -177,7 +177,7 @@ def test_lookup_edge_cases(dev):
     assert rel_l1(out.cpu().view(1, -1, 1, P), ref) < 1e-5
 
 
-@pytest.mark.parametrize("D,L", [(64, 3), (44, 3), (20, 2), (40, 4), (64, 1)])
+@pytest.mark.parametrize("D,L", [(64, 3), (44, 3), (20, 2), (40, 4), (64, 1), (5, 3), (3, 2)])
 def test_lookup_on_level0_rows_is_bit_identical(dev, D, L):
     """Round 5: rows that hold level 0 only (row_stride < the whole pyramid) - both lookup kernels form the pooled levels on the fly, in
     cer_pyramid_f32's association: bit for bit what they read from rows that store the levels (core/corr.py:94-97,102-143), incl. the
@@ -187,7 +187,7 @@ def test_lookup_on_level0_rows_is_bit_identical(dev, D, L):
     P, incre = h * w, 0.0025 / 320
     _, _, rs = ops.row_layout(D, L)
     _, _, rs0 = ops.row_layout(D, L, compact=True)
-    assert rs0 == (D + 3) // 4 * 4 and (rs0 < rs or L == 1)
+    assert rs0 == (D + 3) // 4 * 4 and (rs0 < rs or L == 1 or D <= 5)      # (D <= 5: both forms fit one stride - the flag is explicit)
     full = torch.zeros(P, rs, device=dev)
     full[:, :D] = hashed((P, D), 191, -30.0, 30.0).to(dev)
     ops.pyramid(full, D, L, scale=0.1)
@@ -198,14 +198,33 @@ def test_lookup_on_level0_rows_is_bit_identical(dev, D, L):
     steps[0], steps[1], steps[2], steps[3] = -100.0, 1e6, 3.0, -22.0
     disp = (origin + steps * incre).to(dev)
     origin = origin.to(dev)
-    a = ops.corr_lookup(full, origin, disp, D, incre, L, r)
-    b = ops.corr_lookup(lvl0, origin, disp, D, incre, L, r)
+    a = ops.corr_lookup(full, origin, disp, D, incre, L, r, level0_only=False)
+    b = ops.corr_lookup(lvl0, origin, disp, D, incre, L, r, level0_only=True)
     assert torch.equal(a, b) and float(a.abs().sum()) > 0
     K = L * (2 * r + 1)
     w0t, b0 = hashed((K, 64), 194, -0.2, 0.2).to(dev), hashed((64,), 195, -0.1, 0.1).to(dev)
     for kw in ({}, {"out_split": 2, "log2s": Lb.S16_RELU, "img_w": w}):
-        assert torch.equal(ops.lookup_encode(full, origin, disp, w0t, b0, D, incre, L, r, **kw),
-                           ops.lookup_encode(lvl0, origin, disp, w0t, b0, D, incre, L, r, **kw))
+        assert torch.equal(ops.lookup_encode(full, origin, disp, w0t, b0, D, incre, L, r, level0_only=False, **kw),
+                           ops.lookup_encode(lvl0, origin, disp, w0t, b0, D, incre, L, r, level0_only=True, **kw))
+    if rs0 < rs:       # unmarked tensors: the stride decides where it can ...
+        assert torch.equal(ops.corr_lookup(lvl0, origin, disp, D, incre, L, r), a)
+    elif L > 1:        # ... and a stride that fits both forms is refused, not guessed
+        with pytest.raises(ValueError):
+            ops.corr_lookup(lvl0, origin, disp, D, incre, L, r)
+
+
+def test_lookup_row_form_is_explicit(dev):
+    """ABI 1060 (ADVICE r5): the row form is an argument of both lookup entry points.  Level-0-only rows form at most 4 levels (lk_elem);
+    whole-pyramid rows must hold the whole pyramid."""
+    from cer_mvs_amd import ops
+    P, D, r, incre = 40, 64, 1, 0.0025 / 64
+    origin, disp = torch.zeros(P, device=dev), torch.full((P,), 10 * incre, device=dev)
+    vol = hashed((P, 64), 196, -1.0, 1.0).to(dev)
+    ops.corr_lookup(vol, origin, disp, D, incre, 4, r, level0_only=True)
+    with pytest.raises(RuntimeError):
+        ops.corr_lookup(vol, origin, disp, D, incre, 5, r, level0_only=True)        # five levels cannot be pooled on the fly
+    with pytest.raises(RuntimeError):
+        ops.corr_lookup(vol, origin, disp, D, incre, 3, r, level0_only=False)       # 64 floats do not hold 64 + 32 + 16
 
 
 def test_lookup_flags_a_saturated_output_itself(dev):
@@ -394,6 +413,9 @@ def _cost_lines_matches_walk(dev, D, stage0, geom, lib):
                 b, ob = ops.cost_build(f1, f2, Pij, d0, D, incre, stage0, h1, w1, 3, fold=True, pyramid_scale=1.0 / V)
                 c, _ = ops.cost_build(f1, f2, Pij, d0, D, incre, stage0, h1, w1, 3, fold=True, vol=a.clone(), accumulate=True)
                 s_, _ = ops.cost_build(f1[5 * w1:], f2, Pij, d0[5 * w1:], D, incre, stage0, h1 - 5, w1, 3, fold=True, src_hw=(h1, w1), y0=5)
+                # level-0-only rows, scaled (fuse_levels = 1 means "scale only" in BOTH builders since ABI 1060): level 0 of b, bit for bit
+                e, _ = ops.cost_build(f1, f2, Pij, d0, D, incre, stage0, h1, w1, 3, fold=True, pyramid_scale=1.0 / V, compact=True)
+                assert e.shape[1] == (D + 3) // 4 * 4 and e.level0_only and not b.level0_only and torch.equal(e[:, :D], b[:, :D])
                 res[algo] = (a, oa, b, ob, c, s_)
             finally:
                 lib.cer_cost_build_algo(prev)
