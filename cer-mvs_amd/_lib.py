@@ -13,6 +13,7 @@ ABI_VERSION = 1060
 CONV_MAX_SRC = 4
 EPI_LINEAR, EPI_RELU, EPI_GATES, EPI_GRU, EPI_DELTA = 0, 1, 2, 3, 4
 EPI_OUT_SPLIT, EPI_AUX_SPLIT = 0x100, 0x200       # cer_mvs.h: split32 activation layout flags, or-ed into `epi`
+EPI_CORR_FP6 = 0x800                               # cer_conv3x3_s16: ... on its FP6 (e2m3, block-scaled) form: half the matrix-pipe passes again (round 6)
 EPI_CORR_FP8 = 0x400                               # cer_conv3x3_s16: correction terms of the tensor sources on the fp8 matrix instruction
 # cer_mvs.h, "s16" convs: log2 scales of the split16 activation classes (|x| <= 1: hidden state, r*h; ReLU outputs; generated
 # disparity features)

@@ -42,6 +42,8 @@ __global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : 2) void conv
     constexpr int TH = WM_ * 2 * MT, HR = TH + 2;
     constexpr int ABUF = HR * (F8 ? SX_ROWB8 : SX_ROWB);
     constexpr int NPIX = HR * SX_HW, NITEM = NPIX * 4, ITEMS = (NITEM + 255) / 256;
+    // F8 = 2 (round 6): the correction terms in FP6 (e2m3) with one E8M0 scale per K block - half the matrix-pipe passes of the fp8 form.
+    constexpr bool F6 = F8 == 2;
     constexpr int NITEM8 = NPIX * 4, ITEMS8 = F8 ? (NITEM8 + 255) / 256 : 1;
     constexpr int NB = WN_ * 32;
     constexpr int DROWS = HR + 6;
@@ -202,9 +204,58 @@ __global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : 2) void conv
         }
     }
     constexpr int IB8 = (ITEMS8 + 2) / 3;  // items per batch; three batches per chunk (taps 0 -> 2, 2 -> 4, 4 -> 6)
-    uint4 raw8[IB8][2];
+    constexpr int NLD8 = 2;                // 16-byte pieces per item: hi | lo (1 KiB apart)
+    uint4 raw8[IB8][NLD8];
     auto stage8_addr = [&](const SxStage& st, int pk, int it) {
         return st.base + (long)(pk & 0xFFFFF) * st.mtb + (((it >> 1) & 1) * 2048 + (it & 1) * 512 + ((pk >> 20) & 31) * 16);
+    };
+    // FP6 form (same items as the fp8 form: (pixel, half-chunk hc, kg) = 8 channels, hi and lo piece).  The lane's B operand of the FP6
+    // instruction lives in the pixel's slots 4 + 2 kg | 5 + 2 kg: 32 six-bit e2m3 fields, field i at bit 6 i = [xh (8) | xl * 2^11 (8)] of
+    // half-chunk 0, then of half-chunk 1 (24 bytes), all divided by ONE power of two s = 2^(e - 2) - e: exponent of the largest |xh| of the 16
+    // channels (|xl * 2^11| <= |xh| element by element, so the block maximum lands in [4, 7.75), or one exponent up in [3.875, 4]: nothing
+    // saturates) - then the E8M0 byte of s in byte 24 (dword 6: the register the instruction takes this lane's scale from).  The two items of
+    // a block sit in lanes tid and tid ^ 2: they exchange their maxima by DPP, convert their own 16 values (v_cvt_scalef32_pk32_fp6_f16
+    // divides by its scale operand, rounds to nearest even and packs field i at bit 6 i - tools/ubench/mfma_fp6.hip; the upper 16 inputs are
+    // don't-cares) and write their 96 bits: hc = 0 dwords 0-2 of the region, hc = 1 dwords 3-5 and the scale.
+    auto stage6_put = [&](int bufoff, int pk, int it, uint4 vh, uint4 vl) {
+        const unsigned m = (pk & (1 << 28)) ? 0xFFFFFFFFu : 0u;                // zero padding of the feature map
+        vh.x &= m; vh.y &= m; vh.z &= m; vh.w &= m;
+        vl.x &= m; vl.y &= m; vl.z &= m; vl.w &= m;
+        const int n = it >> 2, r = (n * 3641) >> 16, c = n - r * SX_HW;         // n / 18 for n < 3641
+        const int hc = (it >> 1) & 1, kgs = it & 1, key = (c >> 1) & 7;
+        char* px = sx_smem + bufoff + (r * SX_PITCH + c) * 128;
+        // exponent of the block's largest |xh|: f16 bit patterns without their sign order like the magnitudes (packed unsigned max)
+        typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+        union U2 { unsigned u; ushort2_t s; };
+        U2 a0, a1, a2, a3;
+        a0.u = vh.x & 0x7FFF7FFFu; a1.u = vh.y & 0x7FFF7FFFu; a2.u = vh.z & 0x7FFF7FFFu; a3.u = vh.w & 0x7FFF7FFFu;
+        a0.s = __builtin_elementwise_max(a0.s, a1.s);
+        a2.s = __builtin_elementwise_max(a2.s, a3.s);
+        a0.s = __builtin_elementwise_max(a0.s, a2.s);
+        unsigned mm = max(a0.u & 0xFFFFu, a0.u >> 16);
+        mm = max(mm, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mm, 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]: the item of the other half-chunk
+        const unsigned sb = ((mm + 0x40u) >> 10) + 110u;                        // E8M0 of s = 2^(bexp - 15 - 2); + 0x40: mantissas >= 1.9375 go one up
+        const float sc = __uint_as_float(sb << 23);
+        typedef _Float16 half32_t __attribute__((ext_vector_type(32)));
+        typedef _Float16 half16_t __attribute__((ext_vector_type(16)));
+        typedef int intx6_t __attribute__((ext_vector_type(6)));
+        union { half16_t v; uint4 q[2]; cer_h2 h[8]; } in;
+        in.q[0] = vh; in.q[1] = vl;
+        const cer_h2 k2048 = (cer_h2){(_Float16)2048.0f, (_Float16)2048.0f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) in.h[4 + j] = in.h[4 + j] * k2048;
+        const half32_t in32 = __builtin_shufflevector(in.v, in.v, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
+                                                      -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+        const intx6_t f6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(in32, sc);
+        if (pk & (1 << 29)) {
+            *reinterpret_cast<uint4*>(px + (((2 * kgs + hc) ^ key) << 4)) = vh;
+            char* s0 = px + (((4 + 2 * kgs) ^ key) << 4);
+            char* s1 = px + (((5 + 2 * kgs) ^ key) << 4);
+            *reinterpret_cast<unsigned*>(hc ? s0 + 12 : s0) = (unsigned)f6[0];
+            *reinterpret_cast<unsigned*>(hc ? s1 : s0 + 4) = (unsigned)f6[1];
+            *reinterpret_cast<unsigned*>(hc ? s1 + 4 : s0 + 8) = (unsigned)f6[2];
+            *reinterpret_cast<unsigned*>(hc ? s1 + 8 : s1 + 12) = hc ? sb : 0u;
+        }
     };
     auto stage8_put = [&](int bufoff, int pk, int it, uint4 vh, uint4 vl) {
         const unsigned m = (pk & (1 << 28)) ? 0xFFFFFFFFu : 0u;                // zero padding of the feature map
@@ -236,8 +287,8 @@ __global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : 2) void conv
             const int i = batch * IB8 + k;
             if (i >= ITEMS8) break;
             const char* p = stage8_addr(st, st8_pk[i] ^ vary, (tid ^ vary) + 256 * i);
-            raw8[k][0] = *reinterpret_cast<const uint4*>(p);
-            raw8[k][1] = *reinterpret_cast<const uint4*>(p + 1024);
+#pragma unroll
+            for (int q = 0; q < NLD8; ++q) raw8[k][q] = *reinterpret_cast<const uint4*>(p + 1024 * q);
         }
     };
     auto stage8_store = [&](int bufoff, int batch) {
@@ -246,7 +297,8 @@ __global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : 2) void conv
         for (int k = 0; k < IB8; ++k) {
             const int i = batch * IB8 + k;
             if (i >= ITEMS8) break;
-            stage8_put(bufoff, st8_pk[i] ^ vary, (tid ^ vary) + 256 * i, raw8[k][0], raw8[k][1]);
+            if constexpr (F6) stage6_put(bufoff, st8_pk[i] ^ vary, (tid ^ vary) + 256 * i, raw8[k][0], raw8[k][1]);
+            else stage8_put(bufoff, st8_pk[i] ^ vary, (tid ^ vary) + 256 * i, raw8[k][0], raw8[k][1]);
         }
     };
     // literal disparity features, group g (channels 16g .. 16g+15 of 100 * (unfold7x7(d) - d), core/update.py:80-85,97)
@@ -388,14 +440,14 @@ __global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : 2) void conv
         f.l = *reinterpret_cast<const half8*>(p + 1024);
     };
     const SxStage st0 = describe(0);
-    uint4 raw0[F8 ? 2 * ITEMS8 : ITEMS];
+    uint4 raw0[F8 ? NLD8 * ITEMS8 : ITEMS];
     if (st0.kind == 2) {
         if constexpr (F8) {
 #pragma unroll
             for (int i = 0; i < ITEMS8; ++i) {
                 const char* p = stage8_addr(st0, st8_pk[i], tid + 256 * i);
-                raw0[2 * i] = *reinterpret_cast<const uint4*>(p);
-                raw0[2 * i + 1] = *reinterpret_cast<const uint4*>(p + 1024);
+#pragma unroll
+                for (int q = 0; q < NLD8; ++q) raw0[NLD8 * i + q] = *reinterpret_cast<const uint4*>(p + 1024 * q);
             }
         } else {
 #pragma unroll
@@ -416,25 +468,45 @@ __global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : 2) void conv
             dval[i] = (idx < DROWS * SX_DTW && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) ? dsrc[(long)gy * a.w + gx] : 0.f;
         }
     }
-    struct W8 { half8 h0, h1; union { intx8 v; uint4 q[2]; } q; };
+    // the 8- / 6-bit operand of the block-scaled instruction: 32 bytes (fp8), or 24 bytes of fields + the dword that holds the lane's E8M0 scale
+    // (FP6: 16 + 12 bytes - seven registers instead of eight per fragment and weight slot)
+    typedef unsigned uintx3 __attribute__((ext_vector_type(3)));
+    struct Op8 {
+        uint4 a;
+        typename std::conditional<F8 == 2, uintx3, uint4>::type b;
+        __device__ __forceinline__ void load(const char* p0, const char* p1) {
+            a = *reinterpret_cast<const uint4*>(p0);
+            b = *reinterpret_cast<const decltype(b)*>(p1);
+        }
+        __device__ __forceinline__ intx8 v() const {
+            if constexpr (F8 == 2) {
+                const intx8 lo = (intx8){(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, 0, 0};
+                return __builtin_shufflevector(lo, lo, 0, 1, 2, 3, 4, 5, -1, -1);
+            } else {
+                return (intx8){(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w};
+            }
+        }
+        __device__ __forceinline__ int scale() const { return (int)b.z; }
+    };
+    struct W8 { half8 h0, h1; Op8 q; };
     // F8: weights of the current chunk step and of the next WR - 1.  The 64-output-channel kernels (2 x 2 waves, two m-tiles per wave) spend only
     // 256 matrix-pipe cycles per wave on a chunk step - with two co-resident blocks ~500 cycles between a slice's request and its use, less
     // than an L2 round trip: their chunk loop ran at 1.75 x its pipe floor (tools/trace_s16.py --conv q: 8.0 k cycles per chunk against
     // 4.6 k; alone on a CU 388 per 16-channel step against 128).  They request two steps ahead (ring of three; 9 taps = 3 x 3: no slot swap):
     // 6.7 k per chunk.
     constexpr int WR = (F8 && WM_ == 2 && MT == 2 && SX_WRING3) ? 3 : 2;         // (three m-tiles per wave: 229 VGPRs already, and 384 pipe cycles per step)
+    constexpr bool WSPLIT = F8 && WR == 2 && SX_WSPLIT;                           // two slots, refilled part by part (see mma8_roll)
     W8 w8[WR];
     auto load_w8 = [&](W8& f, int cstep) {                 // (clamped: the steps past the tensors are never multiplied)
         const char* p = wlane8 + (long)min(cstep, (nsteps_t >> 1) - 1) * (2 * wstep);
         f.h0 = *reinterpret_cast<const half8*>(p);
         f.h1 = *reinterpret_cast<const half8*>(p + 1024);
-        f.q.q[0] = *reinterpret_cast<const uint4*>(p + 2048);
-        f.q.q[1] = *reinterpret_cast<const uint4*>(p + 3072);
+        f.q.load(p + 2048, p + 3072);
     };
     // the steps of the disparity source follow the tensors' (same bytes per 16-channel step in both forms)
     if (F8 && ngroups_t > 0) {
         load_w8(w8[0], 0);
-        if constexpr (WR == 3) load_w8(w8[1], 1);
+        if constexpr (WR == 3 || WSPLIT) load_w8(w8[1], 1);
     } else {
         load_w(fw[0], 0);
         load_w(fw[1], 1);
@@ -467,7 +539,10 @@ __global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : 2) void conv
     if (st0.kind == 2) {
         if constexpr (F8) {
 #pragma unroll
-            for (int i = 0; i < ITEMS8; ++i) stage8_put(0, st8_pk[i], tid + 256 * i, raw0[2 * i], raw0[2 * i + 1]);
+            for (int i = 0; i < ITEMS8; ++i) {
+                if constexpr (F6) stage6_put(0, st8_pk[i], tid + 256 * i, raw0[2 * i], raw0[2 * i + 1]);
+                else stage8_put(0, st8_pk[i], tid + 256 * i, raw0[2 * i], raw0[2 * i + 1]);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
@@ -519,15 +594,14 @@ __global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : 2) void conv
 
     // first tap of group gi inside its buffer: tap 0 (dy = dx = 0), or the centre tap for a collapsed disparity group
     const bool first_is_centre0 = st0.kind == 3;
-    union F8Frag { intx8 v; uint4 q[2]; };
+    typedef Op8 F8Frag;
     F8Frag f8[F8 ? MT : 1];                                // F8: fx.h / fx.l hold the f16 hi halves of half-chunk 0 / 1, f8 the fp8 operand
     if (F8 && st0.kind == 2) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             fx.h[m] = *reinterpret_cast<const half8*>(sx_smem + xa[0] + (2 * m) * SX_ROWB8);
             fx.l[m] = *reinterpret_cast<const half8*>(sx_smem + (xa[0] ^ 16) + (2 * m) * SX_ROWB8);
-            f8[m].q[0] = *reinterpret_cast<const uint4*>(sx_smem + (xa[0] ^ 64) + (2 * m) * SX_ROWB8);
-            f8[m].q[1] = *reinterpret_cast<const uint4*>(sx_smem + (xa[0] ^ 80) + (2 * m) * SX_ROWB8);
+            f8[m].load(sx_smem + (xa[0] ^ 64) + (2 * m) * SX_ROWB8, sx_smem + (xa[0] ^ 80) + (2 * m) * SX_ROWB8);
         }
     } else if (first_is_centre0) load_x(fx, xh[1], xl[1], SX_ROWB);
     else load_x(fx, xh[0], xl[0], 0);
@@ -539,26 +613,42 @@ __global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : 2) void conv
     // the instruction's E8M0 block scale 2^3 puts the products on the accumulator's scale S.  64 + 64 matrix-pipe cycles per m-tile
     // and 32 channels instead of 6 x 32.
     if constexpr (F8) {
-        auto mma8_roll = [&](const W8& w, int pa, int rowoff) {
+        // both correction terms of a 32-channel tap: fp8 form - uniform block scales (2^0, 2^3); FP6 form - the per-lane E8M0 bytes that travel
+        // in dword 6 of either operand (the instruction reads six registers of an FP6 operand)
+        auto mma_corr = [&](const W8& w, const F8Frag& x, const floatx16& c) {
+            if constexpr (F6) return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w.q.v(), x.v(), c, 2, 2, 0, w.q.scale(), 0, x.scale());
+            else return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w.q.v(), x.v(), c, 0, 0, 0, 127, 0, 130);
+        };
+        // `refill` (WSPLIT kernels, round 6): chunk step whose weights replace this slot's, PART BY PART, as soon as the part's last MFMA of this
+        // tap has been issued - h0 behind the first group, h1 behind the second, the 8- / 6-bit operand behind the third.  Every part then has
+        // 1 2/3 taps between its request and its use with the same two register slots (loading a whole slot at the top of the tap before its
+        // use gave the f16 hi part of half-chunk 0 ONE tap: with the FP6 form's 768-cycle taps that is less than an L2 round trip, and the
+        // chunk loop ran at 1 100 cycles per tap - 7.9 k per chunk with the weights not streamed at all, tools/trace_s16.py).  -1: no refill.
+        auto mma8_roll = [&](W8& w, int pa, int rowoff, int refill) {
+            const char* wp = wlane8 + (long)min(max(refill, 0), (nsteps_t >> 1) - 1) * (2 * wstep);
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h0, fx.h[m], acc[m], 0, 0, 0);
+            if (WSPLIT && refill >= 0) w.h0 = *reinterpret_cast<const half8*>(wp);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h1, fx.l[m], acc[m], 0, 0, 0);
                 fx.h[m] = *reinterpret_cast<const half8*>(sx_smem + pa + (2 * m) * SX_ROWB8 + rowoff);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (WSPLIT && refill >= 0) w.h1 = *reinterpret_cast<const half8*>(wp + 1024);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                acc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w.q.v, f8[m].v, acc[m], 0, 0, 0, 127, 0, 130);
+                acc[m] = mma_corr(w, f8[m], acc[m]);
                 fx.l[m] = *reinterpret_cast<const half8*>(sx_smem + (pa ^ 16) + (2 * m) * SX_ROWB8 + rowoff);
-                f8[m].q[0] = *reinterpret_cast<const uint4*>(sx_smem + (pa ^ 64) + (2 * m) * SX_ROWB8 + rowoff);
-                f8[m].q[1] = *reinterpret_cast<const uint4*>(sx_smem + (pa ^ 80) + (2 * m) * SX_ROWB8 + rowoff);
+                f8[m].load(sx_smem + (pa ^ 64) + (2 * m) * SX_ROWB8 + rowoff, sx_smem + (pa ^ 80) + (2 * m) * SX_ROWB8 + rowoff);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if (WSPLIT && refill >= 0) {
+                w.q.load(wp + 2048, wp + 3072);
             }
         };
         // the last tap of the last chunk rolls in the first operands of the disparity section (16-channel layout, f16 hi | lo)
-        auto mma8_last = [&](const W8& w, int ph, int pl, int rowoff) {
+        auto mma8_last = [&](W8& w, int ph, int pl, int rowoff) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h0, fx.h[m], acc[m], 0, 0, 0);
 #pragma unroll
@@ -569,7 +659,7 @@ __global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : 2) void conv
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                acc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w.q.v, f8[m].v, acc[m], 0, 0, 0, 127, 0, 130);
+                acc[m] = mma_corr(w, f8[m], acc[m]);
                 fx.l[m] = *reinterpret_cast<const half8*>(sx_smem + pl + (2 * m) * SX_ROWB + rowoff);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -588,11 +678,12 @@ __global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : 2) void conv
                 // the first two slices of the disparity section instead
                 W8& wc = w8[WR == 3 ? t % 3 : (t & 1)];
                 W8& wn = w8[WR == 3 ? (t + 2) % 3 : ((t + 1) & 1)];
-                if (WR == 3 ? (t < 7 || !last) : (t < 8 || !last)) load_w8(wn, gi * 9 + t + WR - 1);
+                if (!WSPLIT && (WR == 3 ? (t < 7 || !last) : (t < 8 || !last))) load_w8(wn, gi * 9 + t + WR - 1);
                 if (t == 8 && last) { load_w(fw[0], nsteps_t); load_w(fw[1], nsteps_t + 1); }     // (the free weight slot's registers)
                 __builtin_amdgcn_sched_barrier(0);
-                if (t < 8) mma8_roll(wc, (xa[(t + 1) % 3] ^ vary) + bufC, ((t + 1) / 3) * SX_ROWB8);
-                else if (!last) mma8_roll(wc, (xa[0] ^ vary) + bufN, 0);
+                const int refill = (WSPLIT && (t < 7 || !last)) ? gi * 9 + t + 2 : -1;
+                if (t < 8) mma8_roll(wc, (xa[(t + 1) % 3] ^ vary) + bufC, ((t + 1) / 3) * SX_ROWB8, refill);
+                else if (!last) mma8_roll(wc, (xa[0] ^ vary) + bufN, 0, refill);
                 else mma8_last(wc, xh[1] + bufN, xl[1] + bufN, SX_ROWB);       // (collapsed disparity group or nothing: see the launcher)
             }
             if constexpr (WR == 2) {
@@ -877,7 +968,7 @@ extern "C" long cer_conv3x3_s16_packed_size(int Cout, const int* ch, const int* 
         if (kind[s] == 1) { ++nd; if (ch[s] != 49) return CER_ESHAPE; }
         else if (ch[s] % 32) return CER_ESHAPE;
     }
-    collapsed &= 1;                                        // (bit 1 = fp8-correction form: same size)
+    collapsed &= 1;                                        // (bit 1 = fp8-, bit 2 = FP6-correction form: same size)
     if (nd > 1 || (collapsed && nd == 0)) return CER_ESHAPE;
     return sx_steps(ch, kind, nsrc, collapsed) * (Cout / 32) * 1024;        // in halves
 }
@@ -1058,10 +1149,68 @@ static void sx_pack_chunk8(_Float16* packed, long cstep, int NT, int nt, const d
             }
 }
 
+// e2m3 (FP6: 1 sign, 2 exponent, 3 mantissa bits: 0, 0.125 .. 0.875, 1 .. 1.875, 2 .. 3.75, 4 .. 7.5), round to nearest even, saturating
+static unsigned sx_e2m3(double v) {
+    const unsigned sgn = v < 0 ? 32u : 0u;
+    const double a = fabs(v);
+    if (!(a == a)) return sgn | 31u;
+    if (a >= 7.5) return sgn | 31u;
+    const int E = a < 2.0 ? 0 : (a < 4.0 ? 1 : 2);          // steps of 0.125 (subnormals and [1, 2)), 0.25, 0.5
+    const int q = (int)nearbyint(ldexp(a, 3 - E));          // a in units of the step: 0..16 (E = 0), 8..16
+    if (E == 0) return sgn | (unsigned)q;                   // codes 0..15 are linear in the value (q = 16: code 16 = 2.0)
+    return sgn | (unsigned)(8 * E + q);                     // e = E + 1, m = q - 8 (q = 16 carries into the next exponent: 7.5 is the cap above)
+}
+
+// FP6-correction form of a tensor chunk step (round 6; 32 channels, one tap): 4 KiB per n-tile = f16 hi halves of half-chunk 0 | of
+// half-chunk 1 (as in the fp8 form) | bytes 0-15 | bytes 16-31 of every lane's A operand of v_mfma_scale_f32_32x32x64_f8f6f4 in its FP6 form:
+// lane (co = lane & 31, kg = lane >> 5): 32 six-bit e2m3 fields, field i at bit 6 i = [wl * 2^11 (8) | wh (8)] of half-chunk 0's channels
+// 8kg..8kg+7, then the same of half-chunk 1, all divided by ONE power of two t = 2^(e - 2) (e: exponent of the block's largest magnitude; one up
+// where that would land above 7.75) = 24 bytes; byte 24 = E8M0 of t * 2^-11 (the lane's scale operand: it undoes the 2^11 on BOTH correction
+// terms - the activations carry [xh | xl * 2^11] in the same positions), bytes 25-31 zero.
+static void sx_pack_chunk6(_Float16* packed, long cstep, int NT, int nt, const double* col /* [32 k][32 co] */, double scale) {
+    char* base = reinterpret_cast<char*>(packed) + (cstep * NT + nt) * 4096;
+    for (int lane = 0; lane < 64; ++lane) {
+        double f[32];
+        double mx = 0.0;
+        for (int hc = 0; hc < 2; ++hc)
+            for (int e = 0; e < 8; ++e) {
+                float v = (float)(col[(hc * 16 + (lane >> 5) * 8 + e) * 32 + (lane & 31)] * scale);
+                v = v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v);
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                reinterpret_cast<_Float16*>(base + hc * 1024)[lane * 8 + e] = hi;
+                f[hc * 16 + e] = ldexp((double)(float)lo, 11);
+                f[hc * 16 + 8 + e] = (double)(float)hi;
+                mx = fmax(mx, fmax(fabs(f[hc * 16 + e]), fabs(f[hc * 16 + 8 + e])));
+            }
+        int te = -100;                                       // t = 2^te
+        if (mx > 0.0) {
+            int e2;
+            frexp(mx, &e2);                                  // mx in [2^(e2-1), 2^e2)
+            te = e2 - 1 - 2;
+            if (ldexp(mx, -te) > 7.75) ++te;
+            if (te < -100) te = -100;
+        }
+        unsigned fields[32];
+        for (int i = 0; i < 32; ++i) fields[i] = sx_e2m3(ldexp(f[i], -te));
+        unsigned q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 32; ++i) {
+            const int bit = 6 * i;
+            q[bit >> 5] |= fields[i] << (bit & 31);
+            if ((bit & 31) > 26) q[(bit >> 5) + 1] |= fields[i] >> (32 - (bit & 31));
+        }
+        q[6] = (unsigned)(te - 11 + 127);
+        memcpy(base + 2048 + lane * 16, q, 16);
+        memcpy(base + 3072 + lane * 16, q + 4, 16);
+    }
+}
+
 extern "C" int cer_conv3x3_s16_pack(const float* w, void* packed_v, int Cout, int Cin, const int* ch, const int* kind, const int* log2sx,
                                     int nsrc, int collapsed, int log2S) {
     if (!w || !packed_v || !ch || !kind || !log2sx) return CER_EINVAL;
-    const int fp8 = (collapsed & 2) != 0;                   // tensor sources in the fp8-correction form (CER_EPI_CORR_FP8 launches)
+    if ((collapsed & 6) == 6) return CER_EINVAL;
+    const int fp6 = (collapsed & 4) != 0;                   // tensor sources in the FP6-correction form (CER_EPI_CORR_FP6 launches)
+    const int fp8 = (collapsed & 2) != 0 || fp6;            // ... in the fp8-correction form (CER_EPI_CORR_FP8 launches): same step structure
     collapsed &= 1;
     if (cer_conv3x3_s16_packed_size(Cout, ch, kind, nsrc, collapsed) < 0) return CER_ESHAPE;
     int order[CER_CONV_MAX_SRC], c0[CER_CONV_MAX_SRC];
@@ -1083,7 +1232,8 @@ extern "C" int cer_conv3x3_s16_pack(const float* w, void* packed_v, int Cout, in
                     for (int nt = 0; nt < NT; ++nt) {
                         for (int k = 0; k < 32; ++k)
                             for (int j = 0; j < 32; ++j) col32[k * 32 + j] = w[((long)(nt * 32 + j) * Cin + c0[s] + c32 * 32 + k) * 9 + tap];
-                        sx_pack_chunk8(packed, step / 2, NT, nt, col32, scale);
+                        if (fp6) sx_pack_chunk6(packed, step / 2, NT, nt, col32, scale);
+                        else sx_pack_chunk8(packed, step / 2, NT, nt, col32, scale);
                     }
         } else if (kind[s] != 1) {
             for (int g = 0; g < ch[s] / 16; ++g)
@@ -1209,8 +1359,10 @@ extern "C" int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, con
     if (!in || !log2sx || !packed_w || !out || h <= 0 || w <= 0 || Cout <= 0) return CER_EINVAL;
     if (in->nsrc <= 0 || in->nsrc > CER_CONV_MAX_SRC) return CER_EINVAL;
     const int out_split = (epi & CER_EPI_OUT_SPLIT) != 0;
-    const int corr_fp8 = (epi & CER_EPI_CORR_FP8) != 0;
-    epi &= ~(CER_EPI_OUT_SPLIT | CER_EPI_AUX_SPLIT | CER_EPI_CORR_FP8);
+    const int corr_fp6 = (epi & CER_EPI_CORR_FP6) != 0;
+    const int corr_fp8 = (epi & CER_EPI_CORR_FP8) != 0 || corr_fp6;       // (the FP6 form shares the fp8 form's structure and restrictions)
+    if ((epi & CER_EPI_CORR_FP8) && corr_fp6) return CER_EINVAL;
+    epi &= ~(CER_EPI_OUT_SPLIT | CER_EPI_AUX_SPLIT | CER_EPI_CORR_FP8 | CER_EPI_CORR_FP6);
     if (epi == CER_EPI_GATES && (!out2 || !aux || Cout != 128)) return CER_EINVAL;
     if (epi == CER_EPI_GRU && (!aux || !aux2)) return CER_EINVAL;
     if (epi == SX_EPI_DELTA && (!aux || Cout % 128 != 0)) return CER_EINVAL;
@@ -1291,6 +1443,7 @@ extern "C" int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, con
     if (Cout % 128 == 0) {
         int mt = tile_mt;
         if (mt != 2 && mt != 4) mt = pick(2, 2, 4, Cout / 128) == 2 ? 2 : 4;
+        if (corr_fp6) return mt == 2 ? sx_launch<1, 4, 2, 2>(a, epi, st) : sx_launch<1, 4, 4, 2>(a, epi, st);
         if (corr_fp8) return mt == 2 ? sx_launch<1, 4, 2, 1>(a, epi, st) : sx_launch<1, 4, 4, 1>(a, epi, st);
         return mt == 2 ? sx_launch<1, 4, 2, 0>(a, epi, st) : sx_launch<1, 4, 4, 0>(a, epi, st);
     }
@@ -1299,6 +1452,7 @@ extern "C" int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, con
     if (corr_fp8) {
         // (the 32-channel chunk buffers of a 16-row tile - 2 x 46 KiB - would leave room for one block per CU: 12 rows at most)
         if (mt < 2 || mt > 3) mt = pick(4, 2, 3, Cout / 64);
+        if (corr_fp6) return mt == 2 ? sx_launch<2, 2, 2, 2>(a, epi, st) : sx_launch<2, 2, 3, 2>(a, epi, st);
         return mt == 2 ? sx_launch<2, 2, 2, 1>(a, epi, st) : sx_launch<2, 2, 3, 1>(a, epi, st);
     }
     if (mt < 2 || mt > 4) mt = pick(4, 2, 4, Cout / 64);

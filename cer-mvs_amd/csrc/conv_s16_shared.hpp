@@ -37,6 +37,9 @@ typedef int intx8 __attribute__((ext_vector_type(8)));
 #ifndef SX_WRING3
 #define SX_WRING3 1  // the 64-output-channel fp8-correction kernels request their weight slices two chunk steps ahead (ring of three register slots)
 #endif
+#ifndef SX_WSPLIT
+#define SX_WSPLIT 1  // the fp8- / FP6-correction kernels with two weight slots refill a slot part by part behind the MFMA group that used the part
+#endif
 #ifndef SX_TRACE
 #define SX_TRACE 0   // variant builds only (tools/trace_s16.py): per wave cycle stamps + HW_ID written to `aux2` (GATES: unused there)
 #endif

@@ -191,9 +191,19 @@ extern "C" int cer_cost_lines1_stats(unsigned long long* out, int reset) {
 }
 #else
 #define CL_CLK() 0ull
-#define CL_STAT(i_, v_) do { } while (0)
+#define CL_STAT(i_, v_) do { (void)sizeof(v_); } while (0)
 #define CL_FLUSH() do { } while (0)
 #endif
+
+// The band of one (view, segment, line) tile: what cl_tile's chunk loop, projection and gather need to know about where the tile's samples
+// lie in the source map.  Round 6: computed by cost_lines_bands_kernel in a pass of its own (one WAVE per tile) instead of by wave 0 of
+// every tile block while its other three waves sat at a barrier (profiles/r05_cost_lines_phases.txt: 15.3 k of a tile's 68 k cycles).
+struct ClBand {
+    int smaj, nchunks, R, Wc, cmin, cmax, dir;      // nchunks < 0: the tile has no pixel (the tile block returns at once)
+    float bm, bl0;                                    // base row of band column c: floor(bl0 + bm * c)
+    int pad[3];
+};
+static_assert(sizeof(ClBand) == 48, "ClBand is read as three 16-byte pieces");
 
 struct ClArgs {
     const _Float16* f1s;      // [8 planes][P][16]   reference map of this call's pixel grid (cer_feat_split_f16 layout)
@@ -208,66 +218,19 @@ struct ClArgs {
     int shift, y0, tpv;
     int tpv8;                 // blocks per view of cost_lines8_kernel (8 lines x one segment each)
     unsigned long long* todo; // [0]: count, then (view, segment, line) of the lines cost_lines8_kernel left to the one-line form
+    ClBand* bands;            // [V][tpv] band records, indexed by (absolute view, tile order inside the view)
 };
 
-// One (view, segment, line) tile by a 256-thread block; every early return is block-uniform.
-__device__ __forceinline__ void cl_tile(const ClArgs& A, const int v, const int seg, const int jj) {
-    __shared__ __attribute__((aligned(16))) float prod[CL_T * 32];      // dots[texel of the chunk][pixel of the tile]
-    // per (hypothesis, pixel): {packed cell, fraction along the band, fraction across it, value}
-    //   packed: bits 0-15 band column of the cell + 4; bits 30-31 kind: 0 = samples through the band (bits 16-20 / 21-25: band row
-    //   of the cell in its own / the next column), 1 = zero (outside the map / non-finite), 2 = direct path (bits 16-29: cell row + 4)
-    extern __shared__ __attribute__((aligned(16))) float desc[];          // [D][CL_DP][4]
-    __shared__ int pidx[32];                                             // pixel index of tile slot i, or -1
-    __shared__ int bandI[8];
-    __shared__ float bandF[2];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, kg = lane >> 5;
-    const int h1 = A.h1, w1 = A.w1, h2 = A.h2, w2 = A.w2, D = A.D;
-    const unsigned long long cl_t0 = CL_CLK();
-#if CL_STATS
-    unsigned long long cl_acc[16] = {0};
-#endif
-    const int axis = (int)A.params[v * 4 + 0];
-    const float shear = A.params[v * 4 + 1];
-    const int La = axis ? h1 : w1, Hm = axis ? w1 : h1;     // extent along / across the tile axis
-    const int njm = Hm + 32;
-    if (jj >= njm) return;
-    const float cm = 0.5f * (float)La;
-    const int a_first = seg * 32, a_last = min(seg * 32 + 31, La - 1);
-    const int sh_f = (int)rintf(shear * ((float)a_first - cm)), sh_l = (int)rintf(shear * ((float)a_last - cm));
-    const int sh_lo = min(sh_f, sh_l), sh_hi = max(sh_f, sh_l);
-    const int j = jj - sh_hi;
-    if (j > Hm - 1 - sh_lo) return;
-    const int a_me = seg * 32 + li;                         // lanes l and l + 32 share pixel slot li (they own different hypotheses)
-    const int b_me = j + (int)rintf(shear * ((float)a_me - cm));
-    const bool valid = a_me < La && b_me >= 0 && b_me < Hm;
-    if (__ballot(valid) == 0ull) return;                    // (block-uniform: every wave sees the same 32 slots)
-    const int x_me = axis ? b_me : a_me, y_me = axis ? a_me : b_me;
-    const long p_me = (long)min(max(y_me, 0), h1 - 1) * w1 + min(max(x_me, 0), w1 - 1);
-    if (wave == 0 && lane < 32) pidx[lane] = valid ? (int)p_me : -1;
-
-    // ---- B fragments: the tile's 32 reference rows (lane: pixel slot li, channels 16 ks + 8 kg .. + 7), held for the whole
-    // tile-view; requested first: they arrive under the projections below
-    const long ps1 = (long)h1 * w1 * 16, ps2 = (long)(h2 + 4) * (w2 + 4) * 16;      // plane strides (halves) of the reference / source maps
-    const _Float16* f1t = A.f1s + p_me * 16;
-    half8 bh[4], bl[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        bh[ks] = *reinterpret_cast<const half8*>(f1t + ks * ps1 + 8 * kg);
-        bl[ks] = *reinterpret_cast<const half8*>(f1t + (4 + ks) * ps1 + 8 * kg);
-    }
-
-    // ---- this lane's pixel: origin (core/corr.py:59-62) and ray (utils/projective_ops.py:26-28)
-    const float* m = A.Pij + v * 16;
-    const float px = (float)x_me, py = (float)(y_me + A.y0);
-    float origin = A.disp_in[p_me];
-    if (A.shift && origin < A.lim) origin = A.lim;
-    const float a0 = fmaf(m[1], py, m[0] * px) + m[2], a1 = fmaf(m[5], py, m[4] * px) + m[6], a2 = fmaf(m[9], py, m[8] * px) + m[10];
-    const float m3 = m[3], m7 = m[7], m11 = m[11];
-    const int half = D / 2;
-    const float incre = A.incre;
-    auto project = [&](int k, float& u, float& w) -> bool {      // same fp32 expressions as cost_build.hip / the reference
+// ---- what a lane knows about its pixel slot of a (view, segment, line) tile: the pixel, its hypothesis origin (core/corr.py:59-62) and its
+// ray (utils/projective_ops.py:26-28).  Shared by the band pass and the tile kernel: the same expressions, so the same bits.
+struct ClLane {
+    bool valid;
+    int x_me, y_me;
+    long p_me;
+    float origin, a0, a1, a2, m3, m7, m11, incre;
+    int half;
+    // same fp32 expressions as cost_build.hip / the reference
+    __device__ __forceinline__ bool project(int k, float& u, float& w) const {
         const float hyp = __fadd_rn(__fmul_rn((float)(k - half), incre), origin);
         const float X = fmaf(m3, hyp, a0), Y = fmaf(m7, hyp, a1), Z = fmaf(m11, hyp, a2);
         u = X / Z;
@@ -276,19 +239,93 @@ __device__ __forceinline__ void cl_tile(const ClArgs& A, const int v, const int 
         u = fminf(fmaxf(u, -1e4f), 1e4f);
         w = fminf(fmaxf(w, -1e4f), 1e4f);
         return ok;
-    };
+    }
+};
+// the pixel of slot li (lanes l and l + 32 share it); false: the tile has no pixel at all (wave-uniform, and the same in every wave)
+__device__ __forceinline__ bool cl_lane_pixel(const ClArgs& A, int v, int seg, int jj, int li, ClLane& L) {
+    const int h1 = A.h1, w1 = A.w1;
+    const int axis = (int)A.params[v * 4 + 0];
+    const float shear = A.params[v * 4 + 1];
+    const int La = axis ? h1 : w1, Hm = axis ? w1 : h1;     // extent along / across the tile axis
+    const int njm = Hm + 32;
+    if (jj >= njm) return false;
+    const float cm = 0.5f * (float)La;
+    const int a_first = seg * 32, a_last = min(seg * 32 + 31, La - 1);
+    const int sh_f = (int)rintf(shear * ((float)a_first - cm)), sh_l = (int)rintf(shear * ((float)a_last - cm));
+    const int sh_lo = min(sh_f, sh_l), sh_hi = max(sh_f, sh_l);
+    const int j = jj - sh_hi;
+    if (j > Hm - 1 - sh_lo) return false;
+    const int a_me = seg * 32 + li;
+    const int b_me = j + (int)rintf(shear * ((float)a_me - cm));
+    L.valid = a_me < La && b_me >= 0 && b_me < Hm;
+    if (__ballot(L.valid) == 0ull) return false;
+    L.x_me = axis ? b_me : a_me;
+    L.y_me = axis ? a_me : b_me;
+    L.p_me = (long)min(max(L.y_me, 0), h1 - 1) * w1 + min(max(L.x_me, 0), w1 - 1);
+    return true;
+}
+__device__ __forceinline__ void cl_lane_ray(const ClArgs& A, int v, ClLane& L) {
+    const float* m = A.Pij + v * 16;
+    const float px = (float)L.x_me, py = (float)(L.y_me + A.y0);
+    float origin = A.disp_in[L.p_me];
+    if (A.shift && origin < A.lim) origin = A.lim;
+    L.origin = origin;
+    L.a0 = fmaf(m[1], py, m[0] * px) + m[2];
+    L.a1 = fmaf(m[5], py, m[4] * px) + m[6];
+    L.a2 = fmaf(m[9], py, m[8] * px) + m[10];
+    L.m3 = m[3]; L.m7 = m[7]; L.m11 = m[11];
+    L.half = A.D / 2;
+    L.incre = A.incre;
+}
 
-    // ---- band analysis, by wave 0 (the other waves wait for its nine numbers: ~600 instructions they do not have to issue).
-    // End points of every pixel's segment: lanes with kg = 0 project hypothesis 0, lanes with kg = 1 hypothesis D - 1, and the
-    // halves swap
+// (view, tile order inside the view) of the o-th tile of a launch that builds views v0 ..: groups of CL_LG lines x all segments, so that
+// the ~100 tiles an XCD works on at a time cover a compact patch (16 lines x 6 segments: ~2 MB of band rows) instead of 100 lines of one
+// segment (6 MB: its 4 MB L2 thrashed)
+__device__ __forceinline__ void cl_decode(const ClArgs& A, unsigned o, int& v, int& rem, int& seg, int& jj) {
+    v = A.v0 + (int)(o / (unsigned)A.tpv);
+    rem = (int)(o % (unsigned)A.tpv);
+    const int axis = (int)A.params[v * 4 + 0];
+    const int La = axis ? A.h1 : A.w1;
+    const int nseg = (La + 31) >> 5;
+    const int lg = (int)((unsigned)rem / (unsigned)(nseg * CL_LG)), rem2 = rem - lg * nseg * CL_LG;
+    seg = rem2 / CL_LG;
+    jj = lg * CL_LG + (rem2 - seg * CL_LG);
+}
+
+// tile order inside its view of (segment, line) - the inverse of cl_decode (the hand-over list of the experimental multi-line form)
+__device__ __forceinline__ int cl_rem(const ClArgs& A, int v, int seg, int jj) {
+    const int axis = (int)A.params[v * 4 + 0];
+    const int nseg = ((axis ? A.h1 : A.w1) + 31) >> 5;
+    const int lg = jj / CL_LG;
+    return lg * nseg * CL_LG + seg * CL_LG + (jj - lg * CL_LG);
+}
+
+// ---- band pass (round 6): one WAVE per tile derives the tile's band - major axis, reference line, rows across, column range, travel
+// direction - from the end points of every pixel's segment: lanes with kg = 0 project hypothesis 0, lanes with kg = 1 hypothesis D - 1,
+// and the halves swap; eight DPP wave reductions; one 48-byte record per tile.  43 680 tiles at the bench size: ~600 instructions per
+// wave, no barrier, nothing waits for anybody.
+__global__ __launch_bounds__(256) void cost_lines_bands_kernel(const ClArgs A, unsigned ntiles) {
+    const unsigned o = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (o >= ntiles) return;
+    const int lane = threadIdx.x & 63, li = lane & 31, kg = lane >> 5;
+    int v, rem, seg, jj;
+    cl_decode(A, o, v, rem, seg, jj);
+    ClBand* rec = A.bands + (long)v * A.tpv + rem;
+    ClLane L;
+    if (!cl_lane_pixel(A, v, seg, jj, li, L)) {
+        if (lane == 0) rec->nchunks = -1;
+        return;
+    }
+    cl_lane_ray(A, v, L);
+    const int h2 = A.h2, w2 = A.w2, D = A.D;
+    const bool valid = L.valid;
     int smaj = 0, nchunks = 0, R = 1, Wc = 1, cmin = 0, cmax = 0, dir = 1;
-    float bm = 0.f, bl0 = 0.f;                               // base row of band column c: floor(bl0 + bm * c)
-    if (wave == 0) {
+    float bm = 0.f, bl0 = 0.f;
     float ua, wa, ub, wb;
     bool part0;
     {
         float ue, we;
-        const bool oke = project(kg ? D - 1 : 0, ue, we);
+        const bool oke = L.project(kg ? D - 1 : 0, ue, we);
         const float uo = __shfl_xor(ue, 32), wo = __shfl_xor(we, 32);
         const bool oko = ((__ballot(oke) >> (lane ^ 32)) & 1ull) != 0ull;
         ua = kg ? uo : ue; wa = kg ? wo : we;
@@ -351,15 +388,56 @@ __device__ __forceinline__ void cl_tile(const ClArgs& A, const int v, const int 
         }
     }
     if (lane == 0) {
-        bandI[0] = smaj; bandI[1] = nchunks; bandI[2] = R; bandI[3] = Wc; bandI[4] = cmin; bandI[5] = cmax; bandI[6] = dir;
-        bandF[0] = bm; bandF[1] = bl0;
+        ClBand r;
+        r.smaj = smaj; r.nchunks = nchunks; r.R = R; r.Wc = Wc; r.cmin = cmin; r.cmax = cmax; r.dir = dir;
+        r.bm = bm; r.bl0 = bl0;
+        r.pad[0] = r.pad[1] = r.pad[2] = 0;
+        *rec = r;
     }
+}
+
+// One (view, segment, line) tile by a 256-thread block; every early return is block-uniform.  `rem`: the tile's order inside its view
+// (its band record is A.bands[v * tpv + rem]).
+__device__ __forceinline__ void cl_tile(const ClArgs& A, const int v, const int rem, const int seg, const int jj) {
+    __shared__ __attribute__((aligned(16))) float prod[CL_T * 32];      // dots[texel of the chunk][pixel of the tile]
+    // per (hypothesis, pixel): {packed cell, fraction along the band, fraction across it, value}
+    //   packed: bits 0-15 band column of the cell + 4; bits 30-31 kind: 0 = samples through the band (bits 16-20 / 21-25: band row
+    //   of the cell in its own / the next column), 1 = zero (outside the map / non-finite), 2 = direct path (bits 16-29: cell row + 4)
+    extern __shared__ __attribute__((aligned(16))) float desc[];          // [D][CL_DP][4]
+    __shared__ int pidx[32];                                             // pixel index of tile slot i, or -1
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kg = lane >> 5;
+    const int h1 = A.h1, w1 = A.w1, h2 = A.h2, w2 = A.w2, D = A.D;
+    const unsigned long long cl_t0 = CL_CLK();
+#if CL_STATS
+    unsigned long long cl_acc[16] = {0};
+#endif
+    // ---- the tile's band (cost_lines_bands_kernel): a uniform address - scalar loads, requested before anything else
+    const ClBand* rec = A.bands + (long)v * A.tpv + rem;
+    int smaj = rec->smaj, nchunks = rec->nchunks, R = rec->R, Wc = rec->Wc, cmin = rec->cmin, cmax = rec->cmax, dir = rec->dir;
+    float bm = rec->bm, bl0 = rec->bl0;
+    ClLane L;
+    if (!cl_lane_pixel(A, v, seg, jj, li, L)) return;       // (lanes l and l + 32 share pixel slot li: they own different hypotheses)
+    const bool valid = L.valid;
+    const long p_me = L.p_me;
+    if (wave == 0 && lane < 32) pidx[lane] = valid ? (int)p_me : -1;
+
+    // ---- first hop, all in one round trip: the pixel's origin (the projections below wait for it), the B fragments - the tile's 32
+    // reference rows (lane: pixel slot li, channels 16 ks + 8 kg .. + 7), held for the whole tile - and the first chunk's A fragments
+    cl_lane_ray(A, v, L);
+    const long ps1 = (long)h1 * w1 * 16, ps2 = (long)(h2 + 4) * (w2 + 4) * 16;      // plane strides (halves) of the reference / source maps
+    const _Float16* f1t = A.f1s + p_me * 16;
+    half8 bh[4], bl[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        bh[ks] = *reinterpret_cast<const half8*>(f1t + ks * ps1 + 8 * kg);
+        bl[ks] = *reinterpret_cast<const half8*>(f1t + (4 + ks) * ps1 + 8 * kg);
     }
-    __syncthreads();
+    auto project = [&](int k, float& u, float& w) -> bool { return L.project(k, u, w); };
+
     const unsigned long long cl_t1 = CL_CLK();
     CL_STAT(0, 1); CL_STAT(3, cl_t1 - cl_t0);
-    smaj = bandI[0]; nchunks = bandI[1]; R = bandI[2]; Wc = bandI[3]; cmin = bandI[4]; cmax = bandI[5]; dir = bandI[6];
-    bm = bandF[0]; bl0 = bandF[1];
     smaj = __builtin_amdgcn_readfirstlane(smaj);
     const int Wmaj = smaj ? h2 : w2, Wmin = smaj ? w2 : h2;
     const int wp = w2 + 4;
@@ -538,16 +616,9 @@ __device__ __forceinline__ unsigned cl_xcd_order() {
 // D <= 44 would fit 4 blocks per CU, but at 128 VGPRs the kernel spills and was measured slower (1.14 vs 1.04 ms)
 template <int OCC>
 __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
-    const unsigned o = cl_xcd_order();
-    const int v = A.v0 + (int)(o / (unsigned)A.tpv), rem = (int)(o % (unsigned)A.tpv);
-    const int axis = (int)A.params[v * 4 + 0];
-    const int La = axis ? A.h1 : A.w1;
-    // tile order inside a view: groups of CL_LG lines x all segments, so that the ~100 tiles an XCD works on at a time cover a
-    // compact patch (16 lines x 6 segments: ~2 MB of band rows) instead of 100 lines of one segment (6 MB: its 4 MB L2 thrashed)
-    const int nseg = (La + 31) >> 5;
-    const int lg = (int)((unsigned)rem / (unsigned)(nseg * CL_LG)), rem2 = rem - lg * nseg * CL_LG;
-    const int seg = rem2 / CL_LG, jj = lg * CL_LG + (rem2 - seg * CL_LG);
-    cl_tile(A, v, seg, jj);
+    int v, rem, seg, jj;
+    cl_decode(A, cl_xcd_order(), v, rem, seg, jj);
+    cl_tile(A, v, rem, seg, jj);
 }
 
 #ifndef CER_WITH_LINES8
@@ -598,7 +669,8 @@ static long cl_tiles_per_view(int h1, int w1) {               // one-line tiles 
 extern "C" long cer_cost_lines_workspace(int V, int h1, int w1, int D) {
     if (V <= 0 || h1 <= 0 || w1 <= 0 || D <= 0) return CER_EINVAL;
     // per-view partial volumes | tile parameters | per view: a count + one entry per one-line tile (the lines the eight-line kernel hands over)
-    return (long)V * h1 * w1 * D * 4 + (long)V * 16 + 256 + (long)V * (cl_tiles_per_view(h1, w1) + 1) * 8 + 64;
+    return (long)V * h1 * w1 * D * 4 + (long)V * 16 + 256 + (long)V * (cl_tiles_per_view(h1, w1) + 1) * 8 + 64
+           + (long)V * cl_tiles_per_view(h1, w1) * (long)sizeof(ClBand) + 64;      // (round 6: + one band record per tile)
 }
 
 #if CER_WITH_LINES8
@@ -665,7 +737,13 @@ extern "C" int cer_cost_lines_views_f32(const void* fmap1_split, const void* fma
         t = (t + 63) & ~(uintptr_t)63;
         a.todo = (unsigned long long*)t + (long)v0 * (a.tpv + 1);     // this call's views own this stretch of the list
     }
+    {   // band records behind the list, [V][tpv]: indexed by the ABSOLUTE view, so launches for different view ranges never collide
+        uintptr_t t = (uintptr_t)((unsigned long long*)(((uintptr_t)(params + (long)V * 4) + 63) & ~(uintptr_t)63) + (long)V * (a.tpv + 1));
+        a.bands = (ClBand*)((t + 63) & ~(uintptr_t)63);
+    }
     a.tpv8 = 0;
+    hipLaunchKernelGGL(cost_lines_bands_kernel, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, st, a, (unsigned)nblk);
+    CER_RETURN_IF_LAUNCH_FAILED();
 #if CER_WITH_LINES8
     if (cer_cost_lines_form(-1) == 1) {
         // NW lines x one segment per block; lines whose bands do not fit its window are listed and done in the one-line form

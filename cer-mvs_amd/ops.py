@@ -599,7 +599,7 @@ class PackedConvS16:
         w = weight.detach().to("cpu", torch.float32).contiguous()
         Cout, Cin = w.shape[0], w.shape[1]
         self.sources = list(sources)
-        self.corr_fp8 = bool(corr_fp8)      # tensor sources packed for CER_EPI_CORR_FP8 launches (cer_mvs.h)
+        self.corr_fp8 = 6 if corr_fp8 == 6 else int(bool(corr_fp8))      # 1: tensor sources packed for CER_EPI_CORR_FP8 launches, 6: for CER_EPI_CORR_FP6 (cer_mvs.h)
         n = len(sources)
         self.ch = (ctypes.c_int * n)(*[c for c, _, _ in sources])
         self.kind = (ctypes.c_int * n)(*[k for _, k, _ in sources])
@@ -616,7 +616,7 @@ class PackedConvS16:
                 raise RuntimeError(f"conv3x3_s16 pack: unsupported shape Cout={Cout} sources={sources}")
             t = torch.empty(size, dtype=torch.float16)
             L.check(lib.cer_conv3x3_s16_pack(wp, ctypes.c_void_p(t.data_ptr()), Cout, Cin, self.ch, self.kind, self.log2sx, n,
-                                             collapsed | (2 if self.corr_fp8 else 0), self.log2S), "conv3x3_s16_pack")
+                                             collapsed | (4 if self.corr_fp8 == 6 else 2 if self.corr_fp8 else 0), self.log2S), "conv3x3_s16_pack")
             return t.to(device)
         self.packed = pack(0)
         self.packed_c, self.edge = None, None
@@ -685,7 +685,7 @@ def conv3x3_s16(pc, srcs, h, w, epi, out=None, out2=None, aux=None, aux2=None, i
     edge = L.dev_ptr(pc.edge, "edge_w", torch.float16) if (EDGE_CORRECT and coll is not None) else None
     flags = L.EPI_OUT_SPLIT if (out_split or epi in (L.EPI_RELU, L.EPI_GATES, L.EPI_GRU)) else 0
     if pc.corr_fp8:
-        flags |= L.EPI_CORR_FP8
+        flags |= L.EPI_CORR_FP6 if pc.corr_fp8 == 6 else L.EPI_CORR_FP8
     rc = L.load().cer_conv3x3_s16(ctypes.byref(ci), pc.log2sx, L.dev_ptr(pc.packed, "packed_w", torch.float16), coll, edge, pc.log2S,
                                   L.dev_ptr(bias, "bias"), L.dev_ptr(init, "init"), L.dev_ptr(out, "out"), L.dev_ptr(out2, "out2"), aux_p,
                                   L.dev_ptr(aux2, "aux2"), h, w, pc.cout, epi | flags, int(log2s_out), int(log2s_aux), int(TILE_MT),

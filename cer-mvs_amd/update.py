@@ -128,7 +128,7 @@ class UpdateBlock(nn.Module):
 
     def packed(self, stage, device):
         """Packed weights for ``stage`` on ``device`` (built once, cached)."""
-        f8 = bool(self.corr_fp8)
+        f8 = 6 if self.corr_fp8 == 6 else bool(self.corr_fp8)      # (False: three f16 terms, True: fp8 corrections, 6: FP6 corrections)
         key = (stage, str(device), self.conv_mode, f8)  # (the dict's contents depend on the arithmetic mode: s16 packs exist only for "s16")
         if key in self._packed:
             return self._packed[key]

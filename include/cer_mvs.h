@@ -231,6 +231,10 @@ int cer_lookup_encode_f32(const float* vol, const float* origin, float* disp,
 /* cer_conv3x3_s16 only: the weights were packed with `collapsed | 2` and the two correction terms of the split-f16 product of the
  * TENSOR sources (xh*wl + xl*wh, 2^-11 of the main term) run on the block-scaled fp8 matrix instruction (twice the f16 rate). */
 #define CER_EPI_CORR_FP8 0x400
+/* cer_conv3x3_s16 only (round 6): the weights were packed with `collapsed | 4` and the same two correction terms run on the FP6 (e2m3) form of
+ * that instruction - half its matrix-pipe passes again - with one E8M0 scale per K block of 16 channels x [hi | lo] on either operand
+ * (activations: per pixel, chosen while the halo tile is staged; weights: per output channel and tap, chosen by the packer). */
+#define CER_EPI_CORR_FP6 0x800
 #define CER_EPI_DELTA 4   /* cer_conv3x3_f16x3 only - see cer_delta_proj_pack */
 
 typedef struct {
@@ -296,7 +300,9 @@ int cer_conv3x3_f16x3(const cer_conv_inputs* in, const void* packed_w, const voi
  * (collapsed = 0) or collapsed (= 1, needs a kind-1 source; used by interior tiles) packing, size in 2-byte halves from
  * cer_conv3x3_s16_packed_size.  HOST pointers.  `collapsed | 2`: the tensor sources' steps in the fp8-correction form (for launches
  * with CER_EPI_CORR_FP8: per 32-channel tap and 32 output channels 4 KiB = f16 hi halves of the two 16-channel halves | the e4m3
- * A operand of v_mfma_scale_f32_32x32x64_f8f6f4: [lo * 2^5 | hi * 2^-6] of each half); same size.  A launch with CER_EPI_CORR_FP8
+ * A operand of v_mfma_scale_f32_32x32x64_f8f6f4: [lo * 2^5 | hi * 2^-6] of each half); same size.  `collapsed | 4` (round 6): the FP6 form for
+ * launches with CER_EPI_CORR_FP6 (the instruction's e2m3 A operand: 32 six-bit fields [lo * 2^11 | hi] of each half over one power of two per
+ * lane, whose E8M0 byte follows the 24 bytes of fields; csrc/conv_s16.hip sx_pack_chunk6); same size.  A launch with CER_EPI_CORR_FP8 / _FP6
  * and a kind-1 source needs packed_collapsed AND edge_w (the fp8 kernels evaluate the disparity source in the collapsed form with
  * the rim correction only; CER_ESHAPE otherwise); tile_mt = 4 is not available for Cout = 64 in that form (3 is used).
  * cer_conv3x3_s16: bias (fp32 [Cout], plain) or init (acc32 [., Cout]) - at most one - seed the accumulators; epilogues:

@@ -28,19 +28,22 @@ def tile_mt():
     ops.TILE_MT = 0
 
 
-@pytest.fixture(params=[False, True], ids=["f16x3terms", "fp8corr"])
+@pytest.fixture(params=[False, True, 6], ids=["f16x3terms", "fp8corr", "fp6corr"])
 def f8(request, monkeypatch):
-    """Both arithmetic forms of the tensor sources: three f16 MFMAs per product, or the two correction terms on the fp8 matrix
-    instruction (CER_EPI_CORR_FP8, gru_precision="s16f8").  Yields the factor by which the fp32-class tolerances widen: the fp8
-    operands carry the 2^-11 correction terms with 2^-4 relative precision, i.e. 2^-15..2^-16 of a product."""
+    """The three arithmetic forms of the tensor sources: three f16 MFMAs per product, the two correction terms on the fp8 matrix
+    instruction (CER_EPI_CORR_FP8, gru_precision="s16f8"), or on its FP6 form with one E8M0 scale per 16-channel block (round 6:
+    CER_EPI_CORR_FP6, gru_precision="s16f6").  Yields the factor by which the fp32-class tolerances widen: the 8- / 6-bit operands carry the
+    2^-11 correction terms with 2^-4 relative precision (FP6: relative to the block maximum for the small elements of a block), i.e.
+    2^-15..2^-16 of a product."""
     from cer_mvs_amd import ops
     if request.param:
         orig = ops.PackedConvS16.__init__
+        form = request.param
 
-        def init(self, weight, bias, sources, device, corr_fp8=True):
+        def init(self, weight, bias, sources, device, corr_fp8=form):
             orig(self, weight, bias, sources, device, corr_fp8=corr_fp8)
         monkeypatch.setattr(ops.PackedConvS16, "__init__", init)
-    return 30.0 if request.param else 1.0
+    return {False: 1.0, True: 30.0, 6: 45.0}[request.param]
 
 
 def frag(x, h, w, log2s):

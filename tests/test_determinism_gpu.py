@@ -46,7 +46,7 @@ def _repeat(fn, n=LAUNCHES):
 
 @pytest.mark.parametrize("size", [(74, 100), (296, 400)], ids=["quarter", "bench"])
 @pytest.mark.parametrize("mt", [2, 4])
-@pytest.mark.parametrize("f8", [False, True], ids=["s16", "s16f8"])
+@pytest.mark.parametrize("f8", [False, True, 6], ids=["s16", "s16f8", "s16f6"])
 def test_update_block_convs_are_deterministic(dev, f8, mt, size):
     """z|r gates, GRU blend, fused delta head, ReLU conv (corr2 shape) and the hoisted linear conv - rim tiles, interior tiles, partial
     last tiles - 200 launches each, every output bit-identical to the first launch's."""
@@ -408,3 +408,15 @@ def test_auto_precision_is_decided_on_the_worst_of_the_first_inputs(dev):
         assert auto.auto_choice == "s16" and not auto._auto_pending()
         assert torch.equal(out, ref_hard)                                   # the harder input already got the fp32-class result
         assert torch.equal(auto(*hard, scale=scale).cpu(), ref_hard)
+        # round 6: the calibration walks a LIST of candidates.  With the FP6-correction form in front (not a default candidate: DESIGN.md 3n)
+        # the easy input keeps it or demotes to the fp8 form - whichever is inside the tolerance on it - and the hard input ends on "s16"
+        m6 = make("s16f6")
+        e6 = rel_l1(m6(*easy, scale=scale).cpu(), m16(*easy, scale=scale).cpu())
+        walk = make("auto")
+        walk.AUTO_FORMS = ("s16f6", "s16f8", "s16")
+        walk.update_block.corr_fp8 = 6
+        o_easy = walk(*easy, scale=scale).cpu()
+        print(f"FP6-correction vs all-f16 form on the first input: {e6:.2e}; the walk kept {walk.auto_choice}")
+        assert walk.auto_choice == ("s16f6" if e6 <= RAFT.AUTO_TOL else "s16f8") and walk._auto_pending()
+        assert torch.equal(o_easy, (m6 if walk.auto_choice == "s16f6" else m8)(*easy, scale=scale).cpu())
+        assert torch.equal(walk(*hard, scale=scale).cpu(), ref_hard) and walk.auto_choice == "s16" and not walk._auto_pending()

@@ -915,15 +915,16 @@ def test_end_to_end_tiny_literal_api(dev, golden):
     assert e_disp < TOL and e_depth < TOL
 
 
-@pytest.mark.parametrize("gru_precision", ["s16f8", "s16", "f16x3", "fp32"])
+@pytest.mark.parametrize("gru_precision", ["s16f6", "s16f8", "s16", "f16x3", "fp32"])
 def test_end_to_end_cfg1(dev, golden, gru_precision):
     """BASELINE.json configs[0] shape: 640x480, 1 ref + 2 src views, 4 GRU iterations."""
     e_disp, e_depth = _run_e2e(dev, golden, "e2e_cfg1", gru_precision=gru_precision)
     print(f"e2e_cfg1[{gru_precision}] rel-L1 disp {e_disp:.3e} depth {e_depth:.3e}")
     assert e_disp < TOL and e_depth < TOL
     # tighter than the bar, per arithmetic: a wrong scale or a lost correction term in one of the forms must not hide under 1e-4
-    # (measured: s16f8 3.9e-6 / 4.1e-6 - the e4m3 correction terms; the all-f16 and fp32 forms 1.9e-7 ... 2.2e-7)
-    assert max(e_disp, e_depth) < (2e-5 if gru_precision == "s16f8" else 2e-6)
+    # (measured: s16f8 3.9e-6 / 4.1e-6 - the e4m3 correction terms; s16f6, round 6: e2m3 with block scales, costed at 5.5e-6 by
+    # tools/experiments/fp8_correction_numerics.py and gated at 1.5e-5 by VERDICT r5; the all-f16 and fp32 forms 1.9e-7 ... 2.2e-7)
+    assert max(e_disp, e_depth) < {"s16f8": 2e-5, "s16f6": 1.5e-5}.get(gru_precision, 2e-6)
 
 
 def test_end_to_end_cfg2_bench_workload(dev, golden):
@@ -1070,7 +1071,7 @@ def test_slab_forward_over_rccl_single_rank(dev, golden):
     assert rel_l1(out.cpu(), torch.from_numpy(g["disp"])) < TOL
 
 
-@pytest.mark.parametrize("gru_precision", ["s16f8", "s16", "f16x3", "fp32"])
+@pytest.mark.parametrize("gru_precision", ["s16f6", "s16f8", "s16", "f16x3", "fp32"])
 def test_odd_image_size_vs_oracle(dev, gru_precision):
     """h1, w1 not multiples of the 8x16 conv tile, V = 1; every arithmetic mode of the update block."""
     from cer_mvs_amd import RAFT

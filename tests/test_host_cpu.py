@@ -67,9 +67,10 @@ def test_argument_errors_without_device():
     assert lib.cer_feat_split_f16(null, null, 1, 10, 64, null, null) == -1
     assert lib.cer_feat_split_f16(fake, fake, 1, 10, 32, null, null) == -2                                     # C != 64
     assert lib.cer_feat_split_f16(misaligned, fake, 1, 10, 64, null, null) == -3
-    # partial volumes + tile parameters + the hand-over list of the eight-line form (one entry per one-line tile of a view)
+    # partial volumes + tile parameters + the hand-over list of the eight-line form (one entry per one-line tile of a view) + (round 6) one
+    # 48-byte band record per tile (cost_lines_bands_kernel)
     tiles = max(13 * ((296 + 32 + 15) // 16 * 16), 10 * ((400 + 32 + 15) // 16 * 16))
-    assert lib.cer_cost_lines_workspace(10, 296, 400, 64) == 10 * 296 * 400 * 64 * 4 + 10 * 16 + 256 + 10 * (tiles + 1) * 8 + 64
+    assert lib.cer_cost_lines_workspace(10, 296, 400, 64) == 10 * 296 * 400 * 64 * 4 + 10 * 16 + 256 + 10 * (tiles + 1) * 8 + 64 + 10 * tiles * 48 + 64
     assert lib.cer_cost_lines_workspace(0, 1, 1, 1) == -1
     if _lib.has_variant_forms():    # (variants/libcermvs_optin.so: the switch of round 4's multi-line form)
         prev = lib.cer_cost_lines_form(-1)

@@ -19,7 +19,10 @@ def main():
     ap.add_argument("--mt", type=int, default=4)
     ap.add_argument("--conv", default="zr", choices=["zr", "q"])
     ap.add_argument("--f8", action="store_true", help="fp8-correction form (CER_EPI_CORR_FP8): stamps after every 32-channel chunk")
+    ap.add_argument("--f6", action="store_true", help="FP6-correction form (CER_EPI_CORR_FP6, round 6): same stamps as --f8")
     args = ap.parse_args()
+    if args.f6:
+        args.f8 = 6
     h, w = (int(x) for x in args.size.split("x"))
     P = h * w
     dev = torch.device("cuda")
