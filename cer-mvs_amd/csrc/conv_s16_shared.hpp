@@ -38,7 +38,11 @@ typedef int intx8 __attribute__((ext_vector_type(8)));
 #define SX_WRING3 1  // the 64-output-channel fp8-correction kernels request their weight slices two chunk steps ahead (ring of three register slots)
 #endif
 #ifndef SX_WSPLIT
-#define SX_WSPLIT 1  // the fp8- / FP6-correction kernels with two weight slots refill a slot part by part behind the MFMA group that used the part
+#define SX_WSPLIT 0  // 1: the fp8- / FP6-correction kernels with two weight slots refill a slot part by part behind the MFMA group that used the part
+                     // (every part gets 1 2/3 taps between request and use instead of 1 .. 1 2/3).  Round 6, same-box A/B (profiles/r06_wsplit_ab.txt):
+                     // z|r stand-alone 98.4-99.4 against 101.8-102.7 us in the fp8 form but 95.6 against 92.6 in the FP6 form, delta 78.7 against
+                     // 77.0; inside the forward 95.5-96.1 against 96.2-96.4 us and the same depth maps per second - and 16 spilled registers
+                     // (outside the chunk loop) where the default has none.  Off.
 #endif
 #ifndef SX_TRACE
 #define SX_TRACE 0   // variant builds only (tools/trace_s16.py): per wave cycle stamps + HW_ID written to `aux2` (GATES: unused there)
