@@ -1425,7 +1425,7 @@ extern "C" int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, con
         }
         return best_mt;
     };
-#ifdef SX_PROBE          // probe builds (tools/r05/mkprobe.sh): ONE kernel configuration - the 64-output-channel fp8-correction form - compiled in seconds
+#ifdef SX_PROBE          // probe builds (tools/archive/r05/mkprobe.sh): ONE kernel configuration - the 64-output-channel fp8-correction form - compiled in seconds
     return sx_launch<2, 2, 2, 1>(a, epi, st);
 #else
     // the fp8-correction kernels evaluate a disparity source in the collapsed form with the rim correction only

@@ -162,8 +162,8 @@ __device__ __noinline__ float cl_direct(const _Float16* __restrict__ f1t, long p
     return d[0] * (wn0 * wm0) + d[1] * (wn0 * wm1) + d[2] * (wn1 * wm0) + d[3] * (wn1 * wm1);
 }
 
-// ---- cycle statistics of the one-line kernel (variant build -DCL_STATS=1: tools/r05/mkvariant.sh clstats cost_lines.hip -DCL_STATS=1;
-// tools/r05/stats_cost_lines1.py).  Wave 0's view of a tile's phases, summed over all tiles with atomics.
+// ---- cycle statistics of the one-line kernel (variant build -DCL_STATS=1: tools/archive/r05/mkvariant.sh clstats cost_lines.hip -DCL_STATS=1;
+// tools/archive/r05/stats_cost_lines1.py).  Wave 0's view of a tile's phases, summed over all tiles with atomics.
 #ifndef CL_STATS
 #define CL_STATS 0
 #endif

@@ -34,7 +34,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define PC_ABL 0                       // profiling ablations (variant builds only): 1 no MFMAs, 2 no output stores, 4 no operand transform (halves of the raw bits)
 #endif
 #ifndef PC_TRACE
-#define PC_TRACE 0                     // debug build: per-wave phase cycle sums written to a.out2 [blocks][8 waves][8] (u64); tools/trace_pc.py
+#define PC_TRACE 0                     // debug build: per-wave phase cycle sums written to a.out2 [blocks][8 waves][8] (u64); tools/archive/trace_pc.py
 #endif
 #if PC_TRACE
 #define PC_T(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tsum[k] += now_ - tlast; tlast = now_; } while (0)

@@ -31,7 +31,7 @@
 #include "conv_s16_shared.hpp"
 
 #ifndef SXPC_TRACE
-#define SXPC_TRACE 0 // variant build (tools/trace_sxpc.py): per wave phase cycle sums written to aux2 of a GATES launch [blocks][8 waves][16] (u64)
+#define SXPC_TRACE 0 // variant build (tools/archive/trace_sxpc.py): per wave phase cycle sums written to aux2 of a GATES launch [blocks][8 waves][16] (u64)
 #endif
 #if SXPC_TRACE
 #define SXPC_T(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tsum[k] += now_ - tlast; tlast = now_; } while (0)

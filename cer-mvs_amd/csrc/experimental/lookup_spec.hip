@@ -1,7 +1,7 @@
 // EXPERIMENT (not part of libcermvs.so): the lookup kernel with the round-2 compile-time specialisation (3 x 11 windows and the 33-deep 1x1 conv
 // unrolled, packed FMAs) that was removed in round 2 after it produced intermittently wrong features when a second process shared the GPU.
 // Restored from the repository's own history (commit f55ed20^) in round 4 to reproduce and root-cause that failure:
-//   make -C cer-mvs_amd/csrc variants/libcermvs_lkspec.so ; tools/repro_lookup_spec.sh
+//   make -C cer-mvs_amd/csrc variants/libcermvs_lkspec.so ; tools/archive/repro_lookup_spec.sh
 // K2: multi-level correlation lookup (reference: CorrBlock.__call__ core/corr.py:102-143 and
 // bilinear_sampler1 utils/bilinear_sampler.py:6-25 - 528 grid_sample launches per GRU iteration in
 // the reference), optionally fused with the view mean (core/update.py:103) and the first

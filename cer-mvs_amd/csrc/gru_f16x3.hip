@@ -55,7 +55,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define HX_EPI_DELTA 4                 // conv + ReLU + projection onto the 9 taps of the 256->1 delta conv (cer_mvs.h: CER_EPI_DELTA)
 #define HX_HS 272                      // LDS bytes per pixel row of the hidden tile (128 f16 + 16 pad: conflict-free b128 reads)
 
-// HX_TRACE (debug builds only, tools/trace_conv.py): per (block, wave, step) cycle stamps written to `aux2`, which the traced
+// HX_TRACE (debug builds only, tools/archive/trace_conv.py): per (block, wave, step) cycle stamps written to `aux2`, which the traced
 // epilogue (GATES) does not use: [0] loop top, [1] after the barrier, [2] after the first k16-step, [3] end of the step; slot
 // 63 of each wave holds (kernel entry, main loop start, main loop end, kernel end) and slot 62 the HW_ID register.
 #ifndef HX_TRACE

@@ -3,9 +3,9 @@
 The reference's ``inference.py`` runs its loader one reference view at a time; every forward here is ~200 dependent kernel
 launches, and each launch ends with a partially filled last wave of tiles (the z|r gate convolution: 925 tiles on 512 block
 slots - 99 of the 256 CUs idle for the last fifth of the launch).  Two forwards on two HIP streams fill each other's tails:
-measured at DTU 1600x1184 x 10 views x 32 iterations 18.3 ms per depth map against 20.8 ms one at a time (tools/exp_streams.py;
+measured at DTU 1600x1184 x 10 views x 32 iterations 18.3 ms per depth map against 20.8 ms one at a time (tools/archive/exp_streams.py;
 three streams: 18.0), outputs bit-identical.  Default three: with the fp8-correction convs 16.4-16.5 ms against 16.7 with two (four:
-17.1, six: 16.7 - an even number of forwards tends to run in phase; tools/exp_streams2.py).  ``DepthMapPipeline`` keeps ``streams`` forwards in flight: one replica of the model
+17.1, six: 16.7 - an even number of forwards tends to run in phase; tools/archive/exp_streams2.py).  ``DepthMapPipeline`` keeps ``streams`` forwards in flight: one replica of the model
 per stream (a deep copy - the packed weights, feature buffers and workspaces of a forward are per replica, the library itself is
 stateless; ``refresh_weights`` re-synchronises the replicas after the original's parameters changed), round-robin submission from
 one host thread."""

@@ -219,7 +219,7 @@ class RAFT(nn.Module):
     # ---------------------------------------------------------------- encoders with the first stage's cost volume underneath
     import os as _os
     # single-GPU fast path: build stage 0's per-view partial volumes on a second stream while later view batches are encoded.  OFF by
-    # default: measured at the bench workload (tools/exp_pipeline.py, same process, 10 forwards each) 20.97 ms with it, 20.96 without -
+    # default: measured at the bench workload (tools/archive/exp_pipeline.py, same process, 10 forwards each) 20.97 ms with it, 20.96 without -
     # the tile kernel's three 50-KiB-LDS blocks per CU leave no room for encoder blocks beside them, so the two kernels take turns
     # on the CUs instead of overlapping.  CER_PIPELINE=1 (or RAFT.PIPELINE_BUILD = True) turns it on; results are bit-identical.
     PIPELINE_BUILD = _os.environ.get("CER_PIPELINE", "0") == "1"

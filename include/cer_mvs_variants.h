@@ -5,7 +5,7 @@
  * Round 4 built two alternative kernel forms that are correct, tested against the default forms and measured SLOWER at the
  * bench workload.  Since round 5 they are not linked into the product library; the variant library keeps
  * them buildable for the tests (tests/test_conv_s16_gpu.py, tests/test_hip_parity.py: skipped unless this library is loaded)
- * and the measurement tools (tools/trace_sxpc.py, tools/bench_cost_lines.py, tools/stats_cost_lines.py).
+ * and the measurement tools (tools/archive/trace_sxpc.py, tools/archive/bench_cost_lines.py, tools/archive/stats_cost_lines.py).
  */
 #ifndef CER_MVS_VARIANTS_H
 #define CER_MVS_VARIANTS_H

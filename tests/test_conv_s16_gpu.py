@@ -301,7 +301,7 @@ def test_conv_s16_producer_consumer_form_matches(dev):
     from cer_mvs_amd import _lib as L, ops
     lib = L.load()
     if not L.has_variant_forms():
-        pytest.skip("the producer / consumer form is not in the product library: run with CER_MVS_LIB=.../variants/libcermvs_optin.so (tools/r05/test_variants.sh)")
+        pytest.skip("the producer / consumer form is not in the product library: run with CER_MVS_LIB=.../variants/libcermvs_optin.so (tools/archive/r05/test_variants.sh)")
     h, w = 118, 150
     P = h * w
     U, R, Dp = L.S16_UNIT, L.S16_RELU, L.S16_DISP

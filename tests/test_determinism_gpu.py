@@ -367,7 +367,7 @@ def test_pipeline_replicas_adopt_the_first_models_precision_decision(dev, golden
 
 def test_auto_precision_is_decided_on_the_worst_of_the_first_inputs(dev):
     """VERDICT r4 "weak" 1(c) / item 7(i): how far the fp8-correction form drifts from the fp32-class form depends on the SCENE as well
-    as on the weights (tools/r05/explore_auto.py: update-block convs x 1.5, heavy-tailed - 7.7e-6 on a noise image stack, 2.1e-5 / 4.7e-5
+    as on the weights (tools/archive/r05/explore_auto.py: update-block convs x 1.5, heavy-tailed - 7.7e-6 on a noise image stack, 2.1e-5 / 4.7e-5
     on two textured scenes, 3.7e-5 on an untextured one; tolerance 2.5e-5).  A first input inside the tolerance and a second one outside:
     round 4's rule - decide on the first input - kept the fp8 form for good; the decision now rests on the first AUTO_INPUTS inputs and
     the model must end on "s16", with the second result already the fp32-class one."""

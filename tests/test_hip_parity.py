@@ -392,7 +392,7 @@ def test_cost_lines_matches_walk(dev, D, stage0, geom, form):
     if form == 0 and not L.has_variant_forms():
         return _cost_lines_matches_walk(dev, D, stage0, geom, lib)
     if not L.has_variant_forms():
-        pytest.skip("the multi-line form is not in the product library: run with CER_MVS_LIB=.../variants/libcermvs_optin.so (tools/r05/test_variants.sh)")
+        pytest.skip("the multi-line form is not in the product library: run with CER_MVS_LIB=.../variants/libcermvs_optin.so (tools/archive/r05/test_variants.sh)")
     prev_form = lib.cer_cost_lines_form(form)
     try:
         _cost_lines_matches_walk(dev, D, stage0, geom, lib)

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round-5 PMC passes (one counter set per rocprofv3 pass, no tracing flags; every kernel launched alone at the bench shapes - rocprofv3's counter
+# collection serialises kernels, so a "three in flight" PMC run would measure the same solo launches): the four update-block convolutions, the
+# lookup in its round-5 form, the cost-volume tiles, the encoder's 32 -> 32 layer.  Run on the GPU box: gpurun -- tools/archive/pmc_r05.sh
+out=${1:-gpurun_out/r05/pmc}
+mkdir -p "$out"
+SETS=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES"
+      "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+      "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA")
+run() {   # name, kernel regex, command...
+  local name=$1 re=$2; shift 2
+  for set in "${SETS[@]}"; do
+    tag=$(echo $set | tr ' ' '_')
+    tools/pmc.sh "$out/$name/$tag" "$re" "$set" -- "$@" | sed "s/^/$name /"
+  done
+}
+{
+  run conv3x3_gates_zr_f8 "conv3x3_s16_kernel<1, 4, 4, 2, 1>" python tools/bench_conv_s16.py --f8 --only "z|r" --rounds 1 --reps 1
+  run conv3x3_gru_q_f8 "conv3x3_s16_kernel<2, 2, ., 3, 1>" python tools/bench_conv_s16.py --f8 --only "gru" --rounds 1 --reps 1
+  run conv3x3_delta_f8 "conv3x3_s16_kernel<1, 4, 4, 4, 1>" python tools/bench_conv_s16.py --f8 --only "delta" --rounds 1 --reps 1
+  run conv3x3_corr2_f8 "conv3x3_s16_kernel<2, 2, ., 1, 1>" python tools/bench_conv_s16.py --f8 --only "corr2" --rounds 1 --reps 1
+  run cost_lines_kernel "cost_lines_kernel" python tools/prof_build.py
+  run lookup_encode "lookup_encode" python tools/prof_conv.py lookup --reps 1
+  CER_PROF_LOOKUP_R04=1 run lookup_encode_r04_form "lookup_encode" python tools/prof_conv.py lookup --reps 1
+  run enc_pc_32to32 "enc_pc_kernel<32, 32, 1, 9, 0, false>" python tools/bench_pc.py 32
+} | tee "$out/counters.txt"
+python tools/pmc_summary.py "$out/counters.txt" "$out/pmc_traffic.json" > /dev/null
+find "$out" -name "*.csv" -size +1M -delete

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""N identical test-mode forwards of a bench workload and nothing else - the profiling subject of tools/prof_r05.sh.
+"""N identical test-mode forwards of a bench workload and nothing else - the profiling subject of tools/archive/prof_r05.sh.
 
 bench.py's process also runs a calibration forward, an instrumented forward and extra encode() calls; under rocprofv3 those make "per forward"
 columns wrong (VERDICT r4 "weak" 7).  Here every forward in the process is the same forward (gru_precision pinned, no calibration): kernel time

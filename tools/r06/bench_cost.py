@@ -2,7 +2,7 @@
 """Cost volume at the bench workload (1600x1184, 10 views), both stages, as RAFT.forward builds it (split operand planes, compact level-0 rows,
 fused view-mean scale): sustained time of the loaded library's epipolar-line-tile build (events around 10 back-to-back builds) and its distance
 from the wave-per-pixel walk (cer_cost_build_algo(1): the reference's fp32 expressions) on the same inputs.  Stage 1 starts from the disparity a
-one-stage forward produces.  usage: [CER_MVS_LIB=...] python tools/r05/bench_cost.py [label]"""
+one-stage forward produces.  usage: [CER_MVS_LIB=...] python tools/archive/r05/bench_cost.py [label]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cer_mvs_amd import RAFT, _lib as L, ops

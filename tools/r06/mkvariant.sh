@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/r05/mkvariant.sh <name> <source.hip> <flags...>  -> cer-mvs_amd/csrc/variants/libcermvs_<name>.so
+# usage: tools/archive/r05/mkvariant.sh <name> <source.hip> <flags...>  -> cer-mvs_amd/csrc/variants/libcermvs_<name>.so
 # ONE source of the product library recompiled with extra -D flags, linked with the product's other objects (A/B runs: CER_MVS_LIB=...)
 set -e
 name=$1; src=$2; shift; shift

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What-if at the bench workload: ms per depth map, one at a time and with three in flight, with ONE component's launches turned into no-ops
 (results are garbage; the timing says what that component costs in each regime - the most any optimisation of it could buy).  Round 2's
-tools/exp_whatif.py did this with cached results for the cost volume and the encoders; this form skips the library calls themselves, so it also
+tools/archive/exp_whatif.py did this with cached results for the cost volume and the encoders; this form skips the library calls themselves, so it also
 covers the update-block convolutions and the lookup.  usage: python tools/r06/whatif.py [--gru-precision s16f8]"""
 import argparse, os, sys
 import torch
