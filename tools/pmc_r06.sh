@@ -17,7 +17,7 @@ run() {   # name, kernel regex, command...
 }
 {
   run conv3x3_gates_zr_f8 "conv3x3_s16_kernel<1, 4, 4, 2, 1>" python tools/bench_conv_s16.py --f8 --only "z|r" --rounds 1 --reps 1
-  run conv3x3_gates_zr_f6 "conv3x3_s16_kernel<1, 4, 4, 2, 2>" python tools/r06/bench_conv_forms.py --rounds 1 --reps 1
+  run conv3x3_gates_zr_f6 "conv3x3_s16_kernel<1, 4, 4, 2, 2>" python tools/r06/bench_conv_forms.py --rounds 2 --reps 4
   run conv3x3_gru_q_f8 "conv3x3_s16_kernel<2, 2, ., 3, 1>" python tools/bench_conv_s16.py --f8 --only "gru" --rounds 1 --reps 1
   run conv3x3_delta_f8 "conv3x3_s16_kernel<1, 4, 4, 4, 1>" python tools/bench_conv_s16.py --f8 --only "delta" --rounds 1 --reps 1
   run conv3x3_corr2_f8 "conv3x3_s16_kernel<2, 2, ., 1, 1>" python tools/bench_conv_s16.py --f8 --only "corr2" --rounds 1 --reps 1

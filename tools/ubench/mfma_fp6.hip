@@ -118,10 +118,10 @@ static void check_cvt() {
         h[l][2] = (_Float16)(0.0f);
     }
     void *di, *ds, *dout;
-    CHECK(hipMalloc(&di, sizeof(h))); CHECK(hipMalloc(&ds, 256)); CHECK(hipMalloc(&dout, 64 * 24));
+    CHECK(hipMalloc(&di, sizeof(h))); CHECK(hipMalloc(&ds, 256)); CHECK(hipMalloc(&dout, 64 * 32));      // (sizeof(intx6) == 32: six ints padded to eight)
     CHECK(hipMemcpy(di, h, sizeof(h), hipMemcpyHostToDevice)); CHECK(hipMemcpy(ds, sc, 256, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(cvt32, dim3(1), dim3(64), 0, 0, (const half32*)di, (const float*)ds, (intx6*)dout);
-    unsigned got[64][6];
+    unsigned got[64][8];
     CHECK(hipMemcpy(got, dout, sizeof(got), hipMemcpyDeviceToHost));
     for (int mode = 0; mode < 2; ++mode) {                 // 0: value / scale, 1: value * scale
         int bad = 0;
