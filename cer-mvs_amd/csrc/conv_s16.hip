@@ -29,6 +29,9 @@
 //     form (6 single-tap steps), border tiles the literal one (4 half-chunks x 9 taps) - same algebra as round 1;
 //   * the hoisted `init` term / bias is the accumulators' initial value (16-byte loads in the prologue).
 #include "conv_s16_shared.hpp"
+#ifndef SX_MT8
+#define SX_MT8 0
+#endif
 
 struct SxStage {                           // what to put into the NEXT activation buffer
     int kind;                              // 0 nothing, 2 tensor half-chunk, 1 literal disparity group, 3 collapsed disparity group
@@ -38,7 +41,7 @@ struct SxStage {                           // what to put into the NEXT activati
 };
 
 template <int WM_, int WN_, int MT, int EPI, int F8>
-__global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : 2) void conv3x3_s16_kernel(const S16Args a) {
+__global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : (MT >= 8 ? 1 : 2)) void conv3x3_s16_kernel(const S16Args a) {
     constexpr int TH = WM_ * 2 * MT, HR = TH + 2;
     constexpr int ABUF = HR * (F8 ? SX_ROWB8 : SX_ROWB);
     constexpr int NPIX = HR * SX_HW, NITEM = NPIX * 4, ITEMS = (NITEM + 255) / 256;
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : 2) void conv
     // than an L2 round trip: their chunk loop ran at 1.75 x its pipe floor (tools/trace_s16.py --conv q: 8.0 k cycles per chunk against
     // 4.6 k; alone on a CU 388 per 16-channel step against 128).  They request two steps ahead (ring of three; 9 taps = 3 x 3: no slot swap):
     // 6.7 k per chunk.
-    constexpr int WR = (F8 && WM_ == 2 && MT == 2 && SX_WRING3) ? 3 : 2;         // (three m-tiles per wave: 229 VGPRs already, and 384 pipe cycles per step)
+    constexpr int WR = (F8 && ((WM_ == 2 && MT == 2 && SX_WRING3) || MT >= 8)) ? 3 : 2;         // (three m-tiles per wave: 229 VGPRs already, and 384 pipe cycles per step)
     constexpr bool WSPLIT = F8 && WR == 2 && SX_WSPLIT;                           // two slots, refilled part by part (see mma8_roll)
     W8 w8[WR];
     auto load_w8 = [&](W8& f, int cstep) {                 // (clamped: the steps past the tensors are never multiplied)
@@ -1442,6 +1445,11 @@ extern "C" int cer_conv3x3_s16(const cer_conv_inputs* in, const int* log2sx, con
 #endif
     if (Cout % 128 == 0) {
         int mt = tile_mt;
+#if SX_MT8
+        // experiment (round 6): ONE block per CU, eight m-tiles (16 rows) per wave - a weight slice is fetched once per CU and tap instead of twice
+        if (mt == 8 && corr_fp6) return sx_launch<1, 4, 8, 2>(a, epi, st);
+        if (mt == 8 && corr_fp8) return sx_launch<1, 4, 8, 1>(a, epi, st);
+#endif
         if (mt != 2 && mt != 4) mt = pick(2, 2, 4, Cout / 128) == 2 ? 2 : 4;
         if (corr_fp6) return mt == 2 ? sx_launch<1, 4, 2, 2>(a, epi, st) : sx_launch<1, 4, 4, 2>(a, epi, st);
         if (corr_fp8) return mt == 2 ? sx_launch<1, 4, 2, 1>(a, epi, st) : sx_launch<1, 4, 4, 1>(a, epi, st);

@@ -12,7 +12,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--size", default="296x400")
+ap.add_argument("--mt", type=int, default=0, help="force the tile height (ops.TILE_MT; 8 needs a -DSX_MT8=1 build of conv_s16.hip)")
 args = ap.parse_args()
+ops.TILE_MT = args.mt
 h, w = (int(x) for x in args.size.split("x"))
 P = h * w
 dev = torch.device("cuda")
