@@ -607,8 +607,19 @@ __device__ __forceinline__ void cl_tile(const ClArgs& A, const int v, const int 
 
 // XCD-aware order (blocks are dealt round-robin over the 8 XCDs): each XCD gets a contiguous range of (view, segment, line):
 // neighbouring lines share most of their band, which then stays in that XCD's L2
+#ifndef CL_CU_ADJ
+#define CL_CU_ADJ 0      // experiment (round 6): N > 0 - the k-th block of an XCD takes, inside groups of 3 N consecutive tiles, tile (k % N) * 3 + k / N:
+                         // if the dispatcher deals an XCD's blocks round-robin over N CUs, the three resident blocks of a CU then hold ADJACENT lines
+#endif
 __device__ __forceinline__ unsigned cl_xcd_order() {
-    const unsigned nblk = gridDim.x, bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+    const unsigned nblk = gridDim.x, bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    unsigned k = bid >> 3;
+#if CL_CU_ADJ > 0
+    {
+        const unsigned len = xcd < r ? q + 1 : q, G = 3u * CL_CU_ADJ, g = k / G, j = k - g * G;
+        if ((g + 1) * G <= len) k = g * G + (j % CL_CU_ADJ) * 3u + j / CL_CU_ADJ;
+    }
+#endif
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
