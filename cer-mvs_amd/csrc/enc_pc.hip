@@ -33,6 +33,9 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #ifndef PC_ABL
 #define PC_ABL 0                       // profiling ablations (variant builds only): 1 no MFMAs, 2 no output stores, 4 no operand transform (halves of the raw bits)
 #endif
+#ifndef PC_EXP24
+#define PC_EXP24 0
+#endif
 #ifndef PC_TRACE
 #define PC_TRACE 0                     // debug build: per-wave phase cycle sums written to a.out2 [blocks][8 waves][8] (u64); tools/archive/trace_pc.py
 #endif
@@ -209,10 +212,18 @@ __device__ __forceinline__ void pc_producer(const PcArgs& a, char* __restrict__ 
         const int gy = min(max(nx_y0 + hyv[i] * PS, 0), a.h - 1), gx = min(max(nx_x0 + hxv[i] * PS, 0), a.w - 1);
         const int off = nx_interior ? (nx_y0 * a.w + nx_x0) * CIN + ioff[i] : (gy * a.w + gx) * CIN + 8 * g;
         rawA[i][0] = cer_ld4(nx_pa + off);
+#if PC_EXP24       // timing experiment (WRONG results): 24 instead of 32 bytes per item in, three of four 16-byte stores out - the traffic of a 3-byte format
+        { const float2 t2 = *reinterpret_cast<const float2*>(nx_pa + off + 4); rawA[i][1] = make_float4(t2.x, t2.y, t2.x, t2.y); }
+#else
         rawA[i][1] = cer_ld4(nx_pa + off + 4);
+#endif
         if (DUAL) {
             rawB[DUAL ? i : 0][0] = cer_ld4(nx_pb + off);
+#if PC_EXP24
+            { const float2 t2 = *reinterpret_cast<const float2*>(nx_pb + off + 4); rawB[DUAL ? i : 0][1] = make_float4(t2.x, t2.y, t2.x, t2.y); }
+#else
             rawB[DUAL ? i : 0][1] = cer_ld4(nx_pb + off + 4);
+#endif
         }
     };
     float muA[8], rsA[8], muB[8], rsB[8];                                        // rs = 2048 rstd
@@ -548,7 +559,7 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
                             *reinterpret_cast<half4_t*>(rowb + loff + 4 * (long)bt16) = (half4_t){l0.x, l0.y, l1.x, l1.y};
                         }
                     } else if (PC_ABL & 2) asm volatile("" :: "v"(v4.x), "v"(v4.y), "v"(v4.z), "v"(v4.w));
-                    else if (FULL || (gy < a.ho && tx0 + (lane >> 3) + 8 * jj < a.wo)) *reinterpret_cast<float4*>(o + lane_off + 8 * jj * pstride) = v4;
+                    else if ((!PC_EXP24 || EPI != PC_EPI_RAW || jj != 3) && (FULL || (gy < a.ho && tx0 + (lane >> 3) + 8 * jj < a.wo))) *reinterpret_cast<float4*>(o + lane_off + 8 * jj * pstride) = v4;
                 }
             }
         };
