@@ -70,9 +70,9 @@ def main():
         U, R, Dp = L.S16_UNIT, L.S16_RELU, L.S16_DISP
         fr = lambda t, k: ops.to_frag16(to_l(t), h, w, k)
         unf = lambda t, k: ops.from_frag16(t, h, w, k)
-        for f8 in (False, True):
+        for f8 in (False, True, 6):                    # (6: the FP6-correction form of round 6, gru_precision="s16f6")
             bar = 5e-5 if f8 else 5e-6
-            tag = "f8" if f8 else "s16"
+            tag = {False: "s16", True: "f8", 6: "f6"}[f8]
             ops.TILE_MT = [0, 2, 3, 4][ri(0, 3)]
             try:
                 for cout, epi in ((128, L.EPI_GATES), (64, L.EPI_GRU), (64, L.EPI_RELU)):
