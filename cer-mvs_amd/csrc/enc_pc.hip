@@ -31,10 +31,14 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 #ifndef PC_ABL
-#define PC_ABL 0                       // profiling ablations (variant builds only): 1 no MFMAs, 2 no output stores, 4 no operand transform (halves of the raw bits)
+#define PC_ABL 0                       // profiling ablations (variant builds only): 1 no MFMAs, 2 no output stores, 4 no operand transform (halves of the raw bits),
+                                       // 8 / 16: the MATRIX TIME of an fp8- / FP6-correction form (2 of 3 / 3 of 6 MFMAs issued; results wrong) - upper bounds
 #endif
 #ifndef PC_EXP24
 #define PC_EXP24 0
+#endif
+#ifndef PC_PAD
+#define PC_PAD 0
 #endif
 #ifndef PC_TRACE
 #define PC_TRACE 0                     // debug build: per-wave phase cycle sums written to a.out2 [blocks][8 waves][8] (u64); tools/archive/trace_pc.py
@@ -152,6 +156,14 @@ __device__ __forceinline__ floatx16 pc_keep(half8 a_, half8 b_, floatx16 c_) { a
 #else
 #define PC_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, 0, 0, 0)
 #endif
+#if PC_ABL & 24
+__device__ __forceinline__ floatx16 pc_keep2(half8 a_, half8 b_, floatx16 c_) { asm volatile("" :: "v"(a_), "v"(b_)); return c_; }
+#define PC_MFMA_C3(a_, b_, c_, s_) pc_keep2(a_, b_, c_)                                        // lo x hi: never issued
+#define PC_MFMA_C2(a_, b_, c_, s_) (((PC_ABL & 16) && ((s_) & 1)) ? pc_keep2(a_, b_, c_) : PC_MFMA(a_, b_, c_))   // hi x lo: FP6 time = every other step
+#else
+#define PC_MFMA_C3(a_, b_, c_, s_) PC_MFMA(a_, b_, c_)
+#define PC_MFMA_C2(a_, b_, c_, s_) PC_MFMA(a_, b_, c_)
+#endif
 #define PC_YMAX 134152192.0f           // 65504 * 2048: what the f16 hi half can hold, in the scaled domain
 
 template <int CIN, int COUT, int STRIDE, int TAPS, bool DUAL>
@@ -261,6 +273,14 @@ __device__ __forceinline__ void pc_producer(const PcArgs& a, char* __restrict__ 
                     lo = __builtin_bit_cast(half8, (f32x4){va[4], va[5], va[6], va[7]});
                 } else
                 pc_split8_scaled(yv, hi, lo);
+#if PC_PAD          // timing experiment: PC_PAD extra VALU instructions per 8-value item (what a narrower correction format's conversion would add)
+                {
+                    unsigned pad_ = __builtin_bit_cast(unsigned, yv[0]);
+#pragma unroll
+                    for (int q_ = 0; q_ < PC_PAD; ++q_) asm volatile("v_add_u32 %0, %0, %1" : "+v"(pad_) : "v"(q_ + 1));
+                    asm volatile("" :: "v"(pad_));
+                }
+#endif
                 *reinterpret_cast<half8*>(buf + lpix[i]) = hi;
                 *reinterpret_cast<half8*>(buf + lpix[i] + 64) = lo;
                 if (DUAL && STRIDE == 1 && a.mout) {                             // merged activation, once per pixel: the tile's core
@@ -445,13 +465,13 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int m = 0; m < C::RPW; ++m) {
-                        accl[m] = PC_MFMA(fa[0][m][0], bl, accl[m]);
+                        accl[m] = PC_MFMA_C2(fa[0][m][0], bl, accl[m], s);
                         if (s + 1 < C::NS) loadA1(0, m, s + 1, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
                     for (int m = 0; m < C::RPW; ++m) {
-                        accl[m] = PC_MFMA(fa[0][m][1], bh, accl[m]);
+                        accl[m] = PC_MFMA_C3(fa[0][m][1], bh, accl[m], s);
                         if (s + 1 < C::NS) loadA1(0, m, s + 1, 1);
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -474,8 +494,8 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
                     const half8 bh = C::WRES ? wres[ch * C::NS + s][0] : wst[s % WR][0];
                     const half8 bl = C::WRES ? wres[ch * C::NS + s][1] : wst[s % WR][1];
                     accm[0] = PC_MFMA(fa[b][0][0], bh, accm[0]);
-                    accl[0] = PC_MFMA(fa[b][0][0], bl, accl[0]);
-                    accl[0] = PC_MFMA(fa[b][0][1], bh, accl[0]);
+                    accl[0] = PC_MFMA_C2(fa[b][0][0], bl, accl[0], s);
+                    accl[0] = PC_MFMA_C3(fa[b][0][1], bh, accl[0], s);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
