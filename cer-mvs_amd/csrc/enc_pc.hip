@@ -23,12 +23,27 @@
 // Statistics partials: consumers leave [row group][channel] (sum, sum of squares) in a double-buffered LDS patch; producer wave 0
 // adds the row groups in fixed order after the next barrier and writes the tile's record: deterministic, one record per tile
 // whatever block processed it (batch invariance, tests/test_hip_parity.py::test_encoder_engine_batch_invariance_at_tnt_size).
+//
+// Round 6, the FP6-correction form (flags & 8; weights from cer_enc_conv_pack_f6): the two correction terms of a 32-channel tap -
+// xh*wl' + xl'*wh for both k16-steps, 2 x 2 f16 MFMAs = 128 matrix-pipe cycles per m-tile - become ONE v_mfma_scale_f32_32x32x64_f8f6f4 with
+// both operands in e2m3 (8 passes = 32 cycles), accumulated into the main term's accumulator: 96 instead of 192 cycles per tap and m-tile.
+// K block of lane (pixel or output channel, kg): 32 six-bit fields, field i at bit 6 i = [xh (8) | xl' (8)] of channels 8kg..8kg+7 of k16-step 0,
+// then of k16-step 1 (weights: [wl' | wh] in the same positions), all divided by one power of two per block - activations: s = 2^(e - 2), e the
+// exponent of the block's largest |xh| (|xl'| <= |xh| element by element: nothing saturates), formed by the producers (packed 16-bit maxima of
+// the two items of a block - lanes tid and tid ^ 2 - one DPP exchange, ONE v_cvt_scalef32_pk32_fp6_f16 per item); weights: from the block
+// maximum on the host, times the 2^-11 that puts both terms on the accumulator's scale.  LDS: the 24 bytes + E8M0 byte of a block take the
+// place of the block's lo halves (dwords 0-3 where lo of k16-step 0 was, dwords 4-5 | scale where lo of step 1 was): the consumers' fragment
+// addresses do not change.  Costed on the oracle first (tools/experiments/encoder_corr_numerics.py: 7e-6 end to end), its matrix time and the
+// producers' slack measured with ablation builds (profiles/r06_encoder_fp6_upper_bound.txt) before the kernels were written.
 #include "common.hpp"
+#include <math.h>
 #include <string.h>
 #include <type_traits>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned int pc_u32x4 __attribute__((ext_vector_type(4)));
+typedef int pc_intx8 __attribute__((ext_vector_type(8)));
 
 #ifndef PC_ABL
 #define PC_ABL 0                       // profiling ablations (variant builds only): 1 no MFMAs, 2 no output stores, 4 no operand transform (halves of the raw bits),
@@ -166,7 +181,31 @@ __device__ __forceinline__ floatx16 pc_keep2(half8 a_, half8 b_, floatx16 c_) { 
 #endif
 #define PC_YMAX 134152192.0f           // 65504 * 2048: what the f16 hi half can hold, in the scaled domain
 
-template <int CIN, int COUT, int STRIDE, int TAPS, bool DUAL>
+// FP6 form: the item's 16 values [hi (8) | lo' (8)] -> 16 e2m3 fields (three dwords) under the block's scale; `sb` = its E8M0 byte
+__device__ __forceinline__ void pc_fp6_item(const half8 hi, const half8 lo, unsigned (&f)[3], unsigned& sb) {
+    typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+    union U2 { unsigned u; ushort2_t s; };
+    const pc_u32x4 hb = __builtin_bit_cast(pc_u32x4, hi);
+    U2 a0, a1, a2, a3;                                                           // f16 bit patterns without their sign order like the magnitudes
+    a0.u = hb.x & 0x7FFF7FFFu; a1.u = hb.y & 0x7FFF7FFFu; a2.u = hb.z & 0x7FFF7FFFu; a3.u = hb.w & 0x7FFF7FFFu;
+    a0.s = __builtin_elementwise_max(a0.s, a1.s);
+    a2.s = __builtin_elementwise_max(a2.s, a3.s);
+    a0.s = __builtin_elementwise_max(a0.s, a2.s);
+    unsigned mm = max(a0.u & 0xFFFFu, a0.u >> 16);
+    mm = max(mm, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mm, 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]: the block's other k16-step
+    sb = ((mm + 0x40u) >> 10) + 110u;                                            // E8M0 of s = 2^(bexp - 15 - 2); + 0x40: mantissas >= 1.9375 go one up
+    const float sc = __uint_as_float(sb << 23);
+    typedef _Float16 half32_t __attribute__((ext_vector_type(32)));
+    typedef _Float16 half16_t __attribute__((ext_vector_type(16)));
+    typedef int intx6_t __attribute__((ext_vector_type(6)));
+    const half16_t in = __builtin_shufflevector(hi, lo, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    const half32_t in32 = __builtin_shufflevector(in, in, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
+                                                  -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    const intx6_t f6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(in32, sc);     // (divides by its scale operand, rounds to nearest even, saturates at 7.5)
+    f[0] = (unsigned)f6[0]; f[1] = (unsigned)f6[1]; f[2] = (unsigned)f6[2];
+}
+
+template <int CIN, int COUT, int STRIDE, int TAPS, bool DUAL, bool F6>
 __device__ __forceinline__ void pc_producer(const PcArgs& a, char* __restrict__ lds, const float* __restrict__ red, int tid) {
     using C = PcCfg<CIN, COUT, STRIDE, TAPS>;
     constexpr int PS = TAPS == 9 ? 1 : STRIDE;                                   // pixel step of the halo in the source (1x1 stride 2: every other pixel)
@@ -282,6 +321,19 @@ __device__ __forceinline__ void pc_producer(const PcArgs& a, char* __restrict__ 
                 }
 #endif
                 *reinterpret_cast<half8*>(buf + lpix[i]) = hi;
+                if constexpr (F6) {
+                    // block (pixel, kg = g & 1): dwords 0-3 at +64 + 16 kg, dwords 4-5 | scale at +96 + 16 kg; this item (k16-step g >> 1) owns
+                    // dwords 0-2 (step 0) or 3-5 (step 1); the scale is the same in both lanes of the block
+                    unsigned f[3], sb;
+                    pc_fp6_item(hi, lo, f, sb);
+                    char* q = buf + lpix[i] + (64 - 16 * g) + 16 * (g & 1);
+                    char* q0 = q + ((g >> 1) ? 12 : 0);
+                    char* q1 = q + ((g >> 1) ? 32 : 4);
+                    *reinterpret_cast<unsigned*>(q0) = f[0];
+                    *reinterpret_cast<unsigned*>(q1) = f[1];
+                    *reinterpret_cast<unsigned*>(q1 + 4) = f[2];
+                    *reinterpret_cast<unsigned*>(q + 40) = sb;
+                } else
                 *reinterpret_cast<half8*>(buf + lpix[i] + 64) = lo;
                 if (DUAL && STRIDE == 1 && a.mout) {                             // merged activation, once per pixel: the tile's core
                     const bool core = TAPS == 9 ? (hyv[i] >= 1 && hyv[i] <= C::TH && hxv[i] >= 1 && hxv[i] <= 32) : true;
@@ -369,7 +421,7 @@ __device__ __forceinline__ void pc_producer(const PcArgs& a, char* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------------------------ consumers
-template <int CIN, int COUT, int STRIDE, int TAPS, int EPI>
+template <int CIN, int COUT, int STRIDE, int TAPS, int EPI, bool F6>
 __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restrict__ lds, float* __restrict__ red, float* __restrict__ patch, int cw,
                                             int lane) {
     using C = PcCfg<CIN, COUT, STRIDE, TAPS>;
@@ -413,6 +465,21 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
 #endif
     constexpr bool ROLL = C::RPW >= 2;          // fragments rolled in place one step ahead (RPW = 1: triple-buffered two steps ahead)
     constexpr int NBUF = ROLL ? 1 : 3;
+    static_assert(!F6 || ROLL || C::WRES, "FP6 form at one m-tile per wave: resident weights only");
+    // FP6 form: both correction terms of a tap (two k16-steps) in one e2m3 MFMA; the block's dwords 0-3 / 4-5 | scale sit where the lo halves of
+    // step 0 / step 1 were - in LDS and in the packed weights alike - so `a0` / `b0` are a step-0 "lo" piece and `a1` / `b1` a step-1 one
+    auto mfma6 = [&](pc_u32x4 a0, pc_u32x4 a1, half8 b0h, half8 b1h, floatx16 c) -> floatx16 {
+        const pc_u32x4 b0 = __builtin_bit_cast(pc_u32x4, b0h), b1 = __builtin_bit_cast(pc_u32x4, b1h);
+        const pc_intx8 A0 = (pc_intx8){(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, 0, 0};
+        const pc_intx8 B0 = (pc_intx8){(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, 0, 0};
+        const pc_intx8 A = __builtin_shufflevector(A0, A0, 0, 1, 2, 3, 4, 5, -1, -1), B = __builtin_shufflevector(B0, B0, 0, 1, 2, 3, 4, 5, -1, -1);
+#if PC_ABL & 1
+        asm volatile("" :: "v"(A), "v"(B));
+        return c;
+#else
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 2, 2, 0, (int)a1.z, 0, (int)b1.z);
+#endif
+    };
 
     for (int j = 0; j < ntile; ++j) {
         int img, tile, ty_, tx_;
@@ -438,14 +505,91 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
                 wst[b][0] = ldw(ch * TAPS + (s >> 1), s & 1, 0);
                 wst[b][1] = ldw(ch * TAPS + (s >> 1), s & 1, 1);
             };
-            if (!C::WRES) {                                                      // (requested in front of the barrier: L2 latency under the wait)
+            if (!C::WRES && !F6) {                                               // (requested in front of the barrier: L2 latency under the wait)
 #pragma unroll
                 for (int d = 0; d < WD; ++d) loadW(d, d);
             }
             PC_T(0);
             pc_barrier();                                                        // #u: the producers have filled buffer u & 1
             PC_T(1);
-            if (ROLL) {
+            if constexpr (F6 && ROLL) {
+                // a tap's MFMAs in three groups (main term of k16-step 0, of step 1, the FP6 correction of both); the four fragment sets of a
+                // row - hi of both steps, the block's two 16-byte pieces - are re-requested for the NEXT tap right behind their last use:
+                // every request 2 RPW .. 3 RPW MFMAs ahead of its first use.  One accumulator per m-tile (the weights' scale byte carries 2^-11).
+                constexpr int WD6 = 4, WR6 = 6;                                  // streamed weights: steps requested 2 taps ahead, ring of 6 steps
+                half8 w6[C::WRES ? 1 : WR6][2];
+                half8 fh[C::RPW][2];
+                pc_u32x4 fq[C::RPW][2];
+                auto loadA6 = [&](int m, int tap) {
+                    fh[m][0] = *reinterpret_cast<const half8*>(A + aoff(m, 2 * tap));
+                    fh[m][1] = *reinterpret_cast<const half8*>(A + aoff(m, 2 * tap + 1));
+                };
+                auto loadQ6 = [&](int m, int tap) {
+                    fq[m][0] = *reinterpret_cast<const pc_u32x4*>(A + aoff(m, 2 * tap) + 64);
+                    fq[m][1] = *reinterpret_cast<const pc_u32x4*>(A + aoff(m, 2 * tap + 1) + 64);
+                };
+                if (!C::WRES) {
+#pragma unroll
+                    for (int d = 0; d < WD6; ++d) {
+                        w6[d][0] = ldw(ch * TAPS + (d >> 1), d & 1, 0);
+                        w6[d][1] = ldw(ch * TAPS + (d >> 1), d & 1, 1);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < C::RPW; ++m) {
+                    loadA6(m, 0);
+                    loadQ6(m, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const int s0 = 2 * t, s1 = 2 * t + 1;
+                    if (!C::WRES) {
+#pragma unroll
+                        for (int d = 0; d < 2; ++d)
+                            if (s0 + WD6 + d < C::NS) {
+                                w6[(s0 + WD6 + d) % WR6][0] = ldw(ch * TAPS + ((s0 + WD6 + d) >> 1), (s0 + WD6 + d) & 1, 0);
+                                w6[(s0 + WD6 + d) % WR6][1] = ldw(ch * TAPS + ((s0 + WD6 + d) >> 1), (s0 + WD6 + d) & 1, 1);
+                            }
+                    }
+                    const half8 wh0 = C::WRES ? wres[ch * C::NS + s0][0] : w6[s0 % WR6][0], wh1 = C::WRES ? wres[ch * C::NS + s1][0] : w6[s1 % WR6][0];
+                    const half8 wq0 = C::WRES ? wres[ch * C::NS + s0][1] : w6[s0 % WR6][1], wq1 = C::WRES ? wres[ch * C::NS + s1][1] : w6[s1 % WR6][1];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < C::RPW; ++m) accm[m] = PC_MFMA(fh[m][0], wh0, accm[m]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < C::RPW; ++m) {
+                        accm[m] = PC_MFMA(fh[m][1], wh1, accm[m]);
+                        if (t + 1 < TAPS) loadA6(m, t + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int m = 0; m < C::RPW; ++m) {
+                        accm[m] = mfma6(fq[m][0], fq[m][1], wq0, wq1, accm[m]);
+                        if (t + 1 < TAPS) loadQ6(m, t + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else if constexpr (F6) {
+                // one m-tile per wave (the stride-2 3x3 layer): fragments of four steps in a ring, requested two steps ahead; the correction
+                // of a tap follows the main term of its second step into a SECOND accumulator (a single one would chain all three MFMAs)
+                half8 fh[4];
+                pc_u32x4 fq[4];
+                auto load6 = [&](int b, int s) {
+                    fh[b] = *reinterpret_cast<const half8*>(A + aoff(0, s));
+                    fq[b] = *reinterpret_cast<const pc_u32x4*>(A + aoff(0, s) + 64);
+                };
+                load6(0, 0);
+                load6(1, 1);
+#pragma unroll
+                for (int s = 0; s < C::NS; ++s) {
+                    if (s + 2 < C::NS) load6((s + 2) % 4, s + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    accm[0] = PC_MFMA(fh[s % 4], wres[ch * C::NS + s][0], accm[0]);
+                    if (s & 1) accl[0] = mfma6(fq[(s - 1) % 4], fq[s % 4], wres[ch * C::NS + s - 1][1], wres[ch * C::NS + s][1], accl[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if (ROLL) {
                 // a step's MFMAs in three groups (main term, hi x lo, lo x hi); a row's hi fragment is re-requested for the next step
                 // right behind its last use in group 2, its lo fragment behind group 3: one fragment set in registers, every request
                 // RPW .. 3 RPW MFMAs (>= 128 cycles at RPW = 2) ahead of its first use
@@ -538,7 +682,7 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int pxc = (r & 3) + 8 * (r >> 2);
-                    float v = fmaf(accl[m][r], 1.0f / 2048.0f, accm[m][r]);
+                    float v = F6 ? (ROLL ? accm[m][r] : accm[m][r] + accl[m][r]) : fmaf(accl[m][r], 1.0f / 2048.0f, accm[m][r]);
                     if (EPI == PC_EPI_RAW) {
                         if (FULL || (gy < a.ho && tx0 + pxc + 4 * kg < a.wo)) {
                             ssum += v;
@@ -608,14 +752,14 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
 #endif
 }
 
-template <int CIN, int COUT, int STRIDE, int TAPS, int EPI, bool DUAL>
+template <int CIN, int COUT, int STRIDE, int TAPS, int EPI, bool DUAL, bool F6 = false>
 __global__ __launch_bounds__(512, 2) void enc_pc_kernel(const PcArgs a) {
     using C = PcCfg<CIN, COUT, STRIDE, TAPS>;
     extern __shared__ __attribute__((aligned(16))) char pc_smem[];
     float* red = reinterpret_cast<float*>(pc_smem + 2 * C::BUF);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);           // wave index in an SGPR: the role branch is scalar
-    if (wave < 4) pc_producer<CIN, COUT, STRIDE, TAPS, DUAL>(a, pc_smem, red, (int)threadIdx.x);
-    else pc_consumer<CIN, COUT, STRIDE, TAPS, EPI>(a, pc_smem, red, reinterpret_cast<float*>(pc_smem + 2 * C::BUF + C::RED), wave - 4, (int)(threadIdx.x & 63));
+    if (wave < 4) pc_producer<CIN, COUT, STRIDE, TAPS, DUAL, F6>(a, pc_smem, red, (int)threadIdx.x);
+    else pc_consumer<CIN, COUT, STRIDE, TAPS, EPI, F6>(a, pc_smem, red, reinterpret_cast<float*>(pc_smem + 2 * C::BUF + C::RED), wave - 4, (int)(threadIdx.x & 63));
 }
 
 // ------------------------------------------------------------------------------------------------------------------ host side
@@ -631,15 +775,19 @@ static int pc_launch(PcArgs a, int nimg, hipStream_t st) {
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     const int cus = cer_num_cus();                         // (persistent: one block per CU the launch may count on)
     const unsigned grid = (unsigned)(total < cus ? total : cus);
-    const bool dual = a.srcB != nullptr;
-    const void* fn = dual ? (const void*)enc_pc_kernel<CIN, COUT, STRIDE, TAPS, EPI, true> : (const void*)enc_pc_kernel<CIN, COUT, STRIDE, TAPS, EPI, false>;
-    static bool raised[2][64];                                                   // per instantiation, per device (not "first device only")
-    if (C::SMEM > 64 * 1024 && (dev < 0 || dev >= 64 || !raised[dual][dev])) {
+    const bool dual = a.srcB != nullptr, f6 = (a.flags & 8) != 0;                // flags & 8: FP6-correction form (weights from cer_enc_conv_pack_f6)
+    const void* fn = f6 ? (dual ? (const void*)enc_pc_kernel<CIN, COUT, STRIDE, TAPS, EPI, true, true> : (const void*)enc_pc_kernel<CIN, COUT, STRIDE, TAPS, EPI, false, true>)
+                        : (dual ? (const void*)enc_pc_kernel<CIN, COUT, STRIDE, TAPS, EPI, true> : (const void*)enc_pc_kernel<CIN, COUT, STRIDE, TAPS, EPI, false>);
+    static bool raised[4][64];                                                   // per instantiation, per device (not "first device only")
+    const int inst = (f6 ? 2 : 0) + (dual ? 1 : 0);
+    if (C::SMEM > 64 * 1024 && (dev < 0 || dev >= 64 || !raised[inst][dev])) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         if (e != hipSuccess) return (int)e;
-        if (dev >= 0 && dev < 64) raised[dual][dev] = true;
+        if (dev >= 0 && dev < 64) raised[inst][dev] = true;
     }
-    if (dual) hipLaunchKernelGGL((enc_pc_kernel<CIN, COUT, STRIDE, TAPS, EPI, true>), dim3(grid), dim3(512), C::SMEM, st, a);
+    if (f6 && dual) hipLaunchKernelGGL((enc_pc_kernel<CIN, COUT, STRIDE, TAPS, EPI, true, true>), dim3(grid), dim3(512), C::SMEM, st, a);
+    else if (f6) hipLaunchKernelGGL((enc_pc_kernel<CIN, COUT, STRIDE, TAPS, EPI, false, true>), dim3(grid), dim3(512), C::SMEM, st, a);
+    else if (dual) hipLaunchKernelGGL((enc_pc_kernel<CIN, COUT, STRIDE, TAPS, EPI, true>), dim3(grid), dim3(512), C::SMEM, st, a);
     else hipLaunchKernelGGL((enc_pc_kernel<CIN, COUT, STRIDE, TAPS, EPI, false>), dim3(grid), dim3(512), C::SMEM, st, a);
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
@@ -657,6 +805,68 @@ extern "C" int cer_enc_pc_supported(int Cin, int Cout, int taps, int stride, int
     if (epi == PC_EPI_FMAP || epi == PC_EPI_FSPLIT) return Cin == 64 && Cout == 64 && taps == 1 && stride == 1;
     if (epi == PC_EPI_CTX) return Cin == 64 && Cout == 128 && taps == 1 && stride == 1;
     return 0;
+}
+
+// e2m3 (FP6: 1 sign, 2 exponent, 3 mantissa bits: 0, 0.125 .. 0.875, 1 .. 1.875, 2 .. 3.75, 4 .. 7.5), round to nearest even, saturating
+static unsigned pc_e2m3(double v) {
+    const unsigned sgn = v < 0 ? 32u : 0u;
+    const double m = fabs(v);
+    if (!(m == m) || m >= 7.5) return sgn | 31u;
+    const int E = m < 2.0 ? 0 : (m < 4.0 ? 1 : 2);          // steps of 0.125 (subnormals and [1, 2)), 0.25, 0.5
+    const int q = (int)nearbyint(ldexp(m, 3 - E));          // in units of the step: 0..16 (E = 0: the codes are linear in the value), 8..16
+    return sgn | (unsigned)(E == 0 ? q : 8 * E + q);        // (q = 16 carries into the next exponent's first code)
+}
+
+// Weights of the FP6-correction form (round 6): cer_enc_conv_pack's order and size, [chunk32][tap][ntile32][k16-step][hi | q][lane][16 B]: the hi
+// plane as before (f16 hi halves of channels 16 ks + 8 kg + 0..7 for output channel lane & 31); the q planes of a tap's two steps hold the
+// lane's K block of v_mfma_scale_f32_32x32x64_f8f6f4 in e2m3: 32 six-bit fields, field i at bit 6 i = [wl' (8) | wh (8)] of step 0, then of step
+// 1 (wl' = (w - wh) 2^11), divided by t = 2^(e - 2), e the exponent of the block's largest magnitude (one up where that would land above 7.75):
+// dwords 0-3 in step 0's q plane, dwords 4-5 | E8M0 byte of t 2^-11 | 0 in step 1's.
+extern "C" int cer_enc_conv_pack_f6(const float* w, void* packed_v, int Cout, int Cin, int taps) {
+    if (!w || !packed_v) return CER_EINVAL;
+    if (Cout % 32 || Cin % 32 || (taps != 1 && taps != 9)) return CER_ESHAPE;
+    _Float16* packed = (_Float16*)packed_v;
+    const int NT = Cout / 32;
+    for (int kc = 0; kc < Cin / 32; ++kc)
+        for (int tap = 0; tap < taps; ++tap)
+            for (int nt = 0; nt < NT; ++nt)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = nt * 32 + (lane & 31);
+                    const long base = (((long)kc * taps + tap) * NT + nt) * 4;              // 512-half planes: (ks 0: hi, q), (ks 1: hi, q)
+                    double f[32], mx = 0.0;
+                    for (int ks = 0; ks < 2; ++ks)
+                        for (int e = 0; e < 8; ++e) {
+                            const int ci = kc * 32 + ks * 16 + (lane >> 5) * 8 + e;
+                            float v = w[((long)co * Cin + ci) * taps + tap];
+                            v = v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v);
+                            const _Float16 hi = (_Float16)v;
+                            const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
+                            packed[(base + 2 * ks) * 512 + lane * 8 + e] = hi;
+                            f[ks * 16 + e] = (double)(float)lo;
+                            f[ks * 16 + 8 + e] = (double)(float)hi;
+                            mx = fmax(mx, fmax(fabs(f[ks * 16 + e]), fabs(f[ks * 16 + 8 + e])));
+                        }
+                    int te = -100;                                                            // t = 2^te
+                    if (mx > 0.0) {
+                        int e2;
+                        frexp(mx, &e2);                                                       // mx in [2^(e2-1), 2^e2)
+                        te = e2 - 1 - 2;
+                        if (ldexp(mx, -te) > 7.75) ++te;
+                        if (te < -100) te = -100;
+                    }
+                    unsigned q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (int i = 0; i < 32; ++i) {
+                        const unsigned fld = pc_e2m3(ldexp(f[i], -te));
+                        const int bit = 6 * i;
+                        q[bit >> 5] |= fld << (bit & 31);
+                        if ((bit & 31) > 26) q[(bit >> 5) + 1] |= fld >> (32 - (bit & 31));
+                    }
+                    q[6] = (unsigned)(te - 11 + 127);
+                    q[7] = 0;
+                    memcpy(reinterpret_cast<char*>(packed + (base + 1) * 512) + lane * 16, q, 16);
+                    memcpy(reinterpret_cast<char*>(packed + (base + 3) * 512) + lane * 16, q + 4, 16);
+                }
+    return CER_OK;
 }
 
 extern "C" int cer_enc_pc_tiles(int ho, int wo, int Cout, int taps, int stride) {
