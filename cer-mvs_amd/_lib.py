@@ -9,7 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CER_MVS_LIB") or os.path.join(_HERE, "csrc", "libcermvs.so")
-ABI_VERSION = 1060
+ABI_VERSION = 1070
 CONV_MAX_SRC = 4
 EPI_LINEAR, EPI_RELU, EPI_GATES, EPI_GRU, EPI_DELTA = 0, 1, 2, 3, 4
 EPI_OUT_SPLIT, EPI_AUX_SPLIT = 0x100, 0x200       # cer_mvs.h: split32 activation layout flags, or-ed into `epi`
@@ -80,6 +80,7 @@ _SIGNATURES = {
     "cer_enc_stem_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cer_enc_conv_packed_size": (_L, [_I, _I, _I]),
     "cer_enc_conv_pack": (_I, [_P, _P, _I, _I, _I]),
+    "cer_enc_conv_pack_f6": (_I, [_P, _P, _I, _I, _I]),
     "cer_enc_conv_tiles": (_I, [_I, _I, _I, _I, _I]),
     "cer_enc_conv_f16x3": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "cer_enc_stats_reduce_f32": (_I, [_P, _P, _I, _I, _I, _L, _F, _P]),

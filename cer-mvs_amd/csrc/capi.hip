@@ -2,7 +2,7 @@
 #include "common.hpp"
 #include <string.h>
 
-extern "C" int cer_abi_version(void) { return 1060; }
+extern "C" int cer_abi_version(void) { return 1070; }
 
 extern "C" const char* cer_error_string(int code) {
     switch (code) {

@@ -45,6 +45,11 @@ class _Conv:
         L.check(lib.cer_enc_conv_pack(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(packed.data_ptr()), self.cout, self.cin, self.taps),
                 "enc_conv_pack")
         self.packed = packed.to(device)
+        # the same weights in the FP6-correction form (csrc/enc_pc.hip, round 6): same size and plane order, the lo planes as e2m3 K blocks
+        packed6 = torch.empty(size, dtype=torch.float16)
+        L.check(lib.cer_enc_conv_pack_f6(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(packed6.data_ptr()), self.cout, self.cin, self.taps),
+                "enc_conv_pack_f6")
+        self.packed_f6 = packed6.to(device)
         self.bias = conv.bias.detach().to(device, torch.float32).contiguous()
 
 
@@ -56,6 +61,9 @@ class HipEncoder:
             raise NotImplementedError("HipEncoder: only type 'HR' with norm 'instance' or 'none'")
         self.inorm = enc.norm_fn == "instance"
         self.device = device
+        # arithmetic of the producer / consumer convolutions: False = three f16 MFMA terms per product (fp32-class), True = the correction
+        # terms on the FP6 form of the block-scaled matrix instruction (half the matrix cycles; RAFT sets it per forward: enc_precision)
+        self.f6 = False
         w = enc.conv1.weight.detach().to("cpu", torch.float32)
         self.stem_w = w.permute(1, 2, 3, 0).reshape(147, 32).contiguous().to(device)
         self.stem_b = enc.conv1.bias.detach().to(device, torch.float32).contiguous()
@@ -138,9 +146,9 @@ class HipEncoder:
             if self.inorm and want_stats:
                 part = torch.empty(N, lib.cer_enc_pc_tiles(ho, wo, c.cout, c.taps, c.stride), c.cout, 2, device=self.device, dtype=torch.float32)
         m = torch.empty(N, h * w, c.cin, device=self.device, dtype=torch.float32) if merged else None
-        flags = (1 if x.rA else 0) | ((2 if x.rB else 0) | 4 if x.B is not None else 0)
+        flags = (1 if x.rA else 0) | ((2 if x.rB else 0) | 4 if x.B is not None else 0) | (8 if self.f6 else 0)
         L.check(lib.cer_enc_pc_conv(L.dev_ptr(x.A, "srcA"), L.dev_ptr(x.sA, "statsA"), L.dev_ptr(x.B, "srcB"), L.dev_ptr(x.sB, "statsB"), flags,
-                                    L.dev_ptr(m, "merged"), L.dev_ptr(c.packed, "w", torch.float16), L.dev_ptr(c.bias, "bias"), L.dev_ptr(out, "out"),
+                                    L.dev_ptr(m, "merged"), L.dev_ptr(c.packed_f6 if self.f6 else c.packed, "w", torch.float16), L.dev_ptr(c.bias, "bias"), L.dev_ptr(out, "out"),
                                     L.dev_ptr(out2, "out2"), L.dev_ptr(part, "part"), N, h, w, c.cin, c.cout, c.taps, c.stride, epi, border,
                                     float(scale), L.cur_stream()), "enc_pc_conv")
         st = self._stats(part, N, part.shape[1], c.cout, ho * wo) if part is not None else None
@@ -215,9 +223,9 @@ class HipEncoder:
         lib = L.load()
 
         def head(part, n, out, b):
-            flags = (1 if part.rA else 0) | ((2 if part.rB else 0) | 4 if part.B is not None else 0)
+            flags = (1 if part.rA else 0) | ((2 if part.rB else 0) | 4 if part.B is not None else 0) | (8 if self.f6 else 0)
             L.check(lib.cer_enc_pc_conv(L.dev_ptr(part.A, "srcA"), L.dev_ptr(part.sA, "statsA"), L.dev_ptr(part.B, "srcB"), L.dev_ptr(part.sB, "statsB"),
-                                        flags, None, L.dev_ptr(self.head.packed, "w", torch.float16), L.dev_ptr(self.head.bias, "bias"),
+                                        flags, None, L.dev_ptr(self.head.packed_f6 if self.f6 else self.head.packed, "w", torch.float16), L.dev_ptr(self.head.bias, "bias"),
                                         L.dev_ptr(out, "out", torch.float16), L.dev_ptr(flag, "flag", torch.int32), None, n, h, w, self.head.cin,
                                         self.head.cout, 1, 1, 3, b, float(scale), L.cur_stream()), "enc_pc_conv(fsplit)")
         if n_ref > 0:

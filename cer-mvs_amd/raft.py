@@ -45,7 +45,8 @@ class SaturationError(RuntimeError):
 
 class RAFT(nn.Module):
     def __init__(self, cascade=[(64, 64, 8), (-1, 320, 8)], encoder_type="HR", dim_fmap=64, dim_net=64, dim_inp=64,
-                 test_mode=False, precision="fp32", view_group=None, gru_precision="auto", encoder_backend="hip", shard="slab"):
+                 test_mode=False, precision="fp32", view_group=None, gru_precision="auto", encoder_backend="hip", shard="slab",
+                 enc_precision="auto"):
         super().__init__()
         self.cascade = [tuple(c) for c in cascade]
         self.encoder_type = encoder_type
@@ -60,8 +61,16 @@ class RAFT(nn.Module):
         if gru_precision not in ("auto", "s16f6", "s16f8", "s16", "f16x3", "fp32"):
             raise ValueError(f"RAFT: unknown gru_precision {gru_precision!r}")
         self.gru_precision = gru_precision
+        # enc_precision (round 6): arithmetic of the encoders' producer / consumer convolutions (csrc/enc_pc.hip).  "f16x3": three f16 MFMA
+        # terms per product (fp32-class; rounds 2-5); "f6": the two correction terms on the FP6 (e2m3, block-scaled) form of
+        # v_mfma_scale_f32_32x32x64_f8f6f4 - half the matrix cycles, features 4e-5 from the f16 form; "auto" (default): part of the
+        # gru_precision="auto" calibration walk (AUTO_FORMS: a "+e6" suffix = encoders in the FP6 form) and "f16x3" whenever gru_precision is pinned.
+        if enc_precision not in ("auto", "f16x3", "f6"):
+            raise ValueError(f"RAFT: unknown enc_precision {enc_precision!r}")
+        self.enc_precision = enc_precision
+        self._enc_f6 = enc_precision == "f6"
         self.update_block.conv_mode = "s16" if gru_precision in ("s16f6", "s16f8", "auto") else gru_precision
-        self.update_block.corr_fp8 = self._CORR_FORM.get(gru_precision if gru_precision != "auto" else self.AUTO_FORMS[0], False)
+        self._set_form(gru_precision if gru_precision != "auto" else self.AUTO_FORMS[0])
         # "auto" (default): the fp8-correction form keeps ~15 product bits in the correction terms; how much of that reaches the depth
         # depends on how the update block's weights condition the 32-iteration recurrence (tests/test_determinism_gpu.py: 22-38 x the
         # all-f16 form's distance from exact fp32 - 3e-6 on the golden weights, 3e-4 with the conv weights doubled and heavy-tailed).
@@ -101,6 +110,19 @@ class RAFT(nn.Module):
 
     def _drop_engines(self):
         self._engines = None
+
+    def _set_form(self, form):
+        """arithmetic form of a forward: a gru_precision name, optionally "+e6" (encoders in the FP6-correction form; honoured with enc_precision="auto")"""
+        g, _, e = form.partition("+")
+        self.update_block.corr_fp8 = self._CORR_FORM.get(g, False)
+        self._enc_f6 = self.enc_precision == "f6" or (self.enc_precision == "auto" and e == "e6")
+
+    def _get_engines(self, dev):
+        from .encoder_hip import HipEncoder
+        if self._engines is None or self._engines[0] != dev:
+            self._engines = (dev, HipEncoder(self.fnet, dev), HipEncoder(self.cnet, dev))
+        self._engines[1].f6 = self._engines[2].f6 = bool(self._enc_f6)
+        return self._engines
 
     def _params_sig(self):
         """Identity + in-place version of every parameter: packed weights are a cache of these (optimizer steps, copy_, deepcopy)."""
@@ -167,10 +189,8 @@ class RAFT(nn.Module):
             if not views:
                 return None, None, None, None
             if self.encoder_backend == "hip" and self.precision == "fp32" and self.encoder_type == "HR":
-                from .encoder_hip import HipEncoder
                 dev = images.device
-                if self._engines is None or self._engines[0] != dev:
-                    self._engines = (dev, HipEncoder(self.fnet, dev), HipEncoder(self.cnet, dev))
+                self._get_engines(dev)
                 factor = 4
                 h, w = images.shape[-2] // factor, images.shape[-1] // factor
                 key = (len(views), h, w, str(dev))
@@ -191,11 +211,8 @@ class RAFT(nn.Module):
         idx = [0] + list(views)
         stack = images[0] if idx == list(range(images.shape[1])) else images[0, idx]      # (no gather copy when every view is local)
         if self.encoder_backend == "hip" and self.precision == "fp32" and self.encoder_type == "HR":
-            from .encoder_hip import HipEncoder
             dev = images.device
-            if self._engines is None or self._engines[0] != dev:
-                self._engines = (dev, HipEncoder(self.fnet, dev), HipEncoder(self.cnet, dev))
-            _, eng_f, eng_c = self._engines
+            _, eng_f, eng_c = self._get_engines(dev)
             net, inp, h, w = eng_c.context(images[0, :1], raw=raw)
             key = (len(views), h, w, str(dev))
             buf = self._src_buf.get(key)
@@ -235,11 +252,8 @@ class RAFT(nn.Module):
         f16 hi|lo and builds that batch's partial cost volumes (cer_cost_lines_views_f32) - a kernel bound by vector issue and LDS
         latency that leaves the matrix pipe and most issue slots idle - while the main stream encodes the next batch (MFMA / HBM
         bound).  Returns (net, inp, f1, f2, (f1s, f2s), event of the last build); the caller finishes the volume with ops.cost_lines_reduce."""
-        from .encoder_hip import HipEncoder
         dev = images.device
-        if self._engines is None or self._engines[0] != dev:
-            self._engines = (dev, HipEncoder(self.fnet, dev), HipEncoder(self.cnet, dev))
-        _, eng_f, eng_c = self._engines
+        _, eng_f, eng_c = self._get_engines(dev)
         main = torch.cuda.current_stream()
         side = _SIDE_STREAMS.get(str(dev))          # (module-level: streams / events must not end up in a deep copy of the model)
         if side is None:
@@ -279,11 +293,8 @@ class RAFT(nn.Module):
 
     def _encode_direct_split(self, images, V, h, w):
         """encode() whose feature head writes the cost volume's split-f16 operand planes directly -> (net, inp, (f1s, f2s, slots))."""
-        from .encoder_hip import HipEncoder
         dev = images.device
-        if self._engines is None or self._engines[0] != dev:
-            self._engines = (dev, HipEncoder(self.fnet, dev), HipEncoder(self.cnet, dev))
-        _, eng_f, eng_c = self._engines
+        _, eng_f, eng_c = self._get_engines(dev)
         net, inp, _, _ = eng_c.context(images[0, :1], raw=True)
         key = ("split", V, h, w, str(dev))
         buf = self._src_buf.get(key)
@@ -360,7 +371,7 @@ class RAFT(nn.Module):
         if (self.gru_precision != "auto" or other.gru_precision != "auto" or other.auto_choice is None or other._auto_pending()
                 or self.update_block.conv_mode != other.update_block.conv_mode):
             return False
-        self.update_block.corr_fp8 = other.update_block.corr_fp8
+        self.update_block.corr_fp8, self._enc_f6 = other.update_block.corr_fp8, other._enc_f6
         self.auto_choice, self.auto_error = other.auto_choice, other.auto_error
         self._auto_sig, self._auto_left = self._params_sig(), 0
         return True
@@ -374,7 +385,7 @@ class RAFT(nn.Module):
         if self._auto_sig != self._params_sig():   # new weights: start over
             self._auto_left, self.auto_error, self.auto_choice = self.AUTO_INPUTS, 0.0, None
         ref_form = self.AUTO_FORMS[-1]
-        ub.corr_fp8 = self._CORR_FORM[ref_form]
+        self._set_form(ref_form)
         out16 = self._forward_fast(images, poses, intrinsics, scale, do_report).clone()
         self._auto_sig = self._params_sig()
         if ub.conv_mode != "s16":                  # (the weights did not fit a shared split-f16 scale: the forward fell back to f16x3 kernels)
@@ -385,7 +396,7 @@ class RAFT(nn.Module):
         cand = self.auto_choice if self.auto_choice in self.AUTO_FORMS else self.AUTO_FORMS[0]
         out, tried = out16, []
         while cand != ref_form:
-            ub.corr_fp8 = self._CORR_FORM[cand]
+            self._set_form(cand)
             outc = self._forward_fast(images, poses, intrinsics, scale, do_report)
             diff = (outc - out16).abs()
             err = float((diff.sum() / den).item())
@@ -404,7 +415,7 @@ class RAFT(nn.Module):
         ok = cand != ref_form
         self._auto_left = (self._auto_left - 1) if ok else 0
         self.auto_choice = cand
-        ub.corr_fp8 = self._CORR_FORM[cand]
+        self._set_form(cand)
         if any(e > self.AUTO_TOL or m > self.AUTO_MAX_TOL or e != e or m != m for _, e, m in tried):
             import warnings
             missed = "; ".join(f"{f}: {e:.2e} relative L1, largest single difference {m:.2e} of the largest disparity" for f, e, m in tried
@@ -457,10 +468,7 @@ class RAFT(nn.Module):
                         and self.precision == "fp32" and self.encoder_type == "HR" and self.dim_fmap == 64
                         and L.load().cer_cost_build_algo(-1) != 1 and all(D_ <= 64 for D_, _, _ in self.stages()))
         if direct_split:
-            from .encoder_hip import HipEncoder
-            if self._engines is None or self._engines[0] != dev:
-                self._engines = (dev, HipEncoder(self.fnet, dev), HipEncoder(self.cnet, dev))
-            direct_split = self._engines[1].supports_split_head()
+            direct_split = self._get_engines(dev)[1].supports_split_head()
         if pipelined:
             net_l, inp_l, f1, f2, split, build_done = self._encode_pipelined(images, V, Pij, disp, D0, incre0, h, w)
         elif direct_split:

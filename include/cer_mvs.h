@@ -423,9 +423,15 @@ int cer_enc_merge_f32(const float* a, const float* a_stats, const float* b, cons
  * cer_cost_lines_f32 - `out` = [N][8 planes][(ho+2b)*(wo+2b)][16] halves, exactly what cer_feat_split_f16 makes of the FMAP output
  * (border texels are not written: zero the buffer once); `out2`, if not NULL, is the device overflow flag (int*; bit 1 on saturation).
  * Shapes: cer_enc_pc_supported(Cin, Cout, taps, stride, epi) != 0 - the "HR" encoder's: 32->32 3x3; 32->64 3x3 / 1x1 stride 2;
- * 64->64 3x3; 64->64 1x1 FMAP; 64->128 1x1 CTX.  Everything else returns CER_ESHAPE (use cer_enc_conv_f16x3). */
+ * 64->64 3x3; 64->64 1x1 FMAP; 64->128 1x1 CTX.  Everything else returns CER_ESHAPE (use cer_enc_conv_f16x3).
+ * Round 6 (ABI 1070), the FP6-correction form: with `flags & 8` and weights packed by cer_enc_conv_pack_f6 (same size and plane order as
+ * cer_enc_conv_pack; the lo planes hold e2m3 K blocks instead) the two correction terms of a 32-channel tap run as ONE
+ * v_mfma_scale_f32_32x32x64_f8f6f4 with both operands in e2m3 and one power-of-two scale per (pixel | output channel, 16-channel block):
+ * half the matrix-pipe cycles of the three-term f16 form, ~15 instead of ~22 product bits in the correction terms (features 4e-5 relative L1
+ * from the f16 form, 7e-6 on the final disparity: RAFT's "auto" calibration decides per set of weights).  Same shapes, epilogues and outputs. */
 int cer_enc_pc_supported(int Cin, int Cout, int taps, int stride, int epi);
 int cer_enc_pc_tiles(int ho, int wo, int Cout, int taps, int stride);
+int cer_enc_conv_pack_f6(const float* w_oihw, void* packed, int Cout, int Cin, int taps);
 int cer_enc_pc_conv(const float* srcA, const float* statsA, const float* srcB, const float* statsB, int flags, float* merged_out,
                     const void* packed_w, const float* bias, float* out, float* out2, float* stats_partial, int N, int h, int w,
                     int Cin, int Cout, int taps, int stride, int epi, int out_border, float out_scale, void* stream);
