@@ -69,6 +69,8 @@ def parse():
                          "of the multi-rank code path on a box with fewer GPUs than ranks: ranks share devices)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "amp"])
     ap.add_argument("--encoder", default="hip", choices=["hip", "miopen"], help="encoder backend: channels-last HIP engine or PyTorch-ROCm (MIOpen)")
+    ap.add_argument("--enc-precision", default="auto", choices=["auto", "f16x3", "f6"],
+                    help="arithmetic of the encoders' convolutions: three f16 MFMA terms, or the correction terms in FP6 (RAFT enc_precision)")
     ap.add_argument("--gru-precision", default="auto", choices=["auto", "s16f6", "s16f8", "s16", "f16x3", "fp32"],
                     help="arithmetic of the update block's 3x3 convs: split-f16 MFMA (s16f8: correction terms on the fp8 matrix instruction, "
                          "4e-6 from fp32; s16: all-f16, fp32-class, one accumulator; f16x3: round-1 kernels), or exact fp32 MFMA.  auto (the "
@@ -254,7 +256,8 @@ def main():
         """W warm-up + K timed forwards in one sharding mode -> (seconds: max over ranks, output, model, inputs, weights)."""
         shard = world > 1 and mode in ("shard", "views")
         model = RAFT(cascade=cascade, test_mode=True, precision=args.precision, view_group=group if shard else None,
-                     gru_precision=args.gru_precision, encoder_backend=args.encoder, shard="slab" if mode == "shard" else "views")
+                     gru_precision=args.gru_precision, encoder_backend=args.encoder, shard="slab" if mode == "shard" else "views",
+                     enc_precision=args.enc_precision)
         sd = fill_state_dict(model.state_dict(), seed=5)
         model.load_state_dict(sd)
         model = model.to(dev).eval()
@@ -340,8 +343,9 @@ def main():
     elapsed, out, model, inputs, scale, sd = timed_run(args.mode)
     requested_precision = args.gru_precision
     if args.gru_precision == "auto":     # the form the calibration kept (cer-mvs_amd/raft.py: RAFT._forward_calibrating) is what was timed
-        assert model.auto_choice in ("s16f6", "s16f8", "s16"), "the warm-up did not calibrate gru_precision='auto'"
-        args.gru_precision = model.auto_choice
+        assert model.auto_choice is not None and model.auto_choice.partition("+")[0] in ("s16f6", "s16f8", "s16"), "the warm-up did not calibrate gru_precision='auto'"
+        args.gru_precision = model.auto_choice.partition("+")[0]
+    enc_f6 = bool(model._enc_f6)          # what the timed forwards ran the encoders in
     if modes is not None:
         modes[args.mode].update(value=args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps, headline=True)
     maps = args.steps * (world if (world > 1 and not shard) else 1)
@@ -350,7 +354,8 @@ def main():
     n1_ref = None
     if world > 1:
         if rank == 0:
-            m1 = RAFT(cascade=cascade, test_mode=True, precision=args.precision, gru_precision=args.gru_precision, encoder_backend=args.encoder)
+            m1 = RAFT(cascade=cascade, test_mode=True, precision=args.precision, gru_precision=args.gru_precision, encoder_backend=args.encoder,
+                      enc_precision="f6" if enc_f6 else "f16x3")
             m1.load_state_dict(sd)
             m1 = m1.to(dev).eval()
             with torch.no_grad():
@@ -522,20 +527,24 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong" if (shard or world == 1) else "weak", "vs_baseline": None,
             "dtype": ("f32" if args.precision == "fp32" else "f32 (encoders f16 autocast)")
-                     + (" [dense convs: f32 operands split into 2 x f16, f32 accumulate; encoders 3 f16 MFMAs per product (fp32-class), "
+                     + ((" [dense convs: f32 operands split into 2 x f16, f32 accumulate; encoders 3 f16 MFMAs per product (fp32-class), "
                         "update-block convs f16 main term + the two 2^-11 correction terms in e4m3 on the fp8 MFMA: 4e-6 relative L1 from fp32 "
                         "end to end, bar 1e-4]" if args.gru_precision == "s16f8" else
                         " [dense convs: f32 operands split into 2 x f16, f32 accumulate; encoders 3 f16 MFMAs per product (fp32-class), "
                         "update-block convs f16 main term + the two 2^-11 correction terms in e2m3 (FP6, one power-of-two scale per 16-channel "
                         "block) on the block-scaled MFMA: ~5e-6 relative L1 from fp32 end to end, bar 1e-4]" if args.gru_precision == "s16f6" else
-                        " [dense convs: f32 operands split into 2 x f16, 3 MFMAs per product, f32 accumulate - fp32-class]" if split else ""),
+                        " [dense convs: f32 operands split into 2 x f16, 3 MFMAs per product, f32 accumulate - fp32-class]" if split else "")
+                        .replace("encoders 3 f16 MFMAs per product (fp32-class), ",
+                                 "encoders f16 main term + the two 2^-11 correction terms in e2m3 (FP6, one power-of-two scale per 16-channel block: features "
+                                 "4e-5 from the three-term form), " if enc_f6 else "encoders 3 f16 MFMAs per product (fp32-class), ")),
             "data": "synthetic",
-            "gru_precision": {"requested": requested_precision, "timed": args.gru_precision,
-                              **({"calibration_rel_l1_vs_s16": model.auto_error, "candidates": list(model.AUTO_FORMS), "tolerance": model.AUTO_TOL,
+            "enc_precision": {"requested": args.enc_precision, "timed": "f6" if enc_f6 else "f16x3"},
+            "gru_precision": {"requested": requested_precision, "timed": args.gru_precision, "auto_form": model.auto_choice,
+                              **({"calibration_rel_l1_vs_s16": model.auto_error, "candidates": list(model._auto_forms()), "tolerance": model.AUTO_TOL,
                                   "calibration_inputs": model.AUTO_INPUTS,
                                   "note": "gru_precision='auto': the first forwards of a set of weights (calibration_inputs of them, inside the "
-                                          "warm-up) run in the fp32-class form 's16' and in the cheapest candidate still standing (FP6 corrections, then fp8 "
-                                          "corrections); a candidate is kept only if it agrees with 's16' within the tolerance on every one of "
+                                          "warm-up) run in the fp32-class form 's16' and in the cheapest candidate still standing ('+e6': the encoders' correction "
+                                          "terms in FP6 as well as the update block's in fp8; then fp8 corrections in the update block only); a candidate is kept only if it agrees with 's16' within the tolerance on every one of "
                                           "them (the figure is the kept form's worst)"}
                                  if requested_precision == "auto" else {})},
             "config": {"workload": args.workload, "image": f"{W}x{H}", "src_views": V, "cascade": cascade,

@@ -490,7 +490,7 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
         for (int m = 0; m < C::RPW; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                accm[m][r] = bias;
+                accm[m][r] = F6 ? 0.f : bias;       // (FP6 form: the bias joins in the epilogue - a splat of it would hold 16 registers through the tile loop)
                 accl[m][r] = 0.f;
             }
 #pragma unroll
@@ -682,7 +682,7 @@ __device__ __forceinline__ void pc_consumer(const PcArgs& a, const char* __restr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int pxc = (r & 3) + 8 * (r >> 2);
-                    float v = F6 ? (ROLL ? accm[m][r] : accm[m][r] + accl[m][r]) : fmaf(accl[m][r], 1.0f / 2048.0f, accm[m][r]);
+                    float v = F6 ? (ROLL ? accm[m][r] + bias : (accm[m][r] + accl[m][r]) + bias) : fmaf(accl[m][r], 1.0f / 2048.0f, accm[m][r]);
                     if (EPI == PC_EPI_RAW) {
                         if (FULL || (gy < a.ho && tx0 + pxc + 4 * kg < a.wo)) {
                             ssum += v;

@@ -70,7 +70,7 @@ class RAFT(nn.Module):
         self.enc_precision = enc_precision
         self._enc_f6 = enc_precision == "f6"
         self.update_block.conv_mode = "s16" if gru_precision in ("s16f6", "s16f8", "auto") else gru_precision
-        self._set_form(gru_precision if gru_precision != "auto" else self.AUTO_FORMS[0])
+        self._set_form(gru_precision if gru_precision != "auto" else self._auto_forms()[0])
         # "auto" (default): the fp8-correction form keeps ~15 product bits in the correction terms; how much of that reaches the depth
         # depends on how the update block's weights condition the 32-iteration recurrence (tests/test_determinism_gpu.py: 22-38 x the
         # all-f16 form's distance from exact fp32 - 3e-6 on the golden weights, 3e-4 with the conv weights doubled and heavy-tailed).
@@ -355,10 +355,17 @@ class RAFT(nn.Module):
     # gru_precision="auto": candidates, cheapest first (the last one is the fp32-class reference).  "s16f6" is NOT among them by default: built and
     # measured in round 6 it costs the same time as "s16f8" - the chunk loop is not bound by the matrix pipe any more - and
     # sits 1.3 x further from fp32; a caller may put it in front (RAFT.AUTO_FORMS = ("s16f6", "s16f8", "s16")) or pin gru_precision="s16f6".
-    AUTO_FORMS = ("s16f8", "s16")
+    # Round 6, second half: a "+e6" suffix puts the ENCODERS' correction terms on the FP6 form as well (csrc/enc_pc.hip; enc_precision="auto" only -
+    # with the encoders pinned the suffixed candidates drop out, `_auto_forms`).  There it does pay (+ 3.8 % depth maps per second, same-box A/B,
+    # profiles/r06_encoder_fp6_ab.txt; 1.2e-5 from the reference capture on the bench workload), so it IS the first default candidate.
+    AUTO_FORMS = ("s16f8+e6", "s16f8", "s16")
     AUTO_TOL = 2.5e-5                             # a quarter of the 1e-4 parity bar
     AUTO_MAX_TOL = 1e-3                           # ... and no single pixel further apart than this fraction of the largest disparity
     AUTO_INPUTS = 3                               # inputs the decision rests on (the worst one counts)
+
+    def _auto_forms(self):
+        """the calibration walk's candidates for this model: AUTO_FORMS, without the "+e6" forms when the encoders' arithmetic is pinned"""
+        return tuple(f for f in self.AUTO_FORMS if self.enc_precision == "auto" or "+" not in f)
 
     def _auto_pending(self):
         return self.update_block.conv_mode == "s16" and (self._auto_sig != self._params_sig() or self._auto_left > 0)
@@ -384,7 +391,8 @@ class RAFT(nn.Module):
         ub = self.update_block
         if self._auto_sig != self._params_sig():   # new weights: start over
             self._auto_left, self.auto_error, self.auto_choice = self.AUTO_INPUTS, 0.0, None
-        ref_form = self.AUTO_FORMS[-1]
+        forms = self._auto_forms()
+        ref_form = forms[-1]
         self._set_form(ref_form)
         out16 = self._forward_fast(images, poses, intrinsics, scale, do_report).clone()
         self._auto_sig = self._params_sig()
@@ -393,7 +401,7 @@ class RAFT(nn.Module):
             return out16
         den = out16.abs().sum().clamp_min(1e-30)
         big = out16.abs().max().clamp_min(1e-30)
-        cand = self.auto_choice if self.auto_choice in self.AUTO_FORMS else self.AUTO_FORMS[0]
+        cand = self.auto_choice if self.auto_choice in forms else forms[0]
         out, tried = out16, []
         while cand != ref_form:
             self._set_form(cand)
@@ -409,7 +417,7 @@ class RAFT(nn.Module):
                 self.auto_error = max(self.auto_error or 0.0, err)
                 out = outc
                 break
-            cand = self.AUTO_FORMS[self.AUTO_FORMS.index(cand) + 1]      # demoted: the next form is tested on this same input
+            cand = forms[forms.index(cand) + 1]      # demoted: the next form is tested on this same input
         if cand == ref_form and tried:
             self.auto_error = tried[-1][1]
         ok = cand != ref_form

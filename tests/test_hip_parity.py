@@ -706,6 +706,37 @@ def test_hip_encoder_engine_matches_oracle(dev, which, size):
     assert rel_l1(got, ref) < 1e-5
 
 
+@pytest.mark.parametrize("size", [(72, 104), (128, 160), (70, 132), (296, 400)])
+@pytest.mark.parametrize("which", ["fnet", "cnet"])
+def test_hip_encoder_fp6_correction_form(dev, which, size):
+    """Round 6: the producer / consumer convolutions with both correction terms of a tap on ONE e2m3 (FP6) MFMA with a power-of-two scale
+    per (pixel | output channel, 16-channel block) - csrc/enc_pc.hip, flags & 8, cer_enc_conv_pack_f6.  Costed on the oracle before it was built
+    (tools/experiments/encoder_corr_numerics.py: features 4.4e-5 / context 2.3e-5 relative L1 from fp32); the kernels must land THERE - a lost
+    term or a wrong scale byte is 1e-3 (the f16-only product) or worse - be a different arithmetic from the three-term form (the flag took effect)
+    and reproduce bit for bit.  Sizes with partial tiles in both directions; (296, 400) has interior AND border units."""
+    from cer_mvs_amd import RAFT
+    from cer_mvs_amd.encoder_hip import HipEncoder
+    from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
+    from oracle import cer_oracle as O
+    images, _, _, _ = synthetic_scene(size[0], size[1], 2, seed=8)
+    model = RAFT(test_mode=True)
+    sd = fill_state_dict(model.state_dict(), seed=13)
+    model.load_state_dict(sd)
+    x = images[0].float() * (2 / 255.0) - 1
+    eng = HipEncoder(getattr(model, which), dev)
+    with torch.no_grad():
+        g3 = eng.forward_nchw(x.to(dev)).cpu()
+        eng.f6 = True
+        g6 = eng.forward_nchw(x.to(dev)).cpu()
+        again = eng.forward_nchw(x.to(dev)).cpu()
+        ref = O.encoder(x, sd, which + ".", "instance" if which == "fnet" else "none")
+    e3, e6, d = rel_l1(g3, ref), rel_l1(g6, ref), rel_l1(g6, g3)
+    print(f"{which} {size}: three-term form {e3:.2e}, FP6-correction form {e6:.2e} from the oracle; {d:.2e} apart")
+    assert torch.isfinite(g6).all() and torch.equal(g6, again)
+    assert e3 < 1e-5 and 2e-6 < d and e6 < (7e-5 if which == "fnet" else 4e-5)
+    assert float((g6 - g3).abs().max() / g3.abs().max()) < 3e-4
+
+
 @pytest.mark.parametrize("size", [(64, 96), (70, 130), (37, 51), (70, 132), (37, 52), (150, 260)])
 @pytest.mark.parametrize("raw", [False, True])
 def test_stem_on_matrix_cores(dev, size, raw):
@@ -780,7 +811,8 @@ def test_encoder_head_writes_split_planes_directly(dev, size):
     assert not ops.check_overflow(dev)
 
 
-def test_encoder_engine_batch_invariance_at_tnt_size(dev):
+@pytest.mark.parametrize("f6", [False, True])
+def test_encoder_engine_batch_invariance_at_tnt_size(dev, f6):
     """BASELINE.json configs[2] size (3840x2160, 16 images per fnet launch): layer-1 activations are 16 x 1080 x 1920 x 32
     floats = 4.2 GB, i.e. element offsets beyond 2^31 bytes.  Instance norm is per image, so the batched launch must
     reproduce, bit for bit, what the LAST image gives alone (an offset overflow would corrupt exactly the late images)."""
@@ -790,6 +822,7 @@ def test_encoder_engine_batch_invariance_at_tnt_size(dev):
     model = RAFT(test_mode=True)
     model.load_state_dict(fill_state_dict(model.state_dict(), seed=13))
     eng = HipEncoder(model.fnet, dev)
+    eng.f6 = f6
     N, H, W = 16, 2160, 3840
     g = torch.Generator(device="cpu").manual_seed(7)
     small = torch.rand(N, 3, H // 8, W // 8, generator=g) * 2 - 1
@@ -878,7 +911,7 @@ def test_large_configs_run(dev):
 
 
 # ------------------------------------------------------------------------------------ end to end
-def _run_e2e(dev, golden, name, literal=False, gru_precision="s16f8"):
+def _run_e2e(dev, golden, name, literal=False, gru_precision="s16f8", enc_precision="auto", info=None):
     from cer_mvs_amd import RAFT
     from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene, tensor_checksum
     g = golden(name)
@@ -886,9 +919,11 @@ def _run_e2e(dev, golden, name, literal=False, gru_precision="s16f8"):
     cascade = [tuple(int(x) for x in c) for c in g["cascade"]]
     images, poses, intr, scale = cached_scene(H, W, V, int(g["scene_seed"]))
     assert tensor_checksum(images) == int(g["images_checksum"])
-    model = RAFT(cascade=cascade, test_mode=True, gru_precision=gru_precision)
+    model = RAFT(cascade=cascade, test_mode=True, gru_precision=gru_precision, enc_precision=enc_precision)
     model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(g["weight_seed"])))
     model = model.to(dev).eval()
+    if info is not None:
+        info["model"] = model
     before = images.clone()
     with torch.no_grad():
         if literal:
@@ -925,6 +960,25 @@ def test_end_to_end_cfg1(dev, golden, gru_precision):
     # (measured: s16f8 3.9e-6 / 4.1e-6 - the e4m3 correction terms; s16f6, round 6: e2m3 with block scales, costed at 5.5e-6 by
     # tools/experiments/fp8_correction_numerics.py and gated at 1.5e-5 by VERDICT r5; the all-f16 and fp32 forms 1.9e-7 ... 2.2e-7)
     assert max(e_disp, e_depth) < {"s16f8": 2e-5, "s16f6": 1.5e-5}.get(gru_precision, 2e-6)
+
+
+@pytest.mark.parametrize("gru_precision", ["s16f8", "s16"])
+def test_end_to_end_cfg1_encoders_in_fp6_form(dev, golden, gru_precision):
+    """enc_precision="f6" against the reference's own output at configs[0]: with the update block fp32-class ("s16") the figure is the encoders'
+    contribution alone (costed at 7e-6 by tools/experiments/encoder_corr_numerics.py), with "s16f8" it is what the default "auto" form runs."""
+    e_disp, e_depth = _run_e2e(dev, golden, "e2e_cfg1", gru_precision=gru_precision, enc_precision="f6")
+    print(f"e2e_cfg1[{gru_precision} + encoders f6] rel-L1 disp {e_disp:.3e} depth {e_depth:.3e}")
+    assert 1e-6 < max(e_disp, e_depth) < 2.5e-5
+
+
+def test_end_to_end_cfg2_default_auto_form(dev, golden):
+    """The bench workload in the DEFAULT arithmetic: gru_precision="auto" calibrates on this input (reference form, then candidates) and returns
+    the kept form's result - whatever it keeps must sit inside a quarter of the bar from the reference's own output."""
+    info = {}
+    e_disp, e_depth = _run_e2e(dev, golden, "e2e_cfg2", gru_precision="auto", info=info)
+    m = info["model"]
+    print(f"e2e_cfg2[auto -> {m.auto_choice}, calibration {m.auto_error:.2e}] rel-L1 disp {e_disp:.3e} depth {e_depth:.3e}")
+    assert m.auto_choice in m._auto_forms() and max(e_disp, e_depth) < 2.5e-5
 
 
 def test_end_to_end_cfg2_bench_workload(dev, golden):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sustained launch time of one producer / consumer encoder conv (40 back-to-back launches at cfg2's shape; the chip drops its
 clock under these kernels, so the first launches of an idle chip are ~25 % faster than the steady state a forward sees).
-usage: [CER_MVS_LIB=variant.so] bench_pc.py [32|64|s2] [dual]"""
+usage: [CER_MVS_LIB=variant.so] [CER_ENC_F6=1] bench_pc.py [32|64|s2] [dual]      (CER_ENC_F6=1: the FP6-correction form)"""
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cer_mvs_amd import RAFT
@@ -13,6 +13,7 @@ dual = len(sys.argv) > 2 and sys.argv[2] == "dual"
 dev = torch.device("cuda")
 model = RAFT(test_mode=True); model.load_state_dict(fill_state_dict(model.state_dict(), seed=5))
 eng = E.HipEncoder(model.fnet, dev)
+eng.f6 = os.environ.get("CER_ENC_F6", "0") == "1"
 N = 11
 h, w, c = {"32": (592, 800, eng.blocks[0][0]), "64": (296, 400, eng.blocks[2][1]), "s2": (592, 800, eng.blocks[2][0])}[which]
 x = torch.randn(N, h * w, c.cin, device=dev); y = torch.randn(N, h * w, c.cin, device=dev)
@@ -26,4 +27,4 @@ for i in range(L):
     ev[i + 1].record()
 torch.cuda.synchronize()
 ts = [ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(L)]
-print(f"{os.path.basename(os.environ.get('CER_MVS_LIB', 'libcermvs.so')):28s} {which} dual={dual}: first {ts[0]:.0f} us, peak {max(ts):.0f}, steady (last 15) {statistics.mean(ts[-15:]):.0f} us")
+print(f"{os.path.basename(os.environ.get('CER_MVS_LIB', 'libcermvs.so')):28s} {which} dual={dual} f6={eng.f6}: first {ts[0]:.0f} us, peak {max(ts):.0f}, steady (last 15) {statistics.mean(ts[-15:]):.0f} us")
