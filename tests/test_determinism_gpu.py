@@ -215,8 +215,8 @@ def test_precision_margin_under_weight_gain(dev, gain, tail):
                 v = torch.where(m, v * 8.0, v)
             sd[k_] = v
     outs, choice = {}, None
-    for prec in ("fp32", "s16", "s16f8", "f16x3", "auto"):
-        model = RAFT(cascade=cascade, test_mode=True, gru_precision=prec)
+    for prec in ("fp32", "s16", "s16f8", "s16f8+e6", "f16x3", "auto"):          # ("+e6": the encoders' correction terms in FP6 as well, round 6)
+        model = RAFT(cascade=cascade, test_mode=True, gru_precision=prec.partition("+")[0], enc_precision="f6" if prec.endswith("+e6") else "auto")
         model.load_state_dict(sd)
         model = model.to(dev).eval()
         model.overflow_policy = "ignore"
