@@ -278,11 +278,6 @@ __device__ __forceinline__ void pc_producer(const PcArgs& a, char* __restrict__ 
         }
     };
     float muA[8], rsA[8], muB[8], rsB[8];                                        // rs = 2048 rstd
-    // FP6 form: the normalisation as ONE packed fma per two values, y = v * rs + (-mu * rs) (v_pk_fma_f32) instead of a subtraction and a
-    // multiplication per value - its rounding differs from (v - mu) * rs by ~|mu| / sigma x 6e-8 of a normalised unit, three orders below this
-    // form's own correction terms; the three-term form keeps the exact expression (fp32-class, bit for bit rounds 4-5).  The producers are
-    // bound by vector issue, and in the two-tensor (DUAL) forms they are the kernel's critical path once the matrix work is halved.
-    cer_f2 rsA2[4], nbA2[4], rsB2[4], nbB2[4];
     int cur_key = -1;
     auto commit_items = [&](auto border_tag, auto bplain_tag, int img, int ty0, int tx0, int c0, char* buf) {
         constexpr bool BORDER = decltype(border_tag)::value, BPLAIN = decltype(bplain_tag)::value;
@@ -298,23 +293,6 @@ __device__ __forceinline__ void pc_producer(const PcArgs& a, char* __restrict__ 
                 const float4 b0 = rawB[ib * i][0], b1 = rawB[ib * i][1];
                 const float vb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
                 float yv[8];
-                if constexpr (F6) {
-                    cer_f2 ya2[4], yb2[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        ya2[k] = __builtin_elementwise_fma((cer_f2){va[2 * k], va[2 * k + 1]}, rsA2[k], nbA2[k]);
-                        if (DUAL) {
-                            const cer_f2 vb2 = (cer_f2){vb[2 * k], vb[2 * k + 1]};
-                            yb2[k] = BPLAIN ? vb2 * 2048.0f : __builtin_elementwise_max(__builtin_elementwise_fma(vb2, rsB2[k], nbB2[k]), (cer_f2){lowB, lowB});
-                            ya2[k] = __builtin_elementwise_max(ya2[k], (cer_f2){lowA, lowA}) + yb2[k];
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float y = __builtin_amdgcn_fmed3f(ya2[e >> 1][e & 1], DUAL ? lowS : lowA, PC_YMAX);
-                        yv[e] = (BORDER && !inside) ? 0.f : y;
-                    }
-                } else
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float y;
@@ -383,15 +361,6 @@ __device__ __forceinline__ void pc_producer(const PcArgs& a, char* __restrict__ 
                 rsA[e] = (a.tfA ? a.tfA[s + 1] : 1.f) * 2048.0f;
                 muB[e] = (DUAL && a.tfB) ? a.tfB[s] : 0.f;
                 rsB[e] = ((DUAL && a.tfB) ? a.tfB[s + 1] : 1.f) * 2048.0f;
-            }
-            if constexpr (F6) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    rsA2[k] = (cer_f2){rsA[2 * k], rsA[2 * k + 1]};
-                    nbA2[k] = (cer_f2){-muA[2 * k] * rsA[2 * k], -muA[2 * k + 1] * rsA[2 * k + 1]};
-                    rsB2[k] = (cer_f2){rsB[2 * k], rsB[2 * k + 1]};
-                    nbB2[k] = (cer_f2){-muB[2 * k] * rsB[2 * k], -muB[2 * k + 1] * rsB[2 * k + 1]};
-                }
             }
         }
         char* buf = lds + (u & 1) * C::BUF;
