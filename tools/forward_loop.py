@@ -16,10 +16,11 @@ ap.add_argument("--workload", default="dtu_1600x1184_v10_it32", choices=sorted(b
 ap.add_argument("--streams", type=int, default=1)
 ap.add_argument("--forwards", type=int, default=12)
 ap.add_argument("--gru-precision", default="s16f8")
+ap.add_argument("--enc-precision", default="f6", help="the shipped auto form on the bench weights is s16f8+e6: encoders in the FP6-correction form")
 args = ap.parse_args()
 H, W, V, cascade = bench.WORKLOADS[args.workload]
 dev = torch.device("cuda")
-model = RAFT(cascade=cascade, test_mode=True, gru_precision=args.gru_precision)
+model = RAFT(cascade=cascade, test_mode=True, gru_precision=args.gru_precision, enc_precision=args.enc_precision)
 model.load_state_dict(fill_state_dict(model.state_dict(), seed=5))
 model = model.to(dev).eval()
 images, poses, intr, scale = synthetic_scene(H, W, V, seed=0)

@@ -25,6 +25,8 @@ run() {   # name, kernel regex, command...
   run cost_lines_bands_kernel "cost_lines_bands_kernel" python tools/prof_build.py
   run lookup_encode "lookup_encode" python tools/prof_conv.py lookup --reps 1
   run enc_pc_32to32 "enc_pc_kernel<32, 32, 1, 9, 0, false>" python tools/bench_pc.py 32
+  run enc_pc_32to32_f6 "enc_pc_kernel<32, 32, 1, 9, 0, false, true>" env CER_ENC_F6=1 python tools/bench_pc.py 32
+  run enc_pc_32to32_dual_f6 "enc_pc_kernel<32, 32, 1, 9, 0, true, true>" env CER_ENC_F6=1 python tools/bench_pc.py 32 dual
   # (2) three depth maps in flight, whole forwards
   for s in 1 3; do
     run inflight${s}_gates_zr_f8 "conv3x3_s16_kernel<1, 4, 4, 2, 1>" python tools/forward_loop.py --streams $s --forwards 6
