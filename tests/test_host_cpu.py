@@ -435,3 +435,79 @@ def test_fp8_correction_weight_packing():
             q = blk[2 + hc]                                                                             # [lane][16]: wl * 2^5 | wh * 2^-6
             assert torch.equal(q[:, :8], (l_ref.float() * 32).to(torch.float8_e4m3fn).view(torch.uint8))
             assert torch.equal(q[:, 8:], (h_ref.float() / 64).to(torch.float8_e4m3fn).view(torch.uint8))
+
+
+def test_arithmetic_forms_of_the_auto_walk():
+    """Round 6: the calibration walk's candidates carry the encoders' form as a "+e6" suffix (csrc/enc_pc.hip, FP6 correction terms); it is
+    honoured only while enc_precision is "auto", and pinned encoders drop the suffixed candidates from the walk (host logic, no GPU)."""
+    import pytest
+    from cer_mvs_amd import RAFT
+    m = RAFT(test_mode=True)
+    assert m.enc_precision == "auto" and m._auto_forms() == RAFT.AUTO_FORMS and RAFT.AUTO_FORMS[-1] == "s16"
+    assert RAFT.AUTO_FORMS[0] == "s16f8+e6" and m._enc_f6 and m.update_block.corr_fp8 is True      # the first candidate until a calibration says otherwise
+    m._set_form("s16f8")
+    assert not m._enc_f6 and m.update_block.corr_fp8 is True
+    m._set_form("s16")
+    assert not m._enc_f6 and m.update_block.corr_fp8 is False
+    p = RAFT(test_mode=True, enc_precision="f16x3")
+    assert p._auto_forms() == tuple(f for f in RAFT.AUTO_FORMS if "+" not in f) and not p._enc_f6
+    p._set_form("s16f8+e6")
+    assert not p._enc_f6                                               # pinned: the suffix is ignored
+    f = RAFT(test_mode=True, enc_precision="f6", gru_precision="s16")
+    assert f._enc_f6 and f.update_block.corr_fp8 is False
+    f._set_form("s16f8")
+    assert f._enc_f6
+    assert not RAFT(test_mode=True, gru_precision="s16f8")._enc_f6     # a pinned update-block form leaves the encoders fp32-class
+    with pytest.raises(ValueError):
+        RAFT(test_mode=True, enc_precision="fp8")
+
+
+def test_encoder_fp6_weight_packing():
+    """cer_enc_conv_pack_f6 (host, round 6): size and plane order of cer_enc_conv_pack - [chunk32][tap][ntile32][k16-step][hi | q][lane][16 B] - with the hi
+    planes IDENTICAL to cer_enc_conv_pack's and the two q planes of a tap holding the lane's K block of the FP6 matrix instruction: 32 e2m3 fields, field i at
+    bit 6 i = [wl' (8) | wh (8)] of k16-step 0, then of step 1, divided by one power of two per block; dwords 0-3 in step 0's plane, dwords 4-5 | E8M0 byte of the
+    scale * 2^-11 | 0 in step 1's.  Decoded here with an independent e2m3 table: every field must be the nearest representable value (ties to even)."""
+    import numpy as np
+    from importlib import import_module
+    lib = import_module("cer-mvs_amd._lib").load()
+    Cout, Cin, taps = 64, 64, 9
+    g = torch.Generator().manual_seed(17)
+    w = ((torch.rand(Cout, Cin, 3, 3, generator=g) - 0.5) * torch.logspace(-3, 0, Cin).view(1, Cin, 1, 1)).contiguous()
+    w[5, 32:48] = 0.0                                                             # an all-zero block
+    size = lib.cer_enc_conv_packed_size(Cout, Cin, taps)
+    p3, p6 = torch.zeros(size, dtype=torch.float16), torch.zeros(size, dtype=torch.float16)
+    assert lib.cer_enc_conv_pack(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(p3.data_ptr()), Cout, Cin, taps) == 0
+    assert lib.cer_enc_conv_pack_f6(ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(p6.data_ptr()), Cout, Cin, taps) == 0
+    r3 = p3.view(torch.uint8).reshape(Cin // 32, taps, Cout // 32, 2, 2, 64, 16)  # [chunk][tap][ntile][ks][hi | lo][lane][16 B]
+    r6 = p6.view(torch.uint8).reshape(Cin // 32, taps, Cout // 32, 2, 2, 64, 16)
+    assert torch.equal(r3[:, :, :, :, 0], r6[:, :, :, :, 0])                      # the main term's operands are the same bytes
+    mags = np.array([0, .125, .25, .375, .5, .625, .75, .875, 1, 1.125, 1.25, 1.375, 1.5, 1.625, 1.75, 1.875,
+                     2, 2.25, 2.5, 2.75, 3, 3.25, 3.5, 3.75, 4, 4.5, 5, 5.5, 6, 6.5, 7, 7.5])
+    hi = w.half()
+    lo = ((w - hi.float()) * 2048.0).half()
+    for kc, tap, nt in ((0, 0, 0), (1, 4, 1), (1, 8, 0), (0, 7, 1), (1, 3, 0)):
+        q = np.concatenate([r6[kc, tap, nt, 0, 1].numpy(), r6[kc, tap, nt, 1, 1].numpy()], axis=1).copy().view(np.uint32)      # [lane][8 dwords]
+        for lane in range(64):
+            co, kg = nt * 32 + (lane & 31), lane >> 5
+            bits = int.from_bytes(q[lane, :6].tobytes(), "little")
+            fields = [(bits >> (6 * i)) & 63 for i in range(32)]
+            dec = np.array([(-1.0 if f & 32 else 1.0) * mags[f & 31] for f in fields])
+            sb = int(q[lane, 6])
+            assert q[lane, 7] == 0 and 0 < sb < 255
+            t = 2.0 ** (sb - 127 + 11)                                            # the block's scale (the byte carries t * 2^-11)
+            ref = []
+            for ks in range(2):
+                ci = kc * 32 + ks * 16 + kg * 8 + np.arange(8)
+                ref += [lo[co, ci, tap // 3, tap % 3].double().numpy(), hi[co, ci, tap // 3, tap % 3].double().numpy()]
+            ref = np.concatenate(ref)
+            mx = np.abs(ref).max()
+            if mx == 0:
+                assert not np.any(dec)
+                continue
+            assert 3.875 <= mx / t <= 7.75                                        # the block maximum lands in the top binade (or just under it)
+            # nearest representable magnitude, ties to the even code
+            x = np.abs(ref) / t
+            d = np.abs(x[:, None] - mags[None, :])
+            best = d.min(axis=1)
+            assert np.all(np.abs(np.abs(dec) - x) <= best + 1e-12)
+            assert np.all((np.sign(dec) == np.sign(ref)) | (dec == 0))
