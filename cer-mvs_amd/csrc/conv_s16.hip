@@ -111,6 +111,16 @@ __global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : (MT >= 8 ? 1
     for (int s = 0; s < ntens; ++s) nsteps += (a.ch[s] >> 4) * 9;
     const int nsteps_t = nsteps;           // steps of the tensor sources (F8: two of them form one 32-channel chunk step of 4 KiB)
     if (dsrc) nsteps += coll ? 6 : 36;
+#if SX_STAGGER
+    // experiment (round 6): the two workgroups of a CU start together and run their phases in lock-step - prologue, chunk loop, epilogue of both at the
+    // same time, the matrix pipe idle through two of the three.  The SECOND workgroup of a CU (HW_ID: SX_STAGGER_BIT) of the launch's first round of
+    // blocks sleeps ~ SX_STAGGER / 8 of a chunk loop before it starts, so that one block's memory phases fall under the other's matrix phase.
+    if ((int)blockIdx.x < 2 * SX_STAGGER_CUS) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+        if ((hw >> SX_STAGGER_BIT) & 1)
+            for (int i = 0; i < nsteps * SX_STAGGER; ++i) __builtin_amdgcn_s_sleep(1);      // 64 cycles each
+    }
+#endif
     const char* wlane = reinterpret_cast<const char*>(coll ? a.wpk_c : a.wpk) + ((long)(nb0 >> 5) + wn) * 2048 + lane * 16;
     const long wstep = (long)NT * 2048;    // bytes per step
     // F8: [chunk step][n-tile][f16 hi of half-chunk 0 | of half-chunk 1 | fp8 bytes 0-15 | fp8 bytes 16-31][lane][16 B]

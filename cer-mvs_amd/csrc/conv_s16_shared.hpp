@@ -44,6 +44,15 @@ typedef int intx8 __attribute__((ext_vector_type(8)));
                      // 77.0; inside the forward 95.5-96.1 against 96.2-96.4 us and the same depth maps per second - and 16 spilled registers
                      // (outside the chunk loop) where the default has none.  Off.
 #endif
+#ifndef SX_STAGGER
+#define SX_STAGGER 0       // experiment (conv_s16.hip): delay of a CU's second workgroup, in 64-cycle units per 16-channel step of the launch
+#endif
+#ifndef SX_STAGGER_BIT
+#define SX_STAGGER_BIT 0   // HW_ID bit that tells the two workgroups of a CU apart: 0 = wave slot parity, 16 = thread-group id parity
+#endif
+#ifndef SX_STAGGER_CUS
+#define SX_STAGGER_CUS 256
+#endif
 #ifndef SX_TRACE
 #define SX_TRACE 0   // variant builds only (tools/trace_s16.py): per wave cycle stamps + HW_ID written to `aux2` (GATES: unused there)
 #endif

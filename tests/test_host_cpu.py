@@ -117,6 +117,10 @@ def test_argument_errors_of_the_conv_and_encoder_entry_points():
     assert lib.cer_conv3x3_f16x3_packed_size(48, 192) == -2
     assert lib.cer_delta_proj_packed_size(256) == 2 * 8 * 2 * 512 and lib.cer_delta_proj_packed_size(200) == -2
     assert lib.cer_enc_conv_packed_size(64, 32, 9) == 9 * 2 * 2048 and lib.cer_enc_conv_packed_size(64, 32, 4) == -2
+    buf16 = (ctypes.c_char * 16)()
+    for pack in (lib.cer_enc_conv_pack, lib.cer_enc_conv_pack_f6):                # (round 6: the FP6-correction form's packer takes the same arguments)
+        assert pack(None, buf16, 32, 32, 9) == -1 and pack(buf16, None, 32, 32, 9) == -1
+        assert pack(buf16, buf16, 48, 32, 9) == -2 and pack(buf16, buf16, 32, 32, 4) == -2
     assert lib.cer_enc_conv_f16x3(fake, null, 0, fake, null, fake, null, null, 1, 8, 8, 48, 64, 9, 1, 0, 0, 1.0, null) == -2
     assert lib.cer_enc_conv_f16x3(fake, null, 0, fake, null, fake, null, null, 1, 8, 8, 32, 32, 9, 2, 0, 0, 1.0, null) == -2   # stride 2 needs Cout % 64
     assert lib.cer_enc_conv_f16x3(null, null, 0, fake, null, fake, null, null, 1, 8, 8, 32, 32, 9, 1, 0, 0, 1.0, null) == -1
