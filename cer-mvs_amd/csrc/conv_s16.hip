@@ -112,10 +112,13 @@ __global__ __launch_bounds__(256, (WM_ == 2 && F8 && SX_OCC3) ? 3 : (MT >= 8 ? 1
     const int nsteps_t = nsteps;           // steps of the tensor sources (F8: two of them form one 32-channel chunk step of 4 KiB)
     if (dsrc) nsteps += coll ? 6 : 36;
 #if SX_STAGGER
-    // experiment (round 6): the two workgroups of a CU start together and run their phases in lock-step - prologue, chunk loop, epilogue of both at the
-    // same time, the matrix pipe idle through two of the three.  The SECOND workgroup of a CU (HW_ID: SX_STAGGER_BIT) of the launch's first round of
-    // blocks sleeps ~ SX_STAGGER / 8 of a chunk loop before it starts, so that one block's memory phases fall under the other's matrix phase.
-    if ((int)blockIdx.x < 2 * SX_STAGGER_CUS) {
+    // Stagger (round 6).  The two workgroups a CU holds start together and run their phases in lock-step - prologue, chunk loop, epilogue of both at the
+    // same time, the matrix pipe idle through two of the three (34 % busy over a z|r launch by PMC).  With several depth maps in flight the blocks of a
+    // launch start whenever another kernel's block retires and the phases are mixed anyway; ONE depth map at a time they are not.  So in launches of more
+    // than three blocks per CU pair the SECOND workgroup of a CU (HW_ID.TG_ID parity) of the first round of blocks sleeps for about a quarter of a chunk
+    // loop before it starts: one block's memory phases then fall under the other's matrix phase.  Timing only - results cannot change.  Same-box A/B
+    // (profiles/r06_stagger_ab.txt): + 1.7 % depth maps per second one at a time (four pairs, every pair), +- 0 with three in flight; longer sleeps lose.
+    if ((!SX_STAGGER_WM1 || WM_ == 1) && (int)gridDim.x > 3 * SX_STAGGER_CUS && (int)blockIdx.x < 2 * SX_STAGGER_CUS) {
         const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
         if ((hw >> SX_STAGGER_BIT) & 1)
             for (int i = 0; i < nsteps * SX_STAGGER; ++i) __builtin_amdgcn_s_sleep(1);      // 64 cycles each

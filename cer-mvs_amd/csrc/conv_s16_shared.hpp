@@ -45,10 +45,13 @@ typedef int intx8 __attribute__((ext_vector_type(8)));
                      // (outside the chunk loop) where the default has none.  Off.
 #endif
 #ifndef SX_STAGGER
-#define SX_STAGGER 0       // experiment (conv_s16.hip): delay of a CU's second workgroup, in 64-cycle units per 16-channel step of the launch
+#define SX_STAGGER 4       // conv_s16.hip: delay of a CU's second workgroup in the first round of blocks, in 64-cycle units per 16-channel step of the launch (0: off)
 #endif
 #ifndef SX_STAGGER_BIT
-#define SX_STAGGER_BIT 0   // HW_ID bit that tells the two workgroups of a CU apart: 0 = wave slot parity, 16 = thread-group id parity
+#define SX_STAGGER_BIT 16  // HW_ID bit that tells the two workgroups of a CU apart: 16 = thread-group id parity (0 = wave slot parity: measured equal)
+#endif
+#ifndef SX_STAGGER_WM1
+#define SX_STAGGER_WM1 0   // 1: only the 128-output-channel launches (1 x 4 wave layout: z|r gates, delta head)
 #endif
 #ifndef SX_STAGGER_CUS
 #define SX_STAGGER_CUS 256
