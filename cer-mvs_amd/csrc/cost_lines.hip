@@ -39,6 +39,9 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+#ifndef CL_NO_F2LO
+#define CL_NO_F2LO 0                        // experiment: the band texels' lo planes are not read (source features as f16: two MFMA terms)
+#endif
 #define CL_T 128                            // texels per chunk (one 32-texel MFMA row tile per wave)
 #define CL_DP 33                            // pitch (float2) of the [hypothesis][pixel] sample / output tile
 #define CL_LOG2S 6                          // operand scale of the split: features (already / 8) saturate at 65504 / 64
@@ -466,7 +469,7 @@ __device__ __forceinline__ void cl_tile(const ClArgs& A, const int v, const int 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             ahf[ks] = *reinterpret_cast<const half8*>(tp + ks * ps2);
-            alf[ks] = *reinterpret_cast<const half8*>(tp + (4 + ks) * ps2);
+            if (!CL_NO_F2LO) alf[ks] = *reinterpret_cast<const half8*>(tp + (4 + ks) * ps2);
         }
     };
     if (nchunks > 0) loadA(0);                              // arrives under the projections below
@@ -524,7 +527,7 @@ __device__ __forceinline__ void cl_tile(const ClArgs& A, const int v, const int 
         for (int ks = 0; ks < 4; ++ks) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahf[ks], bh[ks], acc0, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahf[ks], bl[ks], acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alf[ks], bh[ks], acc0, 0, 0, 0);
+            if (!CL_NO_F2LO) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alf[ks], bh[ks], acc0, 0, 0, 0);
         }
         if (n + 1 < nchunks) loadA(n + 1);                  // in flight during the gather below
         // acc0[r]: texel row (r & 3) + 8 (r >> 2) + 4 kg of this wave's tile, pixel column li
