@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--encoder", default="hip", choices=["hip", "miopen"], help="encoder backend: channels-last HIP engine or PyTorch-ROCm (MIOpen)")
     ap.add_argument("--enc-precision", default="auto", choices=["auto", "f16x3", "f6"],
                     help="arithmetic of the encoders' convolutions: three f16 MFMA terms, or the correction terms in FP6 (RAFT enc_precision)")
+    ap.add_argument("--cost-precision", default="auto", choices=["auto", "x3", "x2"],
+                    help="dots of the cost volume: three split-f16 terms, or without the source texels' lo planes (RAFT cost_precision)")
     ap.add_argument("--gru-precision", default="auto", choices=["auto", "s16f6", "s16f8", "s16", "f16x3", "fp32"],
                     help="arithmetic of the update block's 3x3 convs: split-f16 MFMA (s16f8: correction terms on the fp8 matrix instruction, "
                          "4e-6 from fp32; s16: all-f16, fp32-class, one accumulator; f16x3: round-1 kernels), or exact fp32 MFMA.  auto (the "
@@ -257,7 +259,7 @@ def main():
         shard = world > 1 and mode in ("shard", "views")
         model = RAFT(cascade=cascade, test_mode=True, precision=args.precision, view_group=group if shard else None,
                      gru_precision=args.gru_precision, encoder_backend=args.encoder, shard="slab" if mode == "shard" else "views",
-                     enc_precision=args.enc_precision)
+                     enc_precision=args.enc_precision, cost_precision=args.cost_precision)
         sd = fill_state_dict(model.state_dict(), seed=5)
         model.load_state_dict(sd)
         model = model.to(dev).eval()
@@ -346,6 +348,7 @@ def main():
         assert model.auto_choice is not None and model.auto_choice.partition("+")[0] in ("s16f6", "s16f8", "s16"), "the warm-up did not calibrate gru_precision='auto'"
         args.gru_precision = model.auto_choice.partition("+")[0]
     enc_f6 = bool(model._enc_f6)          # what the timed forwards ran the encoders in
+    cost_x2 = bool(model._cost_x2)        # ... and the cost volume's dots
     if modes is not None:
         modes[args.mode].update(value=args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps, headline=True)
     maps = args.steps * (world if (world > 1 and not shard) else 1)
@@ -355,7 +358,7 @@ def main():
     if world > 1:
         if rank == 0:
             m1 = RAFT(cascade=cascade, test_mode=True, precision=args.precision, gru_precision=args.gru_precision, encoder_backend=args.encoder,
-                      enc_precision="f6" if enc_f6 else "f16x3")
+                      enc_precision="f6" if enc_f6 else "f16x3", cost_precision="x2" if cost_x2 else "x3")
             m1.load_state_dict(sd)
             m1 = m1.to(dev).eval()
             with torch.no_grad():
@@ -539,12 +542,15 @@ def main():
                                  "4e-5 from the three-term form), " if enc_f6 else "encoders 3 f16 MFMAs per product (fp32-class), ")),
             "data": "synthetic",
             "enc_precision": {"requested": args.enc_precision, "timed": "f6" if enc_f6 else "f16x3"},
+            "cost_precision": {"requested": args.cost_precision, "timed": "x2" if cost_x2 else "x3",
+                               "note": "x2: the cost volume's 64-channel dots take the source features as f16 (their lo planes are not read; the reference rows keep "
+                                       "both halves): 1.2e-5 relative L1 on the volume"},
             "gru_precision": {"requested": requested_precision, "timed": args.gru_precision, "auto_form": model.auto_choice,
                               **({"calibration_rel_l1_vs_s16": model.auto_error, "candidates": list(model._auto_forms()), "tolerance": model.AUTO_TOL,
                                   "calibration_inputs": model.AUTO_INPUTS,
                                   "note": "gru_precision='auto': the first forwards of a set of weights (calibration_inputs of them, inside the "
-                                          "warm-up) run in the fp32-class form 's16' and in the cheapest candidate still standing ('+e6': the encoders' correction "
-                                          "terms in FP6 as well as the update block's in fp8; then fp8 corrections in the update block only); a candidate is kept only if it agrees with 's16' within the tolerance on every one of "
+                                          "warm-up) run in the fp32-class form 's16' and in the cheapest candidate still standing ('+c2': two-term cost-volume dots; '+e6': "
+                                          "the encoders' correction terms in FP6; both on top of the update block's fp8 corrections, then those alone); a candidate is kept only if it agrees with 's16' within the tolerance on every one of "
                                           "them (the figure is the kept form's worst)"}
                                  if requested_precision == "auto" else {})},
             "config": {"workload": args.workload, "image": f"{W}x{H}", "src_views": V, "cascade": cascade,

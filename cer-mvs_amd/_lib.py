@@ -53,9 +53,9 @@ _SIGNATURES = {
     "cer_f16_scan_overflow": (_I, [_P, _L, _P, _I, _P]),
     "cer_feat_split_f16": (_I, [_P, _P, _L, _L, _I, _P, _P]),
     "cer_cost_lines_workspace": (_L, [_I, _I, _I, _I]),
-    "cer_cost_lines_views_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _D, _I, _I, _P]),
+    "cer_cost_lines_views_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _D, _I, _I, _I, _P]),
     "cer_cost_lines_reduce_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _D, _I, _I, _I, _F, _P]),
-    "cer_cost_lines_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _D, _I, _I, _I, _I, _F, _P]),
+    "cer_cost_lines_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _D, _I, _I, _I, _I, _F, _I, _P]),
     "cer_pyramid_f32": (_I, [_P, _L, _I, _I, _I, _F, _P]),
     "cer_corr_lookup_f32": (_I, [_P, _P, _P, _L, _P, _I, _L, _I, _I, _D, _I, _I, _I, _P]),
     "cer_corr_encode_f32": (_I, [_P, _P, _P, _P, _I, _I, _L, _I, _P]),

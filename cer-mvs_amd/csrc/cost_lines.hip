@@ -39,9 +39,6 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-#ifndef CL_NO_F2LO
-#define CL_NO_F2LO 0                        // experiment: the band texels' lo planes are not read (source features as f16: two MFMA terms)
-#endif
 #define CL_T 128                            // texels per chunk (one 32-texel MFMA row tile per wave)
 #define CL_DP 33                            // pitch (float2) of the [hypothesis][pixel] sample / output tile
 #define CL_LOG2S 6                          // operand scale of the split: features (already / 8) saturate at 65504 / 64
@@ -401,6 +398,10 @@ __global__ __launch_bounds__(256) void cost_lines_bands_kernel(const ClArgs A, u
 
 // One (view, segment, line) tile by a 256-thread block; every early return is block-uniform.  `rem`: the tile's order inside its view
 // (its band record is A.bands[v * tpv + rem]).
+// F2LO (round 6): true = three-term dots  f1h*f2h + f1l*f2h + f1h*f2l  (fp32-class: rounds 3-5); false = "two-term": the band texels' lo planes
+// are NOT READ - the source features enter as f16 (the reference rows keep both halves) - which halves the bytes of the fragment stream that IS this
+// kernel's run time: stage 0 1 580 -> 1 020 us, 1.2e-5 relative L1 on the volume, 5e-6 on the final disparity (costed on the oracle first).
+template <bool F2LO>
 __device__ __forceinline__ void cl_tile(const ClArgs& A, const int v, const int rem, const int seg, const int jj) {
     __shared__ __attribute__((aligned(16))) float prod[CL_T * 32];      // dots[texel of the chunk][pixel of the tile]
     // per (hypothesis, pixel): {packed cell, fraction along the band, fraction across it, value}
@@ -469,7 +470,7 @@ __device__ __forceinline__ void cl_tile(const ClArgs& A, const int v, const int 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             ahf[ks] = *reinterpret_cast<const half8*>(tp + ks * ps2);
-            if (!CL_NO_F2LO) alf[ks] = *reinterpret_cast<const half8*>(tp + (4 + ks) * ps2);
+            if (F2LO) alf[ks] = *reinterpret_cast<const half8*>(tp + (4 + ks) * ps2);
         }
     };
     if (nchunks > 0) loadA(0);                              // arrives under the projections below
@@ -527,7 +528,7 @@ __device__ __forceinline__ void cl_tile(const ClArgs& A, const int v, const int 
         for (int ks = 0; ks < 4; ++ks) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahf[ks], bh[ks], acc0, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahf[ks], bl[ks], acc0, 0, 0, 0);
-            if (!CL_NO_F2LO) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alf[ks], bh[ks], acc0, 0, 0, 0);
+            if (F2LO) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alf[ks], bh[ks], acc0, 0, 0, 0);
         }
         if (n + 1 < nchunks) loadA(n + 1);                  // in flight during the gather below
         // acc0[r]: texel row (r & 3) + 8 (r >> 2) + 4 kg of this wave's tile, pixel column li
@@ -628,11 +629,11 @@ __device__ __forceinline__ unsigned cl_xcd_order() {
 
 // OCC = waves per SIMD the register allocation aims at: 3 (LDS: 16 KiB of dots + D x 33 descriptors <= 50 KiB per block; 134 VGPRs).
 // D <= 44 would fit 4 blocks per CU, but at 128 VGPRs the kernel spills and was measured slower (1.14 vs 1.04 ms)
-template <int OCC>
+template <int OCC, bool F2LO = true>
 __global__ __launch_bounds__(256, OCC) void cost_lines_kernel(const ClArgs A) {
     int v, rem, seg, jj;
     cl_decode(A, cl_xcd_order(), v, rem, seg, jj);
-    cl_tile(A, v, rem, seg, jj);
+    cl_tile<F2LO>(A, v, rem, seg, jj);
 }
 
 #ifndef CER_WITH_LINES8
@@ -718,8 +719,9 @@ static float* cl_params(void* workspace, int V, long P, int D) {
 // views v0 .. v0 + nv - 1 of a V-view workspace: tile parameters + per-view partial volumes (no reduction)
 extern "C" int cer_cost_lines_views_f32(const void* fmap1_split, const void* fmap2_split, const int* view_slot, const float* Pij,
                                         const float* disp_in, void* workspace, int V, int v0, int nv, int h1, int w1, int h2, int w2, int C, int D,
-                                        double incre_d, int shift, int y0, void* stream) {
+                                        double incre_d, int shift, int y0, int two_term, void* stream) {
     if (!fmap1_split || !fmap2_split || !Pij || !disp_in || !workspace) return CER_EINVAL;
+    if (two_term != 0 && two_term != 1) return CER_EINVAL;
     const int rc = cl_check(V, h1, w1, h2, w2, C, D);
     if (rc != CER_OK) return rc;
     if (v0 < 0 || nv <= 0 || v0 + nv > V) return CER_EINVAL;
@@ -792,7 +794,8 @@ extern "C" int cer_cost_lines_views_f32(const void* fmap1_split, const void* fma
         return CER_OK;
     }
 #endif
-    hipLaunchKernelGGL(cost_lines_kernel<3>, dim3((unsigned)nblk), dim3(256), dyn, st, a);      // (<4> at D <= 44: 128 VGPRs with 16 spilled dwords - 895 against 795 us, re-measured in round 5)
+    if (two_term) hipLaunchKernelGGL((cost_lines_kernel<3, false>), dim3((unsigned)nblk), dim3(256), dyn, st, a);
+    else hipLaunchKernelGGL(cost_lines_kernel<3>, dim3((unsigned)nblk), dim3(256), dyn, st, a);      // (<4> at D <= 44: 128 VGPRs with 16 spilled dwords - 895 against 795 us, re-measured in round 5)
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }
@@ -818,10 +821,10 @@ extern "C" int cer_cost_lines_reduce_f32(const void* workspace, const float* dis
 
 extern "C" int cer_cost_lines_f32(const void* fmap1_split, const void* fmap2_split, const int* view_slot, const float* Pij, const float* disp_in,
                                   float* vol, float* origin_out, void* workspace, int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride,
-                                  double incre_d, int shift, int mode, int y0, int fuse_levels, float fuse_scale, void* stream) {
+                                  double incre_d, int shift, int mode, int y0, int fuse_levels, float fuse_scale, int two_term, void* stream) {
     if (!vol || row_stride < D || (mode != 1 && mode != 2)) return CER_EINVAL;
     int rc = cer_cost_lines_views_f32(fmap1_split, fmap2_split, view_slot, Pij, disp_in, workspace, V, 0, V, h1, w1, h2, w2, C, D, incre_d, shift, y0,
-                                      stream);
+                                      two_term, stream);
     if (rc != CER_OK) return rc;
     return cer_cost_lines_reduce_f32(workspace, disp_in, vol, origin_out, V, h1, w1, D, row_stride, incre_d, shift, mode, fuse_levels, fuse_scale,
                                      stream);

@@ -201,7 +201,7 @@ def _lines_workspace(V, h1, w1, D, device):
 
 
 def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, fold, vol=None, accumulate=False, src_hw=None, y0=0,
-               pyramid_scale=None, split=None, compact=False):
+               pyramid_scale=None, split=None, compact=False, two_term=False):
     """fmap1 [P,C], fmap2 [V,(h2+4)*(w2+4),C] (NHWC, pre-scaled, 2-texel zero border), Pij [V,4,4], disp_in [P].
     (h1, w1): reference grid of this call, first image row ``y0`` (row slabs); ``src_hw``: source-map size (default h1, w1).
     Returns (vol [V,P,rs] or [P,rs], origin [P]).  Level 0 only; call ``pyramid`` next - unless ``pyramid_scale`` is given
@@ -211,7 +211,8 @@ def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, 
     every stage of a forward), else they are made here; a third element ``slots`` (int32 [V], device) says that view v's split
     rows are block slots[v] of the second element (any leading shape; the sharded forward's gathered buffer) - ``fmap2`` may then
     be None and ``V`` = len(slots).  ``compact``: level-0-only rows (``row_layout``); with ``pyramid_scale`` the epilogue then only
-    scales (both builders: ``fuse_levels = 1``)."""
+    scales (both builders: ``fuse_levels = 1``).  ``two_term`` (round 6; epipolar-line-tile kernel only, ignored by the walk): the source
+    texels' lo planes are not read - half the tile kernel's fragment bytes, 1.2e-5 relative L1 on the volume (cer_mvs.h)."""
     if fmap2 is None:
         if split is None or len(split) < 3 or src_hw is None:
             raise ValueError("cost_build: without fmap2 the split rows, their view slots and src_hw are required")
@@ -256,7 +257,7 @@ def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, 
                                        L.dev_ptr(slots, "view_slot", torch.int32), L.dev_ptr(Pij, "Pij"), L.dev_ptr(disp_in, "disp_in"), L.dev_ptr(vol, "vol"),
                                        L.dev_ptr(origin, "origin"), L.dev_ptr(ws, "workspace", torch.uint8), V, h1, w1, h2, w2, C, D, rs,
                                        float(incre), int(bool(shift)), mode, int(y0), fuse_levels,
-                                       float(pyramid_scale) if fuse else 1.0, L.cur_stream()), "cost_lines")
+                                       float(pyramid_scale) if fuse else 1.0, int(bool(two_term)), L.cur_stream()), "cost_lines")
     else:
         if fmap2 is None:
             raise RuntimeError("cost_build: this shape needs the fp32 walk, which takes fmap2 itself")
@@ -269,7 +270,7 @@ def cost_build(fmap1, fmap2, Pij, disp_in, D, incre, shift, h1, w1, num_levels, 
     return vol, origin
 
 
-def cost_lines_views(f1s, f2s, slots, Pij, disp_in, V, v0, nv, h1, w1, D, incre, shift, src_hw=None, y0=0, ws=None):
+def cost_lines_views(f1s, f2s, slots, Pij, disp_in, V, v0, nv, h1, w1, D, incre, shift, src_hw=None, y0=0, ws=None, two_term=False):
     """First half of the epipolar-line-tile cost volume for views v0 .. v0 + nv - 1 of V: their partial volumes go to the device's
     lines workspace (cer_cost_lines_views_f32).  ``cost_lines_reduce`` finishes the volume once every view has been built."""
     h2, w2 = src_hw if src_hw is not None else (h1, w1)
@@ -278,7 +279,7 @@ def cost_lines_views(f1s, f2s, slots, Pij, disp_in, V, v0, nv, h1, w1, D, incre,
     L.check(L.load().cer_cost_lines_views_f32(L.dev_ptr(f1s, "fmap1_split", torch.float16), L.dev_ptr(f2s, "fmap2_split", torch.float16),
                                               L.dev_ptr(slots, "view_slot", torch.int32), L.dev_ptr(Pij, "Pij"), L.dev_ptr(disp_in, "disp_in"),
                                               L.dev_ptr(ws, "workspace", torch.uint8), V, int(v0), int(nv), h1, w1, h2, w2, 64, D, float(incre),
-                                              int(bool(shift)), int(y0), L.cur_stream()), "cost_lines_views")
+                                              int(bool(shift)), int(y0), int(bool(two_term)), L.cur_stream()), "cost_lines_views")
 
 
 def cost_lines_reduce(disp_in, V, h1, w1, D, incre, shift, num_levels, pyramid_scale=None, vol=None, accumulate=False, ws=None, compact=False):

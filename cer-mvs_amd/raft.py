@@ -46,7 +46,7 @@ class SaturationError(RuntimeError):
 class RAFT(nn.Module):
     def __init__(self, cascade=[(64, 64, 8), (-1, 320, 8)], encoder_type="HR", dim_fmap=64, dim_net=64, dim_inp=64,
                  test_mode=False, precision="fp32", view_group=None, gru_precision="auto", encoder_backend="hip", shard="slab",
-                 enc_precision="auto"):
+                 enc_precision="auto", cost_precision="auto"):
         super().__init__()
         self.cascade = [tuple(c) for c in cascade]
         self.encoder_type = encoder_type
@@ -69,6 +69,13 @@ class RAFT(nn.Module):
             raise ValueError(f"RAFT: unknown enc_precision {enc_precision!r}")
         self.enc_precision = enc_precision
         self._enc_f6 = enc_precision == "f6"
+        # cost_precision (round 6): the dots of the epipolar-line-tile cost volume (csrc/cost_lines.hip).  "x3": three split-f16 terms (fp32-class);
+        # "x2": the source texels' lo planes are not read (source features as f16) - half the fragment bytes that bound the tile kernel,
+        # 1.2e-5 on the volume, ~5e-6 on the disparity; "auto" (default): a "+c2" suffix of the calibration walk's forms, "x3" with a pinned gru_precision.
+        if cost_precision not in ("auto", "x3", "x2"):
+            raise ValueError(f"RAFT: unknown cost_precision {cost_precision!r}")
+        self.cost_precision = cost_precision
+        self._cost_x2 = cost_precision == "x2"
         self.update_block.conv_mode = "s16" if gru_precision in ("s16f6", "s16f8", "auto") else gru_precision
         self._set_form(gru_precision if gru_precision != "auto" else self._auto_forms()[0])
         # "auto" (default): the fp8-correction form keeps ~15 product bits in the correction terms; how much of that reaches the depth
@@ -112,10 +119,11 @@ class RAFT(nn.Module):
         self._engines = None
 
     def _set_form(self, form):
-        """arithmetic form of a forward: a gru_precision name, optionally "+e6" (encoders in the FP6-correction form; honoured with enc_precision="auto")"""
-        g, _, e = form.partition("+")
+        """arithmetic form of a forward: a gru_precision name, optionally "+e6" (encoders in the FP6-correction form; honoured with enc_precision="auto") and / or "+c2" (two-term cost-volume dots; cost_precision="auto")"""
+        g, *sfx = form.split("+")
         self.update_block.corr_fp8 = self._CORR_FORM.get(g, False)
-        self._enc_f6 = self.enc_precision == "f6" or (self.enc_precision == "auto" and e == "e6")
+        self._enc_f6 = self.enc_precision == "f6" or (self.enc_precision == "auto" and "e6" in sfx)
+        self._cost_x2 = self.cost_precision == "x2" or (self.cost_precision == "auto" and "c2" in sfx)
 
     def _get_engines(self, dev):
         from .encoder_hip import HipEncoder
@@ -282,7 +290,7 @@ class RAFT(nn.Module):
                 if bi == 0:
                     ops.feat_split(f1, out=f1s)
                 ops.feat_split(buf[v0:v0 + nvb], out=f2s[v0:v0 + nvb])
-                ops.cost_lines_views(f1s, f2s, None, Pij, disp, V, v0, nvb, h, w, D, incre, True, ws=lws)
+                ops.cost_lines_views(f1s, f2s, None, Pij, disp, V, v0, nvb, h, w, D, incre, True, ws=lws, two_term=self._cost_x2)
             v0 += nvb
         done = torch.cuda.Event()
         done.record(side)                      # (the caller waits for it right before the view reduction: the hoisted convs run meanwhile)
@@ -358,14 +366,17 @@ class RAFT(nn.Module):
     # Round 6, second half: a "+e6" suffix puts the ENCODERS' correction terms on the FP6 form as well (csrc/enc_pc.hip; enc_precision="auto" only -
     # with the encoders pinned the suffixed candidates drop out, `_auto_forms`).  There it does pay (+ 3.8 % depth maps per second, same-box A/B,
     # profiles/r06_encoder_fp6_ab.txt; 1.2e-5 from the reference capture on the bench workload), so it IS the first default candidate.
-    AUTO_FORMS = ("s16f8+e6", "s16f8", "s16")
+    # "+c2": the cost volume's dots without the source texels' lo planes (csrc/cost_lines.hip, cost_precision="auto" only): + 5.6 % depth maps per second
+    # on top (profiles/r06_cost_two_term_ab.txt), 1.23e-5 from the reference capture on the bench workload against 1.22e-5 without it.
+    AUTO_FORMS = ("s16f8+e6+c2", "s16f8+e6", "s16f8", "s16")
     AUTO_TOL = 2.5e-5                             # a quarter of the 1e-4 parity bar
     AUTO_MAX_TOL = 1e-3                           # ... and no single pixel further apart than this fraction of the largest disparity
     AUTO_INPUTS = 3                               # inputs the decision rests on (the worst one counts)
 
     def _auto_forms(self):
         """the calibration walk's candidates for this model: AUTO_FORMS, without the "+e6" forms when the encoders' arithmetic is pinned"""
-        return tuple(f for f in self.AUTO_FORMS if self.enc_precision == "auto" or "+" not in f)
+        ok = lambda f: ("e6" not in f.split("+") or self.enc_precision == "auto") and ("c2" not in f.split("+") or self.cost_precision == "auto")
+        return tuple(f for f in self.AUTO_FORMS if ok(f))
 
     def _auto_pending(self):
         return self.update_block.conv_mode == "s16" and (self._auto_sig != self._params_sig() or self._auto_left > 0)
@@ -378,7 +389,7 @@ class RAFT(nn.Module):
         if (self.gru_precision != "auto" or other.gru_precision != "auto" or other.auto_choice is None or other._auto_pending()
                 or self.update_block.conv_mode != other.update_block.conv_mode):
             return False
-        self.update_block.corr_fp8, self._enc_f6 = other.update_block.corr_fp8, other._enc_f6
+        self.update_block.corr_fp8, self._enc_f6, self._cost_x2 = other.update_block.corr_fp8, other._enc_f6, other._cost_x2
         self.auto_choice, self.auto_error = other.auto_choice, other.auto_error
         self._auto_sig, self._auto_left = self._params_sig(), 0
         return True
@@ -516,7 +527,7 @@ class RAFT(nn.Module):
             elif views:
                 vol, origin = ops.cost_build(f1, f2, Pij, disp, D, incre, stage == 0, h, w, ub.num_levels, fold=True,
                                              pyramid_scale=(1.0 / V) if (single and D <= 64) else None, split=split,
-                                             src_hw=(h, w) if f2 is None else None, compact=compact)
+                                             src_hw=(h, w) if f2 is None else None, compact=compact, two_term=self._cost_x2)
             else:                      # more ranks than views: contribute zeros
                 _, _, rs = ops.row_layout(D, ub.num_levels, compact)
                 vol = torch.zeros(P, rs, device=dev)

@@ -400,7 +400,7 @@ def sharded_forward(model, images, poses, intrinsics, scale, ex):
             d = st[g]
             vol, origin = ops.cost_build(d["f1s"], d["f2"], Pij, d["disp"], D, incre, stage == 0, d["hs"], w, ub.num_levels,
                                          fold=True, src_hw=(h, w), y0=d["e0"], pyramid_scale=(1.0 / V) if D <= 64 else None,
-                                         split=d["split"], compact=model.COMPACT_VOLUME)
+                                         split=d["split"], compact=model.COMPACT_VOLUME, two_term=model._cost_x2)
             if D > 64:
                 ops.pyramid(vol, D, 1 if model.COMPACT_VOLUME else ub.num_levels, scale=1.0 / V)
             d["vol"], d["origin"] = vol, origin

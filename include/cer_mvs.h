@@ -137,14 +137,18 @@ long cer_cost_lines_workspace(int V, int h1, int w1, int D);
 int cer_cost_lines_f32(const void* fmap1_split, const void* fmap2_split, const int* view_slot, const float* Pij, const float* disp_in,
                        float* vol, float* origin_out, void* workspace,
                        int V, int h1, int w1, int h2, int w2, int C, int D, int row_stride,
-                       double incre, int shift, int mode, int y0, int fuse_levels, float fuse_scale, void* stream);
-/* The two halves of cer_cost_lines_f32, for callers that build views as their features become available (RAFT.forward encodes the
+                       double incre, int shift, int mode, int y0, int fuse_levels, float fuse_scale, int two_term, void* stream);
+/* two_term (round 6, ABI 1070; 0 or 1, else CER_EINVAL): 0 = three-term split-f16 dots, fp32-class (4e-8 relative L1 from the walk); 1 = the lo planes
+ * of fmap2_split are NOT READ - the source features enter the dots as f16 (the reference rows keep both halves): half the bytes of the band-fragment
+ * stream that bounds the tile kernel (stage 0 at the bench workload 1.58 -> 1.02 ms), 1.2e-5 relative L1 on the volume, ~5e-6 on the final disparity.
+ * RAFT's "auto" calibration decides per set of weights ("+c2" forms); the planes keep their layout either way.
+ * The two halves of cer_cost_lines_f32, for callers that build views as their features become available (RAFT.forward encodes the
  * source views in batches and builds each batch's partial volumes on a second stream while the next batch is being encoded):
  * _views_ writes the partial volumes of views v0 .. v0 + nv - 1 into the V-view workspace (Pij, view_slot, fmap2_split indexed by
  * the absolute view number); _reduce_ sums all V partials in view order into vol (origin, scale, pooled levels as above). */
 int cer_cost_lines_views_f32(const void* fmap1_split, const void* fmap2_split, const int* view_slot, const float* Pij, const float* disp_in,
                              void* workspace, int V, int v0, int nv, int h1, int w1, int h2, int w2, int C, int D,
-                             double incre, int shift, int y0, void* stream);
+                             double incre, int shift, int y0, int two_term, void* stream);
 int cer_cost_lines_reduce_f32(const void* workspace, const float* disp_in, float* vol, float* origin_out, int V, int h1, int w1, int D,
                               int row_stride, double incre, int shift, int mode, int fuse_levels, float fuse_scale, void* stream);
 

@@ -215,8 +215,10 @@ def test_precision_margin_under_weight_gain(dev, gain, tail):
                 v = torch.where(m, v * 8.0, v)
             sd[k_] = v
     outs, choice = {}, None
-    for prec in ("fp32", "s16", "s16f8", "s16f8+e6", "f16x3", "auto"):          # ("+e6": the encoders' correction terms in FP6 as well, round 6)
-        model = RAFT(cascade=cascade, test_mode=True, gru_precision=prec.partition("+")[0], enc_precision="f6" if prec.endswith("+e6") else "auto")
+    for prec in ("fp32", "s16", "s16f8", "s16f8+e6", "s16f8+e6+c2", "f16x3", "auto"):     # (round 6: "+e6" the encoders' correction terms in FP6, "+c2" two-term cost-volume dots)
+        sfx = prec.split("+")[1:]
+        model = RAFT(cascade=cascade, test_mode=True, gru_precision=prec.split("+")[0], enc_precision="f6" if "e6" in sfx else "auto",
+                     cost_precision="x2" if "c2" in sfx else "auto")
         model.load_state_dict(sd)
         model = model.to(dev).eval()
         model.overflow_policy = "ignore"
@@ -231,7 +233,7 @@ def test_precision_margin_under_weight_gain(dev, gain, tail):
     e = {p: rel_l1(outs[p], outs["fp32"]) for p in ("s16", "s16f8", "f16x3", "auto")}
     print(f"gain x{gain} {tail}: rel-L1 vs exact fp32: s16 {e['s16']:.2e}  s16f8 {e['s16f8']:.2e}  f16x3 {e['f16x3']:.2e}  auto {e['auto']:.2e} "
           f"(kept {choice}, calibration {cal:.2e}; s16f8 / s16 = {e['s16f8'] / max(e['s16'], 1e-12):.0f})")
-    assert choice in ("s16f8+e6", "s16f8", "s16")
+    assert choice in RAFT.AUTO_FORMS
     assert torch.equal(outs["auto"], outs[choice])
     if max(e["s16"], e["f16x3"]) < 2e-5:
         assert e["auto"] < 5e-5
@@ -388,7 +390,7 @@ def test_auto_precision_is_decided_on_the_worst_of_the_first_inputs(dev):
             sd[k_] = torch.where(torch.rand(v.shape, generator=gen) < 0.02, v * 8.0, v)
 
     def make(prec):
-        m = RAFT(cascade=cascade, test_mode=True, gru_precision=prec, enc_precision="f16x3")       # (the update block's walk: encoders pinned)
+        m = RAFT(cascade=cascade, test_mode=True, gru_precision=prec, enc_precision="f16x3", cost_precision="x3")   # (the update block's walk: the rest pinned)
         m.load_state_dict(sd)
         m = m.to(dev).eval()
         m.overflow_policy = "ignore"

@@ -400,6 +400,33 @@ def test_cost_lines_matches_walk(dev, D, stage0, geom, form):
         lib.cer_cost_lines_form(prev_form)
 
 
+@pytest.mark.parametrize("geom", ["horizontal", "diagonal", "forward", "converging"])
+@pytest.mark.parametrize("D,stage0", [(64, True), (44, False)])
+def test_cost_lines_two_term_form(dev, D, stage0, geom):
+    """Round 6 (ABI 1070, ``two_term``): the tile kernel WITHOUT the source texels' lo planes - the source features enter the 64-channel dots as
+    f16, the reference rows keep both halves.  Against the three-term form on the same inputs: origins identical, the volume a source-f16
+    rounding away (each texel 2^-12 relative: ~1e-5 relative L1 on the volume - measured 1.2e-5 at the bench workload; a LOST term of the
+    reference rows would be the same size again, a wrong plane 1e-1), and exactly what the THREE-term kernel returns for source features rounded to
+    f16 beforehand - which pins the form to its definition instead of to a tolerance.  Deterministic; the fused epilogue and the
+    level-0-only rows as in the three-term form."""
+    from cer_mvs_amd import ops
+    for h1, w1 in ((19, 45), (70, 150)):
+        f1, f2, Pij, d0, V = _lines_case(dev, D, stage0, geom, h1, w1)
+        incre = 0.0025 / (64 if stage0 else 320)
+        a3, o3 = ops.cost_build(f1, f2, Pij, d0, D, incre, stage0, h1, w1, 3, fold=True, pyramid_scale=1.0 / V)
+        a2, o2 = ops.cost_build(f1, f2, Pij, d0, D, incre, stage0, h1, w1, 3, fold=True, pyramid_scale=1.0 / V, two_term=True)
+        again, _ = ops.cost_build(f1, f2, Pij, d0, D, incre, stage0, h1, w1, 3, fold=True, pyramid_scale=1.0 / V, two_term=True)
+        c2, _ = ops.cost_build(f1, f2, Pij, d0, D, incre, stage0, h1, w1, 3, fold=True, pyramid_scale=1.0 / V, compact=True, two_term=True)
+        assert torch.equal(o3, o2) and torch.equal(a2, again) and torch.equal(c2[:, :D], a2[:, :D])
+        e = rel_l1(a2.cpu(), a3.cpu())
+        # the kernel's operand is x * 2^6 split into f16 hi | lo: the two-term form sees hi only
+        f2r = ((f2 * 64.0).clamp(-65504.0, 65504.0).half().float() / 64.0)
+        r3, _ = ops.cost_build(f1, f2r, Pij, d0, D, incre, stage0, h1, w1, 3, fold=True, pyramid_scale=1.0 / V)
+        print(f"{geom} D={D} {h1}x{w1}: two-term vs three-term {e:.2e}; vs three-term on f16-rounded source rows {rel_l1(a2.cpu(), r3.cpu()):.2e}")
+        assert 1e-6 < e < 1e-4
+        assert torch.equal(a2, r3)
+
+
 def _cost_lines_matches_walk(dev, D, stage0, geom, lib):
     from cer_mvs_amd import ops
     for h1, w1 in ((19, 45), (70, 150)):
@@ -911,7 +938,7 @@ def test_large_configs_run(dev):
 
 
 # ------------------------------------------------------------------------------------ end to end
-def _run_e2e(dev, golden, name, literal=False, gru_precision="s16f8", enc_precision="auto", info=None):
+def _run_e2e(dev, golden, name, literal=False, gru_precision="s16f8", enc_precision="auto", cost_precision="auto", info=None):
     from cer_mvs_amd import RAFT
     from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene, tensor_checksum
     g = golden(name)
@@ -919,7 +946,7 @@ def _run_e2e(dev, golden, name, literal=False, gru_precision="s16f8", enc_precis
     cascade = [tuple(int(x) for x in c) for c in g["cascade"]]
     images, poses, intr, scale = cached_scene(H, W, V, int(g["scene_seed"]))
     assert tensor_checksum(images) == int(g["images_checksum"])
-    model = RAFT(cascade=cascade, test_mode=True, gru_precision=gru_precision, enc_precision=enc_precision)
+    model = RAFT(cascade=cascade, test_mode=True, gru_precision=gru_precision, enc_precision=enc_precision, cost_precision=cost_precision)
     model.load_state_dict(fill_state_dict(model.state_dict(), seed=int(g["weight_seed"])))
     model = model.to(dev).eval()
     if info is not None:
@@ -969,6 +996,14 @@ def test_end_to_end_cfg1_encoders_in_fp6_form(dev, golden, gru_precision):
     e_disp, e_depth = _run_e2e(dev, golden, "e2e_cfg1", gru_precision=gru_precision, enc_precision="f6")
     print(f"e2e_cfg1[{gru_precision} + encoders f6] rel-L1 disp {e_disp:.3e} depth {e_depth:.3e}")
     assert 1e-6 < max(e_disp, e_depth) < 2.5e-5
+
+
+def test_end_to_end_cfg1_two_term_cost_volume(dev, golden):
+    """cost_precision="x2" alone (update block and encoders fp32-class) against the reference's own output at configs[0]: the contribution of the
+    source features' f16 rounding in the cost volume (costed on the oracle at 5-6e-6 before it was built)."""
+    e_disp, e_depth = _run_e2e(dev, golden, "e2e_cfg1", gru_precision="s16", enc_precision="f16x3", cost_precision="x2")
+    print(f"e2e_cfg1[s16, two-term cost volume] rel-L1 disp {e_disp:.3e} depth {e_depth:.3e}")
+    assert 5e-7 < max(e_disp, e_depth) < 2e-5
 
 
 def test_end_to_end_cfg2_default_auto_form(dev, golden):

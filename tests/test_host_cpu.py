@@ -76,11 +76,12 @@ def test_argument_errors_without_device():
         prev = lib.cer_cost_lines_form(-1)
         assert prev in (0, 1) and lib.cer_cost_lines_form(1) == prev and lib.cer_cost_lines_form(prev) == 1 and lib.cer_cost_lines_form(-1) == prev
     args = (1, 4, 4, 4, 4, 64, 64, 112, dbl, 1)
-    assert lib.cer_cost_lines_f32(null, null, null, null, null, null, null, null, *args, 1, 0, 0, 1.0, null) == -1
-    assert lib.cer_cost_lines_f32(fake, fake, null, fake, fake, fake, fake, fake, *args, 0, 0, 0, 1.0, null) == -1      # mode 0: per-view volumes are the walk's
-    assert lib.cer_cost_lines_f32(fake, fake, null, fake, fake, fake, fake, fake, 1, 4, 4, 4, 4, 64, 80, 144, dbl, 1, 1, 0, 0, 1.0, null) == -2   # D > 64
-    assert lib.cer_cost_lines_f32(fake, fake, null, fake, fake, fake, fake, fake, 1, 4, 4, 4, 4, 128, 64, 112, dbl, 1, 1, 0, 0, 1.0, null) == -2  # C != 64
-    assert lib.cer_cost_lines_views_f32(fake, fake, null, fake, fake, fake, 4, 3, 2, 4, 4, 4, 4, 64, 64, dbl, 1, 0, null) == -1      # views 3..4 of 4
+    assert lib.cer_cost_lines_f32(null, null, null, null, null, null, null, null, *args, 1, 0, 0, 1.0, 0, null) == -1
+    assert lib.cer_cost_lines_f32(fake, fake, null, fake, fake, fake, fake, fake, *args, 0, 0, 0, 1.0, 0, null) == -1      # mode 0: per-view volumes are the walk's
+    assert lib.cer_cost_lines_f32(fake, fake, null, fake, fake, fake, fake, fake, 1, 4, 4, 4, 4, 64, 80, 144, dbl, 1, 1, 0, 0, 1.0, 0, null) == -2   # D > 64
+    assert lib.cer_cost_lines_f32(fake, fake, null, fake, fake, fake, fake, fake, 1, 4, 4, 4, 4, 128, 64, 112, dbl, 1, 1, 0, 0, 1.0, 0, null) == -2  # C != 64
+    assert lib.cer_cost_lines_views_f32(fake, fake, null, fake, fake, fake, 4, 3, 2, 4, 4, 4, 4, 64, 64, dbl, 1, 0, 0, null) == -1      # views 3..4 of 4
+    assert lib.cer_cost_lines_views_f32(fake, fake, null, fake, fake, fake, 4, 0, 2, 4, 4, 4, 4, 64, 64, dbl, 1, 0, 2, null) == -1      # two_term is 0 or 1 (ABI 1070)
     assert lib.cer_cost_lines_reduce_f32(fake, fake, fake, null, 2, 4, 4, 64, 60, dbl, 1, 1, 0, 1.0, null) == -1           # row shorter than D
     assert lib.cer_cost_lines_reduce_f32(fake, fake, fake, null, 2, 4, 4, 64, 112, dbl, 1, 2, 3, 1.0, null) == -1          # fused pyramid needs mode 1
     assert lib.cer_f16_scan_overflow(fake, 24, fake, 4, null) == -1 and lib.cer_f16_scan_overflow(misaligned, 32, fake, 4, null) == -3
@@ -448,22 +449,30 @@ def test_arithmetic_forms_of_the_auto_walk():
     from cer_mvs_amd import RAFT
     m = RAFT(test_mode=True)
     assert m.enc_precision == "auto" and m._auto_forms() == RAFT.AUTO_FORMS and RAFT.AUTO_FORMS[-1] == "s16"
-    assert RAFT.AUTO_FORMS[0] == "s16f8+e6" and m._enc_f6 and m.update_block.corr_fp8 is True      # the first candidate until a calibration says otherwise
+    assert RAFT.AUTO_FORMS[0] == "s16f8+e6+c2" and m._enc_f6 and m._cost_x2 and m.update_block.corr_fp8 is True      # the first candidate until a calibration says otherwise
+    m._set_form("s16f8+e6")
+    assert m._enc_f6 and not m._cost_x2
     m._set_form("s16f8")
-    assert not m._enc_f6 and m.update_block.corr_fp8 is True
+    assert not m._enc_f6 and not m._cost_x2 and m.update_block.corr_fp8 is True
     m._set_form("s16")
     assert not m._enc_f6 and m.update_block.corr_fp8 is False
     p = RAFT(test_mode=True, enc_precision="f16x3")
-    assert p._auto_forms() == tuple(f for f in RAFT.AUTO_FORMS if "+" not in f) and not p._enc_f6
-    p._set_form("s16f8+e6")
-    assert not p._enc_f6                                               # pinned: the suffix is ignored
+    assert p._auto_forms() == tuple(f for f in RAFT.AUTO_FORMS if "e6" not in f.split("+")) and not p._enc_f6
+    p._set_form("s16f8+e6+c2")
+    assert not p._enc_f6 and p._cost_x2                                # pinned encoders: their suffix is ignored, the cost volume's is not
+    c = RAFT(test_mode=True, cost_precision="x3")
+    assert c._auto_forms() == tuple(f for f in RAFT.AUTO_FORMS if "c2" not in f.split("+")) and c._enc_f6 and not c._cost_x2
+    assert RAFT(test_mode=True, cost_precision="x2", gru_precision="s16")._cost_x2
     f = RAFT(test_mode=True, enc_precision="f6", gru_precision="s16")
     assert f._enc_f6 and f.update_block.corr_fp8 is False
     f._set_form("s16f8")
     assert f._enc_f6
-    assert not RAFT(test_mode=True, gru_precision="s16f8")._enc_f6     # a pinned update-block form leaves the encoders fp32-class
+    pinned = RAFT(test_mode=True, gru_precision="s16f8")
+    assert not pinned._enc_f6 and not pinned._cost_x2                  # a pinned update-block form leaves the encoders and the cost volume fp32-class
     with pytest.raises(ValueError):
         RAFT(test_mode=True, enc_precision="fp8")
+    with pytest.raises(ValueError):
+        RAFT(test_mode=True, cost_precision="f16")
 
 
 def test_encoder_fp6_weight_packing():
