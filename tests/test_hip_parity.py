@@ -405,8 +405,8 @@ def test_cost_lines_matches_walk(dev, D, stage0, geom, form):
 def test_cost_lines_two_term_form(dev, D, stage0, geom):
     """Round 6 (ABI 1070, ``two_term``): the tile kernel WITHOUT the source texels' lo planes - the source features enter the 64-channel dots as
     f16, the reference rows keep both halves.  Against the three-term form on the same inputs: origins identical, the volume a source-f16
-    rounding away (each texel 2^-12 relative: ~1e-5 relative L1 on the volume - measured 1.2e-5 at the bench workload; a LOST term of the
-    reference rows would be the same size again, a wrong plane 1e-1), and exactly what the THREE-term kernel returns for source features rounded to
+    rounding away (each texel 2^-12 relative: 1.2e-5 relative L1 on the volume at the bench workload, ~2e-4 on this test's hashed features whose
+    dots cancel; a wrong plane is 1e-1), and exactly what the THREE-term kernel returns for source features rounded to
     f16 beforehand - which pins the form to its definition instead of to a tolerance.  Deterministic; the fused epilogue and the
     level-0-only rows as in the three-term form."""
     from cer_mvs_amd import ops
@@ -423,7 +423,7 @@ def test_cost_lines_two_term_form(dev, D, stage0, geom):
         f2r = ((f2 * 64.0).clamp(-65504.0, 65504.0).half().float() / 64.0)
         r3, _ = ops.cost_build(f1, f2r, Pij, d0, D, incre, stage0, h1, w1, 3, fold=True, pyramid_scale=1.0 / V)
         print(f"{geom} D={D} {h1}x{w1}: two-term vs three-term {e:.2e}; vs three-term on f16-rounded source rows {rel_l1(a2.cpu(), r3.cpu()):.2e}")
-        assert 1e-6 < e < 1e-4
+        assert 1e-6 < e < 1e-3            # (hashed features: dots of random signs cancel, the relative figure is 10 x the bench scene's 1.2e-5)
         assert torch.equal(a2, r3)
 
 
