@@ -146,7 +146,7 @@ __device__ __forceinline__ float cl_wmax(float x) {
 // direct path: the four texel dots of one sample from the split planes in global memory (scaled by 2^(2 CL_LOG2S), like the MFMA path).
 // f1t / t00: the (block, texel) base of plane 0 (hi, channels 0-15); ps1 / ps2: plane strides in halves of the two maps
 __device__ __noinline__ float cl_direct(const _Float16* __restrict__ f1t, long ps1, const _Float16* __restrict__ t00, long ps2, int smajS, int sminS,
-                                        float wm0, float wm1, float wn0, float wn1) {
+                                        float wm0, float wm1, float wn0, float wn1, bool f2lo = true) {      // f2lo = false: the two-term form (source texels as f16)
     float d[4] = {0.f, 0.f, 0.f, 0.f};
     const _Float16* tp[4] = {t00, t00 + (long)smajS * 16, t00 + (long)sminS * 16, t00 + (long)(smajS + sminS) * 16};
     for (int c8 = 0; c8 < 8; ++c8) {
@@ -156,7 +156,7 @@ __device__ __noinline__ float cl_direct(const _Float16* __restrict__ f1t, long p
         for (int q = 0; q < 4; ++q) {
             const half8 bh = *reinterpret_cast<const half8*>(tp[q] + ks * ps2 + kg * 8), bl = *reinterpret_cast<const half8*>(tp[q] + (4 + ks) * ps2 + kg * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) d[q] = fmaf((float)ah[e] + (float)al[e], (float)bh[e] + (float)bl[e], d[q]);
+            for (int e = 0; e < 8; ++e) d[q] = fmaf((float)ah[e] + (float)al[e], f2lo ? (float)bh[e] + (float)bl[e] : (float)bh[e], d[q]);
         }
     }
     return d[0] * (wn0 * wm0) + d[1] * (wn0 * wm1) + d[2] * (wn1 * wm0) + d[3] * (wn1 * wm1);
@@ -514,7 +514,7 @@ __device__ __forceinline__ void cl_tile(const ClArgs& A, const int v, const int 
     auto direct_value = [&]() -> float {
         const int sc = (int)(pk & 0xFFFFu) - 4, sr = (int)((pk >> 16) & 0x3FFFu) - 4;
         const _Float16* t00 = f2v + (long)((sc + 2) * smajS + (sr + 2) * sminS) * 16;
-        return cl_direct(f1t, ps1, t00, ps2, smajS, sminS, 1.0f - fm, fm, 1.0f - fn, fn);
+        return cl_direct(f1t, ps1, t00, ps2, smajS, sminS, 1.0f - fm, fm, 1.0f - fn, fn, F2LO);
     };
 
     for (int n = 0; n < nchunks; ++n) {
