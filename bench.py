@@ -433,14 +433,15 @@ def main():
                 if "note" in a_:
                     e["note"] = a_["note"]
             kern[k] = e
-        for cand in ("r03_pmc_traffic.json", "r04_pmc_traffic.json", "r05_pmc_traffic.json"):   # HBM traffic of the cost-volume kernel from the
+        cl_key = "cost_lines_kernel_x2" if cost_x2 else "cost_lines_kernel"            # (round 6: the two-term form has its own PMC row)
+        for cand in ("r03_pmc_traffic.json", "r04_pmc_traffic.json", "r05_pmc_traffic.json", "r06_pmc_traffic.json"):   # HBM traffic of the cost-volume kernel from the
             try:                                                  # committed PMC passes (the latest file holding the kernel wins)
                 with open(os.path.join(REPO, "profiles", cand)) as f:
-                    pm = json.load(f).get("cost_lines_kernel", {})
+                    pm = json.load(f).get(cl_key, {})
                 for k in kern:
                     if k.startswith("cost_build_stage") and "traffic_bytes" in pm:
                         kern[k]["pmc_traffic_bytes_avg_of_both_stages"] = pm["traffic_bytes"]
-                        kern[k]["pmc_source"] = f"profiles/{cand} (cost_lines_kernel, mean of the stage-0 and stage-1 launches)"
+                        kern[k]["pmc_source"] = f"profiles/{cand} ({cl_key}, mean of the stage-0 and stage-1 launches)"
             except Exception:
                 pass
         enc = [(k, v) for k, v in rec.items() if k.startswith("enc_")]

@@ -20,7 +20,7 @@ ap.add_argument("--enc-precision", default="f6", help="the shipped auto form on 
 args = ap.parse_args()
 H, W, V, cascade = bench.WORKLOADS[args.workload]
 dev = torch.device("cuda")
-model = RAFT(cascade=cascade, test_mode=True, gru_precision=args.gru_precision, enc_precision=args.enc_precision)
+model = RAFT(cascade=cascade, test_mode=True, gru_precision=args.gru_precision, enc_precision=args.enc_precision, cost_precision="x2")   # (the shipped auto form on the bench weights: s16f8+e6+c2)
 model.load_state_dict(fill_state_dict(model.state_dict(), seed=5))
 model = model.to(dev).eval()
 images, poses, intr, scale = synthetic_scene(H, W, V, seed=0)

@@ -21,8 +21,9 @@ run() {   # name, kernel regex, command...
   run conv3x3_gru_q_f8 "conv3x3_s16_kernel<2, 2, ., 3, 1>" python tools/bench_conv_s16.py --f8 --only "gru" --rounds 1 --reps 1
   run conv3x3_delta_f8 "conv3x3_s16_kernel<1, 4, 4, 4, 1>" python tools/bench_conv_s16.py --f8 --only "delta" --rounds 1 --reps 1
   run conv3x3_corr2_f8 "conv3x3_s16_kernel<2, 2, ., 1, 1>" python tools/bench_conv_s16.py --f8 --only "corr2" --rounds 1 --reps 1
-  run cost_lines_kernel "cost_lines_kernel" python tools/prof_build.py
+  run cost_lines_kernel "cost_lines_kernel<3, true>" python tools/prof_build.py
   run cost_lines_bands_kernel "cost_lines_bands_kernel" python tools/prof_build.py
+  run cost_lines_kernel_x2 "cost_lines_kernel<3, false>" env CER_COST_X2=1 python tools/prof_build.py
   run lookup_encode "lookup_encode" python tools/prof_conv.py lookup --reps 1
   run enc_pc_32to32 "enc_pc_kernel<32, 32, 1, 9, 0, false>" python tools/bench_pc.py 32
   run enc_pc_32to32_f6 "enc_pc_kernel<32, 32, 1, 9, 0, false, true>" env CER_ENC_F6=1 python tools/bench_pc.py 32

@@ -33,7 +33,7 @@ with torch.no_grad():
         for algo, name in ((1, "walk"), (0, "lines")):
             lib.cer_cost_build_algo(algo)
             fn = lambda: ops.cost_build(f1, f2, Pij, d_in, D, incre, st == 0, h, w, model.update_block.num_levels, fold=True,
-                                        pyramid_scale=1.0 / V, split=split)
+                                        pyramid_scale=1.0 / V, split=split, two_term=os.environ.get("CER_COST_X2", "0") == "1")
             res[name] = fn()[0]
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

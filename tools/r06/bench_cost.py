@@ -42,7 +42,8 @@ with torch.no_grad():
         return 1e3 * e0.elapsed_time(e1) / reps
 
     for stage, (D, inc, d, s0) in enumerate(((D0, i0, disp0, True), (D1, i1, d1, False))):
-        build = lambda: ops.cost_build(f1, f2, Pij, d, D, inc, s0, h, w, 3, fold=True, pyramid_scale=1.0 / V, split=split, compact=True)
+        build = lambda: ops.cost_build(f1, f2, Pij, d, D, inc, s0, h, w, 3, fold=True, pyramid_scale=1.0 / V, split=split, compact=True,
+                                       two_term=os.environ.get("CER_COST_X2", "0") == "1")      # (CER_COST_X2=1: the two-term form, round 6)
         a = build()[0].clone()
         us = t(build)
         prev = lib.cer_cost_build_algo(1)

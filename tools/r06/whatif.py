@@ -38,7 +38,7 @@ def measure(label, pred):
     out = []
     try:
         for S in (1, 3):
-            model = RAFT(cascade=cascade, test_mode=True, gru_precision=args.gru_precision, enc_precision=args.enc_precision)
+            model = RAFT(cascade=cascade, test_mode=True, gru_precision=args.gru_precision, enc_precision=args.enc_precision, cost_precision="x2")   # (the shipped auto form on the bench weights: s16f8+e6+c2)
             model.load_state_dict(fill_state_dict(model.state_dict(), seed=5))
             model = model.to(dev).eval()
             model.overflow_policy = "ignore"

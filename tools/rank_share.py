@@ -89,7 +89,7 @@ def main():
     inputs = (images.to(dev), poses.to(dev), intr.to(dev))
 
     def make(**kw):
-        m = RAFT(cascade=cascade, test_mode=True, gru_precision="s16f8", enc_precision="f6", **kw)
+        m = RAFT(cascade=cascade, test_mode=True, gru_precision="s16f8", enc_precision="f6", cost_precision="x2", **kw)
         m.load_state_dict(fill_state_dict(m.state_dict(), seed=5))
         return m.to(dev).eval()
 
