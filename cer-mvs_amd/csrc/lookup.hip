@@ -11,6 +11,9 @@
 #define LK_PIX 64          // pixels per block
 #define LK_MAX_ROW 256     // max row_stride (floats)
 #define LK_MAX_TAPS 64     // max L*(2r+1)
+#ifndef LK_ABL
+#define LK_ABL 0           // timing ablations (variant builds, results wrong): 1 no 1x1 conv loop, 2 no windows, 4 no row loads, 8 no output stores
+#endif
 #ifndef LK_OCC4
 #define LK_OCC4 5          // blocks per CU the 4-prefetch-register instantiation (level-0-only rows) is compiled for
 #endif
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256, MAXPRE <= 4 ? LK_OCC4 : MAXPRE <= 8 ? 4 : 3) v
 #pragma unroll
         for (int i = 0; i < MAXPRE; ++i) {                // (predicated, not `break`: pre[] must stay in registers)
             if (i < npre) {
-                pre[i] = pr < npix ? cer_ld4(src + (long)(threadIdx.x + 256 * i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                pre[i] = (pr < npix && !(LK_ABL & 4)) ? cer_ld4(src + (long)(threadIdx.x + 256 * i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 pr += dpr; q += dq;
                 if (q >= n4) { q -= n4; ++pr; }
             }
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256, MAXPRE <= 4 ? LK_OCC4 : MAXPRE <= 8 ? 4 : 3) v
         if (tile + (int)gridDim.x < ntiles) request(tile + gridDim.x);
         float* ft = feats;
         if (fuse_delta && active) c = lk_index(dnew[pix], po, incre, D);
-        if (active)
+        if (active && !(LK_ABL & 2))
             for (int lv = grp; lv < L; lv += 4)            // (straight into the feature tile: no per-thread array)
                 lk_window(&rows[pix * rsp], li.off[lv], li.len[lv], c / (float)(1 << lv), r, &ft[pix * FS + lv * taps], li.pool, lv);
         __syncthreads();                                     // [B2] features complete; rows free for the next tile
@@ -230,12 +233,13 @@ __global__ __launch_bounds__(256, MAXPRE <= 4 ? LK_OCC4 : MAXPRE <= 8 ? 4 : 3) v
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = bias[grp * 16 + j];
 #pragma unroll 3
-        for (int k = 0; k < K; ++k) {
+        for (int k = 0; k < ((LK_ABL & 1) ? 1 : K); ++k) {
             const float f = ft[pix * FS + k];
             const float* wr = wgt + k * 64 + grp * 16;       // wave-uniform: scalar loads
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = fmaf(f, wr[j], acc[j]);
         }
+        if (LK_ABL & 8) { if (acc[0] == 123.456f) out[p0 + pix] = acc[1]; continue; }
         if (out_split == 2) {
             // frag16 layout (cer_mvs.h, conv_s16.hip): this thread's 16 channels are group `grp` of its pixel's m-tile: four 16-byte
             // pieces (hi | lo planes x channel octets) of relu(acc) * out_scale
