@@ -16,7 +16,7 @@
 #define LK_ABL 0           // timing ablations (variant builds, results wrong): 1 no 1x1 conv loop, 2 no windows, 4 no row loads, 8 no output stores
 #endif
 #ifndef LK_OCC_MM
-#define LK_OCC_MM 3        // blocks per CU the matrix-core instantiation is compiled for (36 registers of weight fragments: 4 would spill ~100)
+#define LK_OCC_MM 4        // blocks per CU the matrix-core instantiations with one or two k16-steps are compiled for (three steps: 3)
 #endif
 #ifndef LK_OCC4
 #define LK_OCC4 5          // blocks per CU the 4-prefetch-register instantiation (level-0-only rows) is compiled for
@@ -172,19 +172,22 @@ struct LkDelta {
 };
 // MAXPRE: float4 registers of the next tile's rows per thread (4: level-0-only rows up to 64 floats - the model's since round 5; 8: rows up to
 // 128 floats - the stored pyramid's 112; 16: any row the entry point accepts)
-template <int MAXPRE, bool MM = false>
-__global__ __launch_bounds__(256, MM ? LK_OCC_MM : MAXPRE <= 4 ? LK_OCC4 : MAXPRE <= 8 ? 4 : 3) void lookup_encode_kernel(const float* __restrict__ vol, const float* __restrict__ origin,
+// NS: k16-steps of the matrix-core conv (0: the vector form).  K = 33 is two steps + ONE column: the columns behind 16 NS (at most four) are added by
+// plain fmas on the reassembled fp32 value - a third step would spend a third of the MFMAs and 12 registers of weight fragments on one column
+template <int MAXPRE, int NS = 0>
+__global__ __launch_bounds__(256, NS == 3 ? 3 : NS ? LK_OCC_MM : MAXPRE <= 4 ? LK_OCC4 : MAXPRE <= 8 ? 4 : 3) void lookup_encode_kernel(const float* __restrict__ vol, const float* __restrict__ origin,
                                                             const float* __restrict__ disp, const float* __restrict__ wgt,
                                                             const float* __restrict__ bias, float* __restrict__ out, long P, int D, int rs,
                                                             float incre, int L, int r, LevelInfo li, int out_split, float out_scale, int img_w,
                                                             int ntiles, LkDelta dl) {
+    constexpr bool MM = NS > 0;
     extern __shared__ __attribute__((aligned(16))) float lk_smem[];
     const int rsp = lk_pitch(rs);
     const int taps = 2 * r + 1, K = L * taps, FS = K | 1;                         // (odd pixel stride: conflict-free columns)
     float* rows = lk_smem;                                   // [LK_PIX][rsp]
     float* feats = lk_smem + LK_PIX * rsp;                   // [LK_PIX][FS]  (one tile: see the happens-before note above); MM: [LK_PIX][LK_MM_PITCH bytes]
     float* dnew = feats + (MM ? LK_PIX * (LK_MM_PITCH / 4) : LK_PIX * FS);       // [LK_PIX]  updated disparities of the tile (dl.T given)
-    float* lbias = dnew + LK_PIX;                            // MM: the 64 biases (accumulator start values: float4 reads)
+    float* lbias = dnew + LK_PIX;                            // MM: the 64 biases (accumulator start values: float4 reads), then [4][64] weights of the columns k >= 16 NS
     const int n4 = rs / 4, npre = (LK_PIX * n4 + 255) / 256;
     const int pix = threadIdx.x & 63;
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id: lookup level, then output-channel group
@@ -230,10 +233,10 @@ __global__ __launch_bounds__(256, MM ? LK_OCC_MM : MAXPRE <= 4 ? LK_OCC4 : MAXPR
     // MM: this wave's A fragments - the weights of channels 32 chh + li, k = 16 s + 8 kg + 0..7, in three bf16 pieces - for the whole launch;
     // the split feature tile starts as zeros (its k >= K columns stay zero: they are never written)
     const int mm_li = threadIdx.x & 31, mm_kg = (threadIdx.x >> 5) & 1, mm_ph = grp & 1, mm_chh = grp >> 1;
-    lk_bf16x8 wA[MM ? 3 : 1][3];
+    lk_bf16x8 wA[MM ? NS : 1][3];
     if constexpr (MM) {
 #pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3)
+        for (int s3 = 0; s3 < NS; ++s3)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int k = 16 * s3 + 8 * mm_kg + e;
@@ -244,6 +247,10 @@ __global__ __launch_bounds__(256, MM ? LK_OCC_MM : MAXPRE <= 4 ? LK_OCC4 : MAXPR
             }
         for (int t = threadIdx.x; t < LK_PIX * (LK_MM_PITCH / 16); t += 256) reinterpret_cast<float4*>(feats)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (threadIdx.x < 64) lbias[threadIdx.x] = bias[threadIdx.x];
+        {   // weights of the remainder columns (zeros behind K)
+            const int kr = 16 * NS + (threadIdx.x >> 6);
+            lbias[64 + threadIdx.x] = kr < K ? wgt[kr * 64 + (threadIdx.x & 63)] : 0.f;
+        }
     }
     int tile = blockIdx.x;
     if (tile < ntiles) request(tile);
@@ -305,9 +312,20 @@ __global__ __launch_bounds__(256, MM ? LK_OCC_MM : MAXPRE <= 4 ? LK_OCC4 : MAXPR
                 acc[4 * j + 0] = b4.x; acc[4 * j + 1] = b4.y; acc[4 * j + 2] = b4.z; acc[4 * j + 3] = b4.w;
             }
             const char* fb = reinterpret_cast<const char*>(feats) + (32 * mm_ph + mm_li) * LK_MM_PITCH + 16 * mm_kg;
-            // per k16-step the six piece products above 2^-24, smallest first: (weight piece, feature piece)
+            // the remainder columns first (plain fp32: value = b1 + b2 + b3 exactly), then per k16-step the six piece products above 2^-24, smallest first
+            for (int kr = 16 * NS; kr < K; ++kr) {
+                const char* fr = reinterpret_cast<const char*>(feats) + (32 * mm_ph + mm_li) * LK_MM_PITCH + 2 * kr;
+                const float f = ((float)*reinterpret_cast<const __bf16*>(fr + 192) + (float)*reinterpret_cast<const __bf16*>(fr + 96)) + (float)*reinterpret_cast<const __bf16*>(fr);
+                const float* wr = lbias + 64 + (kr - 16 * NS) * 64 + 32 * mm_chh + 4 * mm_kg;
 #pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) {
+                for (int j = 0; j < 4; ++j) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(wr + 8 * j);
+                    acc[4 * j + 0] = fmaf(f, w4.x, acc[4 * j + 0]); acc[4 * j + 1] = fmaf(f, w4.y, acc[4 * j + 1]);
+                    acc[4 * j + 2] = fmaf(f, w4.z, acc[4 * j + 2]); acc[4 * j + 3] = fmaf(f, w4.w, acc[4 * j + 3]);
+                }
+            }
+#pragma unroll
+            for (int s3 = 0; s3 < NS; ++s3) {
                 lk_bf16x8 fB[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) fB[q] = *reinterpret_cast<const lk_bf16x8*>(fb + 96 * q + 32 * s3);
@@ -462,25 +480,30 @@ extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, floa
     // round 6: the 1x1 conv on the matrix cores (the model's launches: level-0-only rows up to 64 floats, frag16 output, K <= 48).  CER_LOOKUP_MM=0 keeps the
     // vector form (A/B runs, tests/test_hip_parity.py::test_lookup_conv_on_matrix_cores)
     const char* mm_env = getenv("CER_LOOKUP_MM");           // (read per call: a test toggles it inside one process)
-    const bool mm = !(mm_env && mm_env[0] == '0') && pre == 4 && out_split == 2 && K <= 48;
-    const size_t smem = mm ? sizeof(float) * LK_PIX * ((size_t)lk_pitch(row_stride) + 1) + (size_t)LK_PIX * LK_MM_PITCH + 64 * sizeof(float)
+    const bool mm = !(mm_env && mm_env[0] == '0') && pre == 4 && out_split == 2 && K >= 16 && K <= 48;
+    const int ns = (K % 16 == 0 || K % 16 > 4) ? (K + 15) / 16 : K / 16;                    // k16-steps on the matrix cores; up to four columns behind them by fmas
+    const size_t smem = mm ? sizeof(float) * LK_PIX * ((size_t)lk_pitch(row_stride) + 1) + (size_t)LK_PIX * LK_MM_PITCH + 5 * 64 * sizeof(float)
                            : sizeof(float) * LK_PIX * ((size_t)lk_pitch(row_stride) + (K | 1) + 1) + 64 * sizeof(float);
     const int ncu = cer_num_cus();
     LkDelta dl;
     dl.T = delta_taps; dl.disp_rw = disp; dl.nhalf = delta_nhalf; dl.h = delta_taps ? (int)(P / img_w) : 0; dl.bias = delta_bias;
     dl.flag = out_split == 2 ? cer_overflow_flag_get() : nullptr;
-    const int by_regs = mm ? LK_OCC_MM : pre == 4 ? LK_OCC4 : pre == 8 ? 4 : 3;
+    const int by_regs = mm ? (ns == 3 ? 3 : LK_OCC_MM) : pre == 4 ? LK_OCC4 : pre == 8 ? 4 : 3;
     const int by_lds = (int)((long)cer_lds_per_cu() / (long)(smem + 256));
     const long resident = (long)ncu * (by_lds < 1 ? 1 : by_lds < by_regs ? by_lds : by_regs);
     const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);
 #define LK_LAUNCH(N) hipLaunchKernelGGL(lookup_encode_kernel<N>, dim3(grid), dim3(256), smem, (hipStream_t)stream, vol, origin, disp, w, b, out, P, D, row_stride, \
                                         (float)incre, num_levels, radius, li, out_split, ldexpf(1.0f, log2s_out), img_w, (int)ntiles, dl)
-    if (mm) hipLaunchKernelGGL((lookup_encode_kernel<4, true>), dim3(grid), dim3(256), smem, (hipStream_t)stream, vol, origin, disp, w, b, out, P, D, row_stride,
-                               (float)incre, num_levels, radius, li, out_split, ldexpf(1.0f, log2s_out), img_w, (int)ntiles, dl);
+#define LK_LAUNCH_MM(NS_) hipLaunchKernelGGL((lookup_encode_kernel<4, NS_>), dim3(grid), dim3(256), smem, (hipStream_t)stream, vol, origin, disp, w, b, out, P, D, row_stride, \
+                               (float)incre, num_levels, radius, li, out_split, ldexpf(1.0f, log2s_out), img_w, (int)ntiles, dl)
+    if (mm && ns == 1) LK_LAUNCH_MM(1);
+    else if (mm && ns == 2) LK_LAUNCH_MM(2);
+    else if (mm) LK_LAUNCH_MM(3);
     else if (pre == 4) LK_LAUNCH(4);
     else if (pre == 8) LK_LAUNCH(8);
     else LK_LAUNCH(LK_MAX_PRE);
 #undef LK_LAUNCH
+#undef LK_LAUNCH_MM
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }
