@@ -7,16 +7,12 @@
 // L*(2r+1) = 33 floats (or 64 encoded floats) are written.  A block stages 64 consecutive rows
 // into LDS with coalesced 16-B loads; each thread then owns (pixel, level-slice) windows.
 #include "common.hpp"
-#include <stdlib.h>
 
 #define LK_PIX 64          // pixels per block
 #define LK_MAX_ROW 256     // max row_stride (floats)
 #define LK_MAX_TAPS 64     // max L*(2r+1)
 #ifndef LK_ABL
 #define LK_ABL 0           // timing ablations (variant builds, results wrong): 1 no 1x1 conv loop, 2 no windows, 4 no row loads, 8 no output stores
-#endif
-#ifndef LK_OCC_MM
-#define LK_OCC_MM 4        // blocks per CU the matrix-core instantiations with one or two k16-steps are compiled for (three steps: 3)
 #endif
 #ifndef LK_OCC4
 #define LK_OCC4 5          // blocks per CU the 4-prefetch-register instantiation (level-0-only rows) is compiled for
@@ -126,38 +122,6 @@ __global__ __launch_bounds__(256) void lookup_kernel(const float* __restrict__ v
 // there - i.e. has finished its conv of tile t (the conv precedes the next tile's row stores and [B1](t+1) in every wave's program order).
 // The schedule-fuzz build (common.hpp CER_FUZZ) reproduces the first launch over 2 000 launches.
 #define LK_MAX_PRE 16      // float4 per thread of one 64-row tile: 64 * (LK_MAX_ROW / 4) / 256
-// Round 6 (MM = true): the 1x1 conv (K = L * taps <= 48 -> 64 channels) on the matrix cores.  By the kernel's ablation builds (LK_ABL) the conv loop - 33 x
-// (LDS read + 16 scalar-loaded weights + 8 packed fmas) per thread - is 10 of the launch's 27.7 us, all vector issue.  fp32-class on f16 / bf16 MFMAs needs
-// split operands; the correlation values have no bound that f16 could rely on, so both operands are split into THREE bf16 pieces (x = b1 + b2 + b3 exactly
-// to 24 bits, fp32 range) and the six products whose weight is above 2^-24 are accumulated - smallest first - into one fp32 accumulator that starts at the
-// bias: 18 v_mfma_f32_32x32x16_bf16 per wave and tile (576 matrix-pipe cycles) instead of 264 packed fmas + 33 scalar loads.  The window code splits a
-// value as it produces it (2-byte LDS stores into [pixel][piece][k], pitch 304 B: conflict-free 16-byte fragment reads); the weights are split once per
-// block into A fragments in registers.  Orientation as in conv_s16.hip: A = weights (rows = channels), B = features (columns = pixels), so after one
-// v_permlane32_swap per register pair a lane owns 8 consecutive channels of one pixel = one 16-byte piece of the frag16 planes.
-#define LK_MM_PITCH 304    // bytes per pixel of the split feature tile: 3 pieces x 48 k x 2 B + 16 (odd number of 16-byte slots)
-typedef __bf16 lk_bf16x8 __attribute__((ext_vector_type(8)));
-typedef float lk_floatx16 __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ void lk_split3(float f, __bf16& b1, __bf16& b2, __bf16& b3) {
-    b1 = (__bf16)f;                                          // round to nearest even; the residuals are exact fp32 differences
-    const float r1 = f - (float)b1;
-    b2 = (__bf16)r1;
-    b3 = (__bf16)(r1 - (float)b2);
-}
-// lk_window with the taps handed to `emit(j, value)` instead of being stored as floats
-template <typename Emit>
-__device__ __forceinline__ void lk_window_emit(const float* __restrict__ row, int off, int len, float x, int r, int pool, int lv, Emit emit) {
-    const float fx = floorf(x);
-    const float w = x - fx;
-    const bool in_range = fx < (float)(len + r + 1);
-    const int i0 = in_range ? (int)fx - r : 0;
-    float prev = (in_range && i0 >= 0 && i0 < len) ? (pool ? lk_elem(row, lv, i0) : row[off + i0]) : 0.f;
-    for (int j = 0; j < 2 * r + 1; ++j) {
-        const int i = i0 + j + 1;
-        const float next = (in_range && i >= 0 && i < len) ? (pool ? lk_elem(row, lv, i) : row[off + i]) : 0.f;
-        emit(j, prev * (1.0f - w) + next * w);               // (the expression of lk_window: the same value bit for bit)
-        prev = next;
-    }
-}
 // Round 5: the PREVIOUS iteration's disparity update (core/update.py:114, core/raft.py:101: disp += 0.01 * delta, the 18-tap gather of
 // cer_delta_sum_f32) can ride on this launch: with `dT` given, wave 3 - idle while waves 0-2 form the three levels' windows - requests the
 // tap planes of a tile's pixels together with the tile's rows, forms  d' = d + 0.01 * (bias + sum of the taps)  in cer_delta_sum_f32's
@@ -172,22 +136,18 @@ struct LkDelta {
 };
 // MAXPRE: float4 registers of the next tile's rows per thread (4: level-0-only rows up to 64 floats - the model's since round 5; 8: rows up to
 // 128 floats - the stored pyramid's 112; 16: any row the entry point accepts)
-// NS: k16-steps of the matrix-core conv (0: the vector form).  K = 33 is two steps + ONE column: the columns behind 16 NS (at most four) are added by
-// plain fmas on the reassembled fp32 value - a third step would spend a third of the MFMAs and 12 registers of weight fragments on one column
-template <int MAXPRE, int NS = 0>
-__global__ __launch_bounds__(256, NS == 3 ? 3 : NS ? LK_OCC_MM : MAXPRE <= 4 ? LK_OCC4 : MAXPRE <= 8 ? 4 : 3) void lookup_encode_kernel(const float* __restrict__ vol, const float* __restrict__ origin,
+template <int MAXPRE>
+__global__ __launch_bounds__(256, MAXPRE <= 4 ? LK_OCC4 : MAXPRE <= 8 ? 4 : 3) void lookup_encode_kernel(const float* __restrict__ vol, const float* __restrict__ origin,
                                                             const float* __restrict__ disp, const float* __restrict__ wgt,
                                                             const float* __restrict__ bias, float* __restrict__ out, long P, int D, int rs,
                                                             float incre, int L, int r, LevelInfo li, int out_split, float out_scale, int img_w,
                                                             int ntiles, LkDelta dl) {
-    constexpr bool MM = NS > 0;
     extern __shared__ __attribute__((aligned(16))) float lk_smem[];
     const int rsp = lk_pitch(rs);
     const int taps = 2 * r + 1, K = L * taps, FS = K | 1;                         // (odd pixel stride: conflict-free columns)
     float* rows = lk_smem;                                   // [LK_PIX][rsp]
-    float* feats = lk_smem + LK_PIX * rsp;                   // [LK_PIX][FS]  (one tile: see the happens-before note above); MM: [LK_PIX][LK_MM_PITCH bytes]
-    float* dnew = feats + (MM ? LK_PIX * (LK_MM_PITCH / 4) : LK_PIX * FS);       // [LK_PIX]  updated disparities of the tile (dl.T given)
-    float* lbias = dnew + LK_PIX;                            // MM: the 64 biases (accumulator start values: float4 reads), then [4][64] weights of the columns k >= 16 NS
+    float* feats = lk_smem + LK_PIX * rsp;                   // [LK_PIX][FS]  (one tile: see the happens-before note above)
+    float* dnew = feats + LK_PIX * FS;                       // [LK_PIX]  updated disparities of the tile (dl.T given)
     const int n4 = rs / 4, npre = (LK_PIX * n4 + 255) / 256;
     const int pix = threadIdx.x & 63;
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id: lookup level, then output-channel group
@@ -230,28 +190,6 @@ __global__ __launch_bounds__(256, NS == 3 ? 3 : NS ? LK_OCC_MM : MAXPRE <= 4 ? L
             }
         }
     };
-    // MM: this wave's A fragments - the weights of channels 32 chh + li, k = 16 s + 8 kg + 0..7, in three bf16 pieces - for the whole launch;
-    // the split feature tile starts as zeros (its k >= K columns stay zero: they are never written)
-    const int mm_li = threadIdx.x & 31, mm_kg = (threadIdx.x >> 5) & 1, mm_ph = grp & 1, mm_chh = grp >> 1;
-    lk_bf16x8 wA[MM ? NS : 1][3];
-    if constexpr (MM) {
-#pragma unroll
-        for (int s3 = 0; s3 < NS; ++s3)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = 16 * s3 + 8 * mm_kg + e;
-                const float wv = k < K ? wgt[k * 64 + 32 * mm_chh + mm_li] : 0.f;
-                __bf16 b1, b2, b3;
-                lk_split3(wv, b1, b2, b3);
-                wA[s3][0][e] = b1; wA[s3][1][e] = b2; wA[s3][2][e] = b3;
-            }
-        for (int t = threadIdx.x; t < LK_PIX * (LK_MM_PITCH / 16); t += 256) reinterpret_cast<float4*>(feats)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (threadIdx.x < 64) lbias[threadIdx.x] = bias[threadIdx.x];
-        {   // weights of the remainder columns (zeros behind K)
-            const int kr = 16 * NS + (threadIdx.x >> 6);
-            lbias[64 + threadIdx.x] = kr < K ? wgt[kr * 64 + (threadIdx.x & 63)] : 0.f;
-        }
-    }
     int tile = blockIdx.x;
     if (tile < ntiles) request(tile);
     for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
@@ -285,90 +223,11 @@ __global__ __launch_bounds__(256, NS == 3 ? 3 : NS ? LK_OCC_MM : MAXPRE <= 4 ? L
         if (tile + (int)gridDim.x < ntiles) request(tile + gridDim.x);
         float* ft = feats;
         if (fuse_delta && active) c = lk_index(dnew[pix], po, incre, D);
-        if constexpr (MM) {
-            if (active)
-                for (int lv = grp; lv < L; lv += 4) {
-                    char* fp = reinterpret_cast<char*>(feats) + pix * LK_MM_PITCH + 2 * lv * taps;
-                    lk_window_emit(&rows[pix * rsp], li.off[lv], li.len[lv], c / (float)(1 << lv), r, li.pool, lv, [&](int j, float v) {
-                        __bf16 b1, b2, b3;
-                        lk_split3(v, b1, b2, b3);
-                        *reinterpret_cast<__bf16*>(fp + 2 * j) = b1;
-                        *reinterpret_cast<__bf16*>(fp + 96 + 2 * j) = b2;
-                        *reinterpret_cast<__bf16*>(fp + 192 + 2 * j) = b3;
-                    });
-                }
-        } else
         if (active && !(LK_ABL & 2))
             for (int lv = grp; lv < L; lv += 4)            // (straight into the feature tile: no per-thread array)
                 lk_window(&rows[pix * rsp], li.off[lv], li.len[lv], c / (float)(1 << lv), r, &ft[pix * FS + lv * taps], li.pool, lv);
         __syncthreads();                                     // [B2] features complete; rows free for the next tile
         CER_FUZZ_POINT();
-        if constexpr (MM) {
-            // wave (ph, chh): pixels 32 ph + 0..31 (columns) x channels 32 chh + 0..31 (rows); acc[4 j + e] = channel 32 chh + 8 j + 4 kg + e of pixel li
-            lk_floatx16 acc;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 b4 = *reinterpret_cast<const float4*>(lbias + 32 * mm_chh + 8 * j + 4 * mm_kg);
-                acc[4 * j + 0] = b4.x; acc[4 * j + 1] = b4.y; acc[4 * j + 2] = b4.z; acc[4 * j + 3] = b4.w;
-            }
-            const char* fb = reinterpret_cast<const char*>(feats) + (32 * mm_ph + mm_li) * LK_MM_PITCH + 16 * mm_kg;
-            // the remainder columns first (plain fp32: value = b1 + b2 + b3 exactly), then per k16-step the six piece products above 2^-24, smallest first
-            for (int kr = 16 * NS; kr < K; ++kr) {
-                const char* fr = reinterpret_cast<const char*>(feats) + (32 * mm_ph + mm_li) * LK_MM_PITCH + 2 * kr;
-                const float f = ((float)*reinterpret_cast<const __bf16*>(fr + 192) + (float)*reinterpret_cast<const __bf16*>(fr + 96)) + (float)*reinterpret_cast<const __bf16*>(fr);
-                const float* wr = lbias + 64 + (kr - 16 * NS) * 64 + 32 * mm_chh + 4 * mm_kg;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 w4 = *reinterpret_cast<const float4*>(wr + 8 * j);
-                    acc[4 * j + 0] = fmaf(f, w4.x, acc[4 * j + 0]); acc[4 * j + 1] = fmaf(f, w4.y, acc[4 * j + 1]);
-                    acc[4 * j + 2] = fmaf(f, w4.z, acc[4 * j + 2]); acc[4 * j + 3] = fmaf(f, w4.w, acc[4 * j + 3]);
-                }
-            }
-#pragma unroll
-            for (int s3 = 0; s3 < NS; ++s3) {
-                lk_bf16x8 fB[3];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) fB[q] = *reinterpret_cast<const lk_bf16x8*>(fb + 96 * q + 32 * s3);
-#pragma unroll
-                for (int t6 = 0; t6 < 6; ++t6) {
-                    constexpr int QA[6] = {2, 1, 0, 1, 0, 0}, QB[6] = {0, 1, 2, 0, 1, 0};
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA[s3][QA[t6]], fB[QB[t6]], acc, 0, 0, 0);
-                }
-            }
-            const long pp = p0 + 32 * mm_ph + mm_li;
-            const bool ok = pp < P;
-            const unsigned pu = (unsigned)(ok ? pp : 0);
-            const unsigned y = pu / (unsigned)img_w, x = pu - y * (unsigned)img_w;
-            const long mt = (long)(y >> 1) * ((img_w + 15) >> 4) + (x >> 4);
-            char* dst0 = reinterpret_cast<char*>(out) + (mt * 4 + 2 * mm_chh) * 2048 + (((y & 1) << 4) | (x & 15)) * 16 + 512 * mm_kg;
-            float amax = 0.f;
-#pragma unroll
-            for (int jp = 0; jp < 2; ++jp) {                 // register pairs (j = 2 jp, 2 jp + 1) -> channels 32 chh + 16 jp + 8 kg + 0..7 of the lane's pixel
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * jp + e]), __float_as_uint(acc[8 * jp + 4 + e]), false, false);
-                    v[e] = __uint_as_float(sw[0]);
-                    v[4 + e] = __uint_as_float(sw[1]);
-                }
-                cer_h2 h[4], l[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {                // packed: relu, scale, clamp, hi = f16(xs), lo = f16(xs - hi) - the VALU form's expressions
-                    amax = fmaxf(amax, fmaxf(v[2 * e], v[2 * e + 1]));
-                    cer_f2 xs = __builtin_elementwise_max((cer_f2){v[2 * e], v[2 * e + 1]}, (cer_f2){0.f, 0.f}) * out_scale;
-                    xs = __builtin_elementwise_min(xs, (cer_f2){65504.0f, 65504.0f});
-                    h[e] = __builtin_convertvector(xs, cer_h2);
-                    l[e] = __builtin_convertvector(xs - __builtin_convertvector(h[e], cer_f2), cer_h2);
-                }
-                if (ok) {
-                    char* dst = dst0 + jp * 2048;            // group 2 chh + jp: hi plane, then lo plane 1 KiB behind
-                    *reinterpret_cast<cer_h8*>(dst) = (cer_h8){h[0].x, h[0].y, h[1].x, h[1].y, h[2].x, h[2].y, h[3].x, h[3].y};
-                    *reinterpret_cast<cer_h8*>(dst + 1024) = (cer_h8){l[0].x, l[0].y, l[1].x, l[1].y, l[2].x, l[2].y, l[3].x, l[3].y};
-                }
-            }
-            if (dl.flag && __ballot(ok && !(amax * out_scale <= 65504.0f)) != 0ull && (threadIdx.x & 63) == 0) atomicOr(dl.flag, 4);
-            continue;
-        }
         if (!active) continue;
         float acc[16];
 #pragma unroll
@@ -476,34 +335,22 @@ extern "C" int cer_lookup_encode_f32(const float* vol, const float* origin, floa
     const int K = num_levels * (2 * radius + 1);
     const long ntiles = (P + LK_PIX - 1) / LK_PIX;
     if (ntiles >= (1L << 30)) return CER_ESHAPE;
-    const int pre = row_stride <= 64 ? 4 : row_stride <= 128 ? 8 : LK_MAX_PRE;      // prefetch registers per thread: which instantiation
-    // round 6: the 1x1 conv on the matrix cores (the model's launches: level-0-only rows up to 64 floats, frag16 output, K <= 48).  CER_LOOKUP_MM=0 keeps the
-    // vector form (A/B runs, tests/test_hip_parity.py::test_lookup_conv_on_matrix_cores)
-    const char* mm_env = getenv("CER_LOOKUP_MM");           // (read per call: a test toggles it inside one process)
-    const bool mm = !(mm_env && mm_env[0] == '0') && pre == 4 && out_split == 2 && K >= 16 && K <= 48;
-    const int ns = (K % 16 == 0 || K % 16 > 4) ? (K + 15) / 16 : K / 16;                    // k16-steps on the matrix cores; up to four columns behind them by fmas
-    const size_t smem = mm ? sizeof(float) * LK_PIX * ((size_t)lk_pitch(row_stride) + 1) + (size_t)LK_PIX * LK_MM_PITCH + 5 * 64 * sizeof(float)
-                           : sizeof(float) * LK_PIX * ((size_t)lk_pitch(row_stride) + (K | 1) + 1) + 64 * sizeof(float);
+    const size_t smem = sizeof(float) * LK_PIX * ((size_t)lk_pitch(row_stride) + (K | 1) + 1);
     const int ncu = cer_num_cus();
     LkDelta dl;
     dl.T = delta_taps; dl.disp_rw = disp; dl.nhalf = delta_nhalf; dl.h = delta_taps ? (int)(P / img_w) : 0; dl.bias = delta_bias;
     dl.flag = out_split == 2 ? cer_overflow_flag_get() : nullptr;
-    const int by_regs = mm ? (ns == 3 ? 3 : LK_OCC_MM) : pre == 4 ? LK_OCC4 : pre == 8 ? 4 : 3;
+    const int pre = row_stride <= 64 ? 4 : row_stride <= 128 ? 8 : LK_MAX_PRE;      // prefetch registers per thread: which instantiation
+    const int by_regs = pre == 4 ? LK_OCC4 : pre == 8 ? 4 : 3;
     const int by_lds = (int)((long)cer_lds_per_cu() / (long)(smem + 256));
     const long resident = (long)ncu * (by_lds < 1 ? 1 : by_lds < by_regs ? by_lds : by_regs);
     const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);
 #define LK_LAUNCH(N) hipLaunchKernelGGL(lookup_encode_kernel<N>, dim3(grid), dim3(256), smem, (hipStream_t)stream, vol, origin, disp, w, b, out, P, D, row_stride, \
                                         (float)incre, num_levels, radius, li, out_split, ldexpf(1.0f, log2s_out), img_w, (int)ntiles, dl)
-#define LK_LAUNCH_MM(NS_) hipLaunchKernelGGL((lookup_encode_kernel<4, NS_>), dim3(grid), dim3(256), smem, (hipStream_t)stream, vol, origin, disp, w, b, out, P, D, row_stride, \
-                               (float)incre, num_levels, radius, li, out_split, ldexpf(1.0f, log2s_out), img_w, (int)ntiles, dl)
-    if (mm && ns == 1) LK_LAUNCH_MM(1);
-    else if (mm && ns == 2) LK_LAUNCH_MM(2);
-    else if (mm) LK_LAUNCH_MM(3);
-    else if (pre == 4) LK_LAUNCH(4);
+    if (pre == 4) LK_LAUNCH(4);
     else if (pre == 8) LK_LAUNCH(8);
     else LK_LAUNCH(LK_MAX_PRE);
 #undef LK_LAUNCH
-#undef LK_LAUNCH_MM
     CER_RETURN_IF_LAUNCH_FAILED();
     return CER_OK;
 }

@@ -248,38 +248,6 @@ def test_lookup_flags_a_saturated_output_itself(dev):
     assert ops.check_overflow(dev) == 0                         # (reading clears it)
 
 
-@pytest.mark.parametrize("h,w", [(9, 21), (40, 150), (7, 64), (296, 400)])
-@pytest.mark.parametrize("spread", [1.0, 1e4, 1e-6])
-def test_lookup_conv_on_matrix_cores(dev, h, w, spread, monkeypatch):
-    """Round 6: the lookup's 1x1 conv (33 -> 64) as bf16 MFMAs on operands split into THREE bf16 pieces (fp32 range, six products: fp32-class) against the
-    vector form (CER_LOOKUP_MM=0: packed fp32 fmas) and an fp64 restatement of the conv on the vector form's own windows.  The correlation values have no
-    bound (spread 1e4: beyond any f16 split; 1e-6: far below its subnormals) - the form must not care.  Disparity update on board, partial tiles, the
-    launch repeated: bit-reproducible."""
-    from cer_mvs_amd import _lib as Lb, ops
-    P, D, L, r, incre = h * w, 64, 3, 5, 0.0025 / 64
-    _, _, rs0 = ops.row_layout(D, L, compact=True)
-    vol = (hashed((P, rs0), 221, -30.0, 30.0) * spread).to(dev)
-    origin = hashed((P,), 222, 0.001, 0.002).to(dev)
-    disp0 = (origin.cpu() + hashed((P,), 223, -30.0, 40.0) * incre).to(dev)
-    T = hashed((2, 9, P), 224, -0.02, 0.02).to(dev)
-    w0t, b0 = (hashed((L * (2 * r + 1), 64), 225, -0.2, 0.2) / spread).to(dev), hashed((64,), 226, -0.1, 0.1).to(dev)
-    run = lambda: (lambda d: (ops.lookup_encode(vol, origin, d, w0t, b0, D, incre, L, r, out_split=2, log2s=Lb.S16_RELU, img_w=w, delta=(T, 0.01)), d))(disp0.clone())
-    monkeypatch.setenv("CER_LOOKUP_MM", "0")
-    f_v, d_v = run()
-    feats = ops.lookup_encode(vol, origin, d_v.clone(), w0t, b0, D, incre, L, r, out_split=0)        # fp32 NHWC relu(conv): the windows are the same code
-    monkeypatch.setenv("CER_LOOKUP_MM", "1")
-    f_m, d_m = run()
-    f_m2, _ = run()
-    assert torch.equal(d_m, d_v) and torch.equal(f_m, f_m2)
-    dec = lambda t: ops.from_frag16(t, h, w, Lb.S16_RELU).cpu().double()
-    a, b = dec(f_m), dec(f_v)
-    assert not torch.equal(f_m, f_v)                            # (a different summation order: the matrix-core form did run)
-    ref = feats.cpu().double()
-    e_m, e_v = rel_l1(a, ref), rel_l1(b, ref)
-    print(f"{h}x{w} spread {spread:g}: matrix-core form {e_m:.2e}, vector form {e_v:.2e} from the fp32 NHWC output; {rel_l1(a, b):.2e} apart")
-    assert e_m < 3e-7 and e_v < 3e-7 and float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
-
-
 @pytest.mark.parametrize("h,w,nhalf", [(9, 21, 2), (40, 150, 2), (7, 64, 1)])
 def test_lookup_applies_the_pending_disparity_update(dev, h, w, nhalf):
     """Round 5: cer_lookup_encode_f32 with delta_taps = the previous iteration's cer_delta_sum_f32 (core/update.py:114, core/raft.py:101)
