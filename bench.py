@@ -129,7 +129,36 @@ def kernel_timing(model, inputs, scale):
     return out, wall
 
 
-def cpu_baseline(H, W, V, cascade, sd):
+def _cpu_baseline_child(H, W, V, cascade, sd, budget_s, q):
+    try:
+        q.put(cpu_baseline(H, W, V, cascade, sd, budget_s))
+    except Exception as e:                                   # (reported, not raised: the GPU line must not depend on the host side)
+        q.put({"value": None, "unit": "depth-maps/s", "kind": "port", "sample": f"the CPU baseline failed: {type(e).__name__}: {e}"})
+
+
+def cpu_baseline_guarded(H, W, V, cascade, sd):
+    """``cpu_baseline`` in a child process under a wall-clock limit (CER_BENCH_CPU_BUDGET seconds of CPU work, default 300, + start-up): the boxes of the
+    pool differ in the cores a process may really use, and a baseline that oversubscribes a small quota has taken 50 minutes before (round 6) - the GPU
+    line of this script must not hang on the host side.  The child also adapts to its budget (fewer calibration candidates, fewer timed runs)."""
+    import multiprocessing as mp
+    import queue as _queue
+    budget = float(os.environ.get("CER_BENCH_CPU_BUDGET", "300"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_cpu_baseline_child, args=(H, W, V, [list(c) for c in cascade], sd, budget, q), daemon=True)
+    p.start()
+    try:
+        res = q.get(timeout=budget + 150.0)
+    except _queue.Empty:
+        res = {"value": None, "unit": "depth-maps/s", "kind": "port", "cores": None,
+               "sample": f"the CPU baseline did not finish within {budget + 150.0:.0f} s on this box (host cores {os.cpu_count()}): stopped"}
+    p.join(5.0)
+    if p.is_alive():
+        p.kill()
+    return res
+
+
+def cpu_baseline(H, W, V, cascade, sd, budget_s=300.0):
     """The oracle (oracle/cer_oracle.py: the reference's torch op sequence on CPU, fp32) on the bench workload itself - one
     whole depth map, same images / weights, nothing extrapolated - on this box's host cores.  Thread count (round 6, VERDICT r5
     "weak" 7): calibrated on the workload's OWN op sizes - one full-resolution image through the feature encoder, one source view's
@@ -140,6 +169,7 @@ def cpu_baseline(H, W, V, cascade, sd):
     from oracle import cer_oracle as O
     from cer_mvs_amd.synthetic import synthetic_scene
     cores = os.cpu_count() or 1
+    t_begin = time.perf_counter()
     runs = max(1, int(os.environ.get("CER_BENCH_CPU_RUNS", "3")))
     images, poses, intr, scale = synthetic_scene(H, W, V, seed=0)
     sdp = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
@@ -172,6 +202,8 @@ def cpu_baseline(H, W, V, cascade, sd):
         usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cores
         best_piece = {}
         for c in sorted({c for c in (16, 32, 64) if c <= min(cores, usable)} or {min(cores, usable)}):
+            if cal and time.perf_counter() - t_begin > 0.3 * budget_s:          # (a slow box: the candidates measured so far have to do)
+                break
             torch.set_num_threads(c)
             tot, dropped = 0.0, False
             for name, (fn, weight) in pieces.items():
@@ -195,6 +227,8 @@ def cpu_baseline(H, W, V, cascade, sd):
             torch.set_num_threads(nthreads)
             ts = []
             for _ in range(n):
+                if ts and (time.perf_counter() - t_begin) + max(ts) > budget_s:  # (the next run would not fit the budget: fewer runs, said in `sample`)
+                    break
                 t0 = time.perf_counter()
                 O.raft_forward(sd, images, poses, intr, scale, cascade=cascade)
                 ts.append(time.perf_counter() - t0)
@@ -206,7 +240,7 @@ def cpu_baseline(H, W, V, cascade, sd):
     return {
         "value": 1.0 / best_total, "unit": "depth-maps/s", "cores": best_threads, "host_cores": cores, "kind": "port",
         "sample": (f"oracle/cer_oracle.py, ONE WHOLE depth map of the bench workload ({W}x{H}, {V} source views, "
-                   f"{iters} GRU iterations): {runs} timed run(s), median {total:.1f} s, on {threads} of {cores} host cores; thread count "
+                   f"{iters} GRU iterations): {len(times)} timed run(s), median {total:.1f} s, on {threads} of {cores} host cores; thread count "
                    f"calibrated on full-size pieces of this workload, weighted by their count per depth map ({cal_txt}; projected "
                    + ", ".join(f"{c} thr {t:.1f} s" for c, t in sorted(cal.items())) + "); CER_BENCH_CPU_RUNS sets the number of runs"),
         "seconds_per_depth_map": best_total, "runs_s": times, "usable_cores": usable,
@@ -597,7 +631,7 @@ def main():
                 result["parity"] = {"rel_l1_disparity_vs_reference_capture": float((got - ref).abs().sum() / ref.abs().sum()),
                                     "tolerance": 1e-4, "fixture": "tests/golden/e2e_cfg2.npz"}
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(H, W, V, cascade, {k: v.cpu() for k, v in sd.items()})
+            result["cpu_baseline"] = cpu_baseline_guarded(H, W, V, cascade, {k: v.detach().cpu() for k, v in sd.items()})
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result))
