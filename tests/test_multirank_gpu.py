@@ -22,6 +22,25 @@ def dev():
     return torch.device("cuda:0")
 
 
+# Collectives of these tests time out after 5 minutes instead of gloo's default 30: one verification run of round 6 sat for 35 minutes in the FIRST
+# two-process test on one box (the same suite had passed on three other boxes the same day; every later multi-process test of that run passed too).
+import datetime
+_PG_TIMEOUT = datetime.timedelta(seconds=300)
+
+
+def _spawn(fn, args, nprocs):
+    """mp.spawn with ONE retry on a fresh port: the transport of these tests (gloo between processes that share one GPU) is test infrastructure -
+    the product's collectives run over RCCL - and a stuck rendezvous / host-staged copy must not be mistaken for a wrong result.  A second failure
+    is a failure; the retry is reported."""
+    try:
+        mp.spawn(fn, args=args, nprocs=nprocs, join=True)
+    except Exception as e:                                   # (ProcessRaisedException / ProcessExitedException)
+        import warnings
+        warnings.warn(f"multi-process test: first attempt failed ({type(e).__name__}: {str(e)[:200]}); retrying once")
+        args = tuple(_free_port() if (isinstance(a, int) and 20000 < a < 65536 and i == 1) else a for i, a in enumerate(args))
+        mp.spawn(fn, args=args, nprocs=nprocs, join=True)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -38,7 +57,7 @@ def _worker(rank, world, port, shard, name, out_path, aggregation=None):
     from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=_PG_TIMEOUT)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     g = np.load(os.path.join(REPO, "tests", "golden", name + ".npz"))
@@ -63,7 +82,7 @@ def _worker(rank, world, port, shard, name, out_path, aggregation=None):
 def test_two_process_sharded_forward(dev, golden, tmp_path, shard, name):
     world = 2
     out_path = str(tmp_path / "disp")
-    mp.spawn(_worker, args=(world, _free_port(), shard, name, out_path), nprocs=world, join=True)
+    _spawn(_worker, (world, _free_port(), shard, name, out_path), world)
     ref = torch.from_numpy(golden(name)["disp"])
     outs = [torch.from_numpy(np.load(f"{out_path}.{r}.npy")) for r in range(world)]
     assert outs[0].shape == ref.shape
@@ -82,7 +101,7 @@ def test_four_process_sharded_forward(dev, golden, tmp_path, shard):
     cost-volume kernel reads through its view -> block map."""
     world, name = 4, "e2e_cfg1"
     out_path = str(tmp_path / "disp")
-    mp.spawn(_worker, args=(world, _free_port(), shard, name, out_path), nprocs=world, join=True)
+    _spawn(_worker, (world, _free_port(), shard, name, out_path), world)
     ref = torch.from_numpy(golden(name)["disp"])
     outs = [torch.from_numpy(np.load(f"{out_path}.{r}.npy")) for r in range(world)]
     errs = [rel_l1(o, ref) for o in outs]
@@ -124,7 +143,7 @@ def test_concurrent_processes_reproduce_the_capture_every_time(dev, tmp_path):
     capture (1e-4) and be bit-identical to the process's first output.  (tools/stress_parity.py is the open-ended form.)"""
     world, n = 2, 30
     out_path = str(tmp_path / "stress")
-    mp.spawn(_stress_worker, args=(world, n, out_path), nprocs=world, join=True)
+    _spawn(_stress_worker, (world, n, out_path), world)
     for r in range(world):
         worst, differs, overflow = np.load(f"{out_path}.{r}.npy")
         assert worst < TOL and differs == 0 and overflow == 0, (r, worst, differs, overflow)
@@ -140,7 +159,7 @@ def test_two_process_literal_forward_with_max_aggregation(dev, golden, tmp_path)
     name, agg = "e2e_tiny", ("mean", "max")
     world = 2
     out_path = str(tmp_path / "disp")
-    mp.spawn(_worker, args=(world, _free_port(), "views", name, out_path, agg), nprocs=world, join=True)
+    _spawn(_worker, (world, _free_port(), "views", name, out_path, agg), world)
     g = golden(name)
     cascade = [tuple(int(x) for x in c) for c in g["cascade"]]
     images, poses, intr, scale = synthetic_scene(int(g["H"]), int(g["W"]), int(g["V"]), seed=int(g["scene_seed"]))
@@ -163,7 +182,7 @@ def _ragged_worker(rank, world, port, shard, H, W, V, out_path):
     from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=_PG_TIMEOUT)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     images, poses, intr, scale = synthetic_scene(H, W, V, seed=31)
@@ -187,7 +206,7 @@ def test_two_process_forward_at_ragged_size(dev, tmp_path, shard, V):
     from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
     H, W, world = 100, 132, 2
     out_path = str(tmp_path / "disp")
-    mp.spawn(_ragged_worker, args=(world, _free_port(), shard, H, W, V, out_path), nprocs=world, join=True)
+    _spawn(_ragged_worker, (world, _free_port(), shard, H, W, V, out_path), world)
     images, poses, intr, scale = synthetic_scene(H, W, V, seed=31)
     model = RAFT(cascade=[(64, 64, 2), (-1, 320, 2)], test_mode=True)
     model.load_state_dict(fill_state_dict(model.state_dict(), seed=12))
@@ -208,7 +227,7 @@ def _worker_pipelined(rank, world, port, shard, name, out_path, streams):
     from cer_mvs_amd.synthetic import fill_state_dict, synthetic_scene
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=_PG_TIMEOUT)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     g = np.load(os.path.join(REPO, "tests", "golden", name + ".npz"))
@@ -243,7 +262,7 @@ def test_two_process_pipelined_sharded_forward(dev, golden, tmp_path, shard):
     two streams, five forwards of the cfg1 capture's input: every result of every rank matches the reference capture."""
     world, streams, name = 2, 2, "e2e_cfg1"
     out_path = str(tmp_path / "disp")
-    mp.spawn(_worker_pipelined, args=(world, _free_port(), shard, name, out_path, streams), nprocs=world, join=True)
+    _spawn(_worker_pipelined, (world, _free_port(), shard, name, out_path, streams), world)
     ref = torch.from_numpy(golden(name)["disp"])
     for r in range(world):
         outs = torch.from_numpy(np.load(f"{out_path}.{r}.npy"))
